@@ -1,0 +1,198 @@
+"""Pins oracle/ (the CPU checker) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.golden_util import CFG2_SEEDS, MISC_SOLVES, MODEL_NAMES, PASS_CASES, cfg2_params, relerr
+
+TOL_PASS = 1e-10   # single pass: summation order differs from BLAS, nothing else
+TOL_SOLVE = 1e-6   # full solve: 1e-13 perturbations grow ~1e5..1e6x through the iterations (hard part 1)
+
+
+def problem_from(z, prefix=""):
+    g = lambda k: z[prefix + k]
+    return orc.Problem(g("model"), g("n_dims"), g("xf"), g("Q"), g("R"), g("Qf"), float(g("radius")), float(g("dt")),
+                       int(g("T")))
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_models_vs_reference(golden, name):
+    z = golden("g1_models"); m = int(z[f"{name}_enum"])
+    for i in range(z[f"{name}_x"].shape[0]):
+        x, u, dt = z[f"{name}_x"][i], z[f"{name}_u"][i], float(z[f"{name}_dt"][i])
+        assert relerr(orc.model_f(m, x, u), z[f"{name}_f"][i]) < 1e-14
+        assert relerr(orc.model_integrate(m, x, u, dt), z[f"{name}_xn"][i]) < 1e-13
+        A, B = orc.model_linearize(m, x, u, dt)
+        assert relerr(A, z[f"{name}_A"][i]) < 1e-14 and relerr(B, z[f"{name}_B"][i]) < 1e-14
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_models_vs_compiled_reference(golden, name):
+    """oracle/_ref = the reference's own bbdynamics.cpp compiled where it lies."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (reference not mounted)")
+    z = golden("g1_models"); m = int(z[f"{name}_enum"])
+    for i in range(z[f"{name}_x"].shape[0]):
+        x, u, dt = z[f"{name}_x"][i], z[f"{name}_u"][i], float(z[f"{name}_dt"][i])
+        np.testing.assert_array_equal(orc.model_integrate(m, x, u, dt, ref=True), z[f"{name}_xn"][i])
+        A, B = orc.model_linearize(m, x, u, dt, ref=True)
+        np.testing.assert_array_equal(A, z[f"{name}_A"][i]); np.testing.assert_array_equal(B, z[f"{name}_B"][i])
+        assert relerr(orc.model_integrate(m, x, u, dt), orc.model_integrate(m, x, u, dt, ref=True)) < 1e-13
+
+
+def test_reference_own_double_int_test(golden):
+    """Inputs of the reference's tests/test_dynamics.py:31-37 (x0, u, dt=0.5).  Its hand-written
+    truth table is wrong as shipped (it forgets the a*dt^2/2 term: 1.25 vs 1.0, outside its own
+    atol=0.1), so the expectation here is the reference MODEL's output on those inputs."""
+    x = np.array([0.0, 2, 0, -2]); u = np.array([0.0, 2.0])
+    for ref_row in golden("g1_models")["DoubleInt4D_reftest_traj"]:
+        assert relerr(x, ref_row) < 1e-13
+        x = orc.model_integrate(0, x, u, 0.5)
+
+
+def test_reference_cost(golden):
+    z = golden("g2_costs")
+    p = orc.Problem([0], [2], z["ref_xf"], z["ref_Q"], z["ref_R"], z["ref_Qf"], 0.5, 0.1, 1)
+    for i in range(4):
+        for term, tag in ((False, "S"), (True, "T")):
+            assert abs(p.cost(z["ref_x"][i], z["ref_u"][i], term) - z[f"ref_cost_{tag}"][i]) < 1e-12
+            q = p.quadraticize(z["ref_x"][i], z["ref_u"][i], term)
+            for got, nm in zip(q, ["Lx", "Lu", "Lxx", "Luu", "Lux"]):
+                assert np.allclose(got, z[f"ref_{nm}_{tag}"][i], rtol=0, atol=1e-12), nm
+
+
+def test_reference_own_cost_test(golden):
+    """tests/test_cost.py:39-78 of the reference (the three tests that pass as shipped)."""
+    z = golden("g2_costs"); x, u = z["reftest_x"], z["reftest_u"]
+    # Car3D has 3 states / 2 controls like the reference test's ad-hoc cost
+    p = orc.Problem([2], [2], np.zeros(3), np.eye(3), np.eye(2), np.diag([1.0, 1, 0]), 0.5, 0.1, 1)
+    assert abs(p.cost(x, u) - (np.sum(x ** 2) + np.sum(u ** 2))) < 1e-12
+    assert abs(p.cost(x, u, True) - np.sum(x[:-1] ** 2)) < 1e-12
+    assert np.allclose([p.cost(x, u), p.cost(x, u, True)], z["reftest_cost"])
+    Lx, Lu, Lxx, Luu, Lux = p.quadraticize(x, u)
+    assert np.allclose(Lx, 2 * x) and np.allclose(Lu, 2 * u) and np.allclose(Lxx, 2 * np.eye(3))
+    assert np.allclose(Luu, 2 * np.eye(2)) and np.allclose(Lux, 0)
+
+
+def test_quadraticize_distance(golden):
+    z = golden("g2_costs")
+    for i in range(6):
+        g, H = orc.quadraticize_distance(z["qd_pa"][i], z["qd_pb"][i], float(z["qd_radius"]), int(z["qd_nd"][i]))
+        assert np.allclose(g, z["qd_Lx"][i], rtol=1e-13, atol=1e-14)
+        assert np.allclose(H, z["qd_Lxx"][i], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("tag,model", [("p2", 0), ("p3", 1), ("pm", 1)])
+def test_proximity_cost(golden, tag, model):
+    z = golden("g2_costs"); ns = orc.MODEL_DIMS[model][0]
+    p = orc.Problem([model] * 3, z[f"{tag}_ndims"], np.zeros(3 * ns), np.eye(ns), np.eye(orc.MODEL_DIMS[model][1]),
+                    np.eye(ns), 0.5, 0.1, 1)
+    for i in range(4):
+        assert abs(p.prox_cost(z[f"{tag}_x"][i]) - z[f"{tag}_cost"][i]) < 1e-13
+        Lx, Lxx = p.prox_quadraticize(z[f"{tag}_x"][i])
+        assert np.allclose(Lx, z[f"{tag}_Lx"][i], rtol=1e-12, atol=1e-13)
+        assert np.allclose(Lxx, z[f"{tag}_Lxx"][i], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_game_cost(golden, k):
+    z = golden("g2_costs")
+    p = orc.Problem([0] * k, [2] * k, z[f"gc{k}_xf"], np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, 1)
+    for i in range(3):
+        for term, tag in ((False, "S"), (True, "T")):
+            x, u = z[f"gc{k}_x"][i], z[f"gc{k}_u"][i]
+            assert abs(p.cost(x, u, term) - z[f"gc{k}_cost_{tag}"][i]) < 1e-10 * max(1, abs(z[f"gc{k}_cost_{tag}"][i]))
+            q = p.quadraticize(x, u, term)
+            for got, nm in zip(q, ["Lx", "Lu", "Lxx", "Luu", "Lux"]):
+                ref = z[f"gc{k}_{nm}_{tag}"][i]
+                assert np.allclose(got, ref, rtol=1e-12, atol=1e-10), (nm, tag)
+
+
+@pytest.mark.parametrize("case", PASS_CASES)
+def test_passes(golden, case):
+    z = golden(f"g3_passes_{case}")
+    p = problem_from(z)
+    X, J = p.rollout(z["x0"], z["U0"])
+    assert relerr(X, z["X_roll"]) < 1e-12 and abs(J - z["J_roll"]) < 1e-11 * abs(z["J_roll"])
+    # tiles (the plugin contract) at the operating point
+    T = int(z["T"])
+    for t in (0, T // 2, T - 1):
+        A, B = p.linearize(z["X"][t], z["U"][t])
+        assert relerr(A, z["tile_A"][t]) < 1e-14 and relerr(B, z["tile_B"][t]) < 1e-14
+        q = p.quadraticize(z["X"][t], z["U"][t])
+        for got, nm in zip(q, ["Lx", "Lu", "Lxx", "Luu", "Lux"]):
+            assert np.allclose(got, z[f"tile_{nm}"][t], rtol=1e-11, atol=1e-9), nm
+    K, d = p.backward_pass(z["X"], z["U"], float(z["mu"]))
+    assert relerr(K, z["K"]) < TOL_PASS and relerr(d, z["d"]) < TOL_PASS
+    K2, d2 = orc.backward_pass_tiles(z["tile_A"], z["tile_B"], z["tile_Lx"], z["tile_Lu"], z["tile_Lxx"],
+                                     z["tile_Luu"], z["tile_Lux"], float(z["mu"]))
+    assert relerr(K2, z["K"]) < TOL_PASS and relerr(d2, z["d"]) < TOL_PASS
+    assert np.array_equal(orc.alphas(), z["alphas"])
+    for a in range(10):
+        Xn, Un, Jn = p.forward_pass(z["X"], z["U"], z["K"], z["d"], z["alphas"][a])
+        assert relerr(Xn, z["X_fwd"][a]) < TOL_PASS and relerr(Un, z["U_fwd"][a]) < TOL_PASS
+        assert abs(Jn - z["J_fwd"][a]) < 1e-10 * abs(z["J_fwd"][a])
+
+
+def check_solve(r, z, pre):
+    nb = len(z[pre + "mu_trace"])
+    assert r["n_bwd"] == nb, "number of backward passes differs"
+    tr = r["trace"]
+    np.testing.assert_array_equal(tr[:, 0], z[pre + "mu_trace"])
+    np.testing.assert_array_equal(tr[:, 1].astype(int), z[pre + "acc_trace"])   # decision trace
+    np.testing.assert_array_equal(tr[:, 4].astype(int), z[pre + "nfwd_trace"])
+    assert relerr(tr[:, 2], z[pre + "Jlast_trace"]) < TOL_SOLVE
+    assert relerr(r["X"], z[pre + "X"]) < TOL_SOLVE and relerr(r["U"], z[pre + "U"]) < TOL_SOLVE
+    assert abs(r["J"] - z[pre + "J"]) < TOL_SOLVE * abs(z[pre + "J"])
+
+
+@pytest.mark.parametrize("seed", CFG2_SEEDS)
+def test_solve_cfg2(golden, seed):
+    z = golden("g4_solves_cfg2"); c = cfg2_params()
+    p = orc.Problem(c["model"], c["n_dims"], z[f"s{seed}_xf"], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    r = p.solve(z[f"s{seed}_x0"], np.zeros((50, 10)))
+    check_solve(r, z, f"s{seed}_")
+    last = int(z[f"s{seed}_acc_trace"][-1])
+    assert r["status"] == (2 if last < 0 else 1)
+
+
+@pytest.mark.parametrize("tag", MISC_SOLVES)
+def test_solve_misc(golden, tag):
+    z = golden("g4_solves_misc")
+    p = problem_from(z, tag + "_")
+    r = p.solve(z[tag + "_x0"], z[tag + "_U0"])
+    check_solve(r, z, tag + "_")
+
+
+@pytest.mark.parametrize("tag", ["uni5", "quad10", "uni8"])
+def test_dispatch(golden, tag):
+    z = golden("g5_dispatch")
+    p = problem_from(z, tag + "_")
+    k, ns = p.k, p.n_s
+    g = orc.define_inter_graph_threshold(z[tag + "_x0"].reshape(1, -1), 0.5, k, ns)
+    adj = np.zeros((k, k), dtype=np.int32)
+    for i, nb in g.items():
+        adj[i, nb] = 1
+    np.testing.assert_array_equal(adj, z[tag + "_adj_x0"])
+    g2 = orc.define_inter_graph_threshold(z[tag + "_X_dec"], 0.5, k, ns)
+    adj2 = np.zeros((k, k), dtype=np.int32)
+    for i, nb in g2.items():
+        adj2[i, nb] = 1
+    np.testing.assert_array_equal(adj2, z[tag + "_adj_traj"])
+    if tag == "quad10":
+        return  # the solve itself is covered by the two unicycle cases (keeps the CPU suite short)
+    Xd, Ud, Jf, _ = orc.solve_distributed(p, z[tag + "_x0"].reshape(1, -1), z[tag + "_U0"], 0.5)
+    assert relerr(Xd, z[tag + "_X_dec"]) < TOL_SOLVE and relerr(Ud, z[tag + "_U_dec"]) < TOL_SOLVE
+    assert abs(Jf - z[tag + "_J_full"]) < TOL_SOLVE * abs(z[tag + "_J_full"])
+
+
+def test_solve_batch_matches_single(golden):
+    z = golden("g4_solves_cfg2"); c = cfg2_params()
+    seeds = [0, 17, 2]
+    x0 = np.array([z[f"s{s}_x0"] for s in seeds]); xf = np.array([z[f"s{s}_xf"] for s in seeds])
+    proto = orc.Problem(c["model"], c["n_dims"], xf[0], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    r = orc.solve_batch(proto, x0, xf, np.zeros((3, 50, 10)), n_threads=2)
+    for i, s in enumerate(seeds):
+        assert relerr(r["X"][i], z[f"s{s}_X"]) < TOL_SOLVE
+        assert r["n_bwd"][i] == len(z[f"s{s}_mu_trace"])
