@@ -1,0 +1,111 @@
+"""ctypes binding of libdpilqr_hip.so (include/dpilqr_hip.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared object is missing, or no
+gfx950 device is visible when a compute entry point is called, this module raises.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libdpilqr_hip.so"
+
+i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
+
+OK, EINVAL, EUNSUPPORTED, EHIP, ENOGPU, EWORKSPACE = 0, -1, -2, -3, -4, -5
+N_ALPHA = 10
+STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STATUS_SINGULAR = 0, 1, 2, 3, 4
+
+
+class BatchDesc(C.Structure):
+    """struct dpilqr_batch_desc"""
+    _fields_ = [("B", i32), ("k", i32), ("n_s", i32), ("n_c", i32), ("T", i32), ("reserved", i32),
+                ("dt", f64), ("w_ref", f64), ("w_prox", f64),
+                ("model", vp), ("model_bstride", i64), ("n_dims", vp), ("n_dims_bstride", i64),
+                ("xf", vp), ("xf_bstride", i64), ("Q", vp), ("Q_bstride", i64), ("R", vp), ("R_bstride", i64),
+                ("Qf", vp), ("Qf_bstride", i64), ("radius", vp), ("radius_bstride", i64)]
+
+
+class DpilqrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdpilqr_hip error {code}: {msg}")
+        self.code = code
+
+
+# name -> (restype, argtypes); every symbol include/dpilqr_hip.h declares
+_DP = C.POINTER(BatchDesc)
+SIGNATURES = {
+    "dpilqr_abi_version": (i32, []),
+    "dpilqr_last_error": (C.c_char_p, []),
+    "dpilqr_device_info": (i32, [i32, C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    "dpilqr_model_dims": (i32, [i32, C.POINTER(i32), C.POINTER(i32)]),
+    "dpilqr_model_f": (i32, [i32, i32, vp, vp, vp, vp, vp]),
+    "dpilqr_model_integrate": (i32, [i32, i32, vp, vp, vp, f64, vp, vp]),
+    "dpilqr_model_linearize": (i32, [i32, i32, vp, vp, vp, f64, vp, vp, vp]),
+    "dpilqr_cost_eval": (i32, [_DP, i32, vp, vp, i32, vp, vp]),
+    "dpilqr_tile_layout": (i32, [i32, i32, C.POINTER(i64 * 7), C.POINTER(i64)]),
+    "dpilqr_make_tiles": (i32, [_DP, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_rollout": (i32, [_DP, vp, vp, vp, vp, vp]),
+    "dpilqr_backward_pass_tiles": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_tiles_bytes": (i64, [i32, i32, i32, i32]),
+    "dpilqr_backward_pass": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_forward_pass": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "dpilqr_alphas": (i32, [C.POINTER(f64 * N_ALPHA)]),
+    "dpilqr_solve_workspace_bytes": (i64, [_DP]),
+    "dpilqr_solve_batch": (i32, [_DP, vp, vp, i32, f64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdpilqr_hip.so; raises if it has not been built (run `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  dpilqr_amd has no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dpilqr_abi_version() != 1:
+            raise ImportError("libdpilqr_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise DpilqrError(rc, load().dpilqr_last_error().decode())
+    return rc
+
+
+def alphas():
+    a = (f64 * N_ALPHA)()
+    check(load().dpilqr_alphas(C.byref(a)))
+    return list(a)
+
+
+def tile_layout(n_x, n_u):
+    off = (i64 * 7)()
+    stride = i64(0)
+    check(load().dpilqr_tile_layout(n_x, n_u, C.byref(off), C.byref(stride)))
+    return dict(zip(["A", "B", "Lxx", "Lux", "Luu", "Lx", "Lu"], list(off))), stride.value
+
+
+_device_ok = None
+
+
+def require_gpu():
+    """Raise unless a gfx950 device is usable through both torch and the HIP library."""
+    global _device_ok
+    if _device_ok is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise DpilqrError(ENOGPU, "torch.cuda.is_available() is False: dpilqr_amd needs an MI355X (no CPU fallback)")
+        check(load().dpilqr_device_info(torch.cuda.current_device(), None, None, None, 0))
+        _device_ok = True
+    return True

@@ -1,0 +1,197 @@
+"""Batched device solver: the lowering target of ilqrProblem and the one-launch-per-pass API.
+
+A `ProblemBatch` is B sub-problems of one shape (k agents x (n_s, n_c), horizon T) held as device
+tensors behind a `dpilqr_batch_desc` (include/dpilqr_hip.h).  It replaces the reference's per-problem
+Python objects on the hot path:
+
+    ilqrSolver._rollout        control.py:80-93    -> ProblemBatch.rollout
+    ilqrSolver._backward_pass  control.py:116-148  -> ProblemBatch.make_tiles + backward_pass_tiles
+    ilqrSolver._forward_pass   control.py:95-114   -> ProblemBatch.forward_pass
+    ilqrSolver.solve           control.py:150-225  -> ProblemBatch.solve
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import device, empty, ptr, stream_handle, to_dev, zeros
+
+MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 6: (6, 3), 7: (12, 4)}
+
+
+def _shared_or_batched(a, B, per_item_shape, dtype):
+    """Returns (device tensor, batch stride in elements): stride 0 when one copy serves the batch."""
+    a = np.asarray(a)
+    per = int(np.prod(per_item_shape))
+    if a.size == per:
+        return to_dev(a.reshape(per_item_shape), dtype), 0
+    if a.size == B * per:
+        return to_dev(a.reshape((B,) + tuple(per_item_shape)), dtype), per
+    raise ValueError(f"expected {per_item_shape} or {(B,) + tuple(per_item_shape)}, got {a.shape}")
+
+
+class ProblemBatch:
+    """B independent sub-problems with identical (k, n_s, n_c, T), resident in HBM.
+
+    model, n_dims : (k,) shared or (B,k) per item     xf : (B, k*n_s)
+    Q, Qf : (n_s,n_s) | (k,n_s,n_s) | (B,k,n_s,n_s)   R likewise with n_c     radius : scalar | (B,)
+    """
+
+    def __init__(self, model, n_dims, xf, Q, R, Qf, radius, dt, T, w_ref=1.0, w_prox=200.0, B=None):
+        lib = _lib.load()
+        xf = np.asarray(xf, dtype=np.float64)
+        model = np.asarray(model, dtype=np.int32)
+        self.k = int(model.shape[-1])
+        m0 = int(model.reshape(-1)[0])
+        self.n_s, self.n_c = MODEL_DIMS[m0]
+        if any(MODEL_DIMS[int(v)] != (self.n_s, self.n_c) for v in np.unique(model)):
+            raise ValueError("all agents of a batch must share (n_s, n_c) -- the reference assumes it too "
+                             "(dynamics.py:165-166)")
+        self.n_x, self.n_u = self.k * self.n_s, self.k * self.n_c
+        xf = xf.reshape(-1, self.n_x)
+        self.B = int(B if B is not None else xf.shape[0])
+        self.T, self.dt = int(T), float(dt)
+        self.w_ref, self.w_prox = float(w_ref), float(w_prox)
+        B_, k, ns, nc = self.B, self.k, self.n_s, self.n_c
+
+        def expand(M, n):  # (n,n) -> (k,n,n)
+            M = np.asarray(M, dtype=np.float64)
+            return np.broadcast_to(M, (k, n, n)) if M.ndim == 2 else M
+
+        self._model, ms = _shared_or_batched(model, B_, (k,), torch.int32)
+        self._n_dims, ds = _shared_or_batched(np.asarray(n_dims, dtype=np.int32), B_, (k,), torch.int32)
+        self._xf, xs = _shared_or_batched(xf, B_, (self.n_x,), torch.float64)
+        if xf.shape[0] == 1 and B_ > 1:
+            xs = 0
+        self._Q, qs = _shared_or_batched(expand(Q, ns), B_, (k, ns, ns), torch.float64)
+        self._R, rs = _shared_or_batched(expand(R, nc), B_, (k, nc, nc), torch.float64)
+        self._Qf, fs = _shared_or_batched(expand(Qf, ns), B_, (k, ns, ns), torch.float64)
+        self._radius, ras = _shared_or_batched(np.asarray(radius, dtype=np.float64), B_, (1,), torch.float64)
+        self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, 0, self.dt, self.w_ref, self.w_prox,
+                                   ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
+                                   ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
+        self._lib = lib
+        self._ws = None
+        self.tile_offsets, self.tile_stride = _lib.tile_layout(self.n_x, self.n_u)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def _d(self):
+        return C.byref(self.desc)
+
+    def tiles_buffer(self):
+        return empty((self.B, self.T + 1, self.tile_stride))
+
+    def _in(self, a, shape):
+        t = to_dev(a)
+        if tuple(t.shape) != tuple(shape):
+            t = t.reshape(shape)
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ passes
+    def rollout(self, x0, U):
+        """control.py:80-93 for every item: returns X (B,T+1,n_x), J (B,) device tensors."""
+        x0 = self._in(x0, (self.B, self.n_x)); U = self._in(U, (self.B, self.T, self.n_u))
+        X = empty((self.B, self.T + 1, self.n_x)); J = empty((self.B,))
+        _lib.check(self._lib.dpilqr_rollout(self._d, ptr(x0), ptr(U), ptr(X), ptr(J), stream_handle()))
+        return X, J
+
+    def make_tiles(self, X, U, tiles=None):
+        """linearize + quadraticize at every (X[t],U[t]) -> packed tile records (B,T+1,stride)."""
+        X = self._in(X, (self.B, self.T + 1, self.n_x)); U = self._in(U, (self.B, self.T, self.n_u))
+        tiles = self.tiles_buffer() if tiles is None else tiles
+        _lib.check(self._lib.dpilqr_make_tiles(self._d, ptr(X), ptr(U), ptr(tiles), None, None, stream_handle()))
+        return tiles
+
+    def unpack_tiles(self, tiles):
+        """Tile records -> dict of host arrays shaped like the plugin returns (per item, per step)."""
+        t = tiles.cpu().numpy(); o = self.tile_offsets; n, m = self.n_x, self.n_u
+        cut = lambda key, size, shape: t[:, :, o[key]:o[key] + size].reshape((self.B, self.T + 1) + shape)
+        return dict(A=cut("A", n * n, (n, n)), B=cut("B", n * m, (n, m)), Lxx=cut("Lxx", n * n, (n, n)),
+                    Lux=cut("Lux", m * n, (m, n)), Luu=cut("Luu", m * m, (m, m)), Lx=cut("Lx", n, (n,)),
+                    Lu=cut("Lu", m, (m,)))
+
+    def backward_pass(self, X, U, mu, tiles=None):
+        """control.py:116-148: K (B,T,n_u,n_x), d (B,T,n_u)."""
+        tiles = self.make_tiles(X, U, tiles)
+        return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu)
+
+    def forward_pass(self, X, U, K, d, alphas):
+        """control.py:95-114 for all alphas: Xn (B,A,T+1,n_x), Un (B,A,T,n_u), Jn (B,A)."""
+        X = self._in(X, (self.B, self.T + 1, self.n_x)); U = self._in(U, (self.B, self.T, self.n_u))
+        K = self._in(K, (self.B, self.T, self.n_u, self.n_x)); d = self._in(d, (self.B, self.T, self.n_u))
+        al = to_dev(np.asarray(alphas, dtype=np.float64)); A = int(al.numel())
+        Xn = empty((self.B, A, self.T + 1, self.n_x)); Un = empty((self.B, A, self.T, self.n_u)); Jn = empty((self.B, A))
+        _lib.check(self._lib.dpilqr_forward_pass(self._d, ptr(X), ptr(U), ptr(K), ptr(d), ptr(al), A, ptr(Xn),
+                                                 ptr(Un), ptr(Jn), stream_handle()))
+        return Xn, Un, Jn
+
+    def cost(self, x, u, terminal=False):
+        """GameCost.__call__ at n_pts points per item: x (B,n_pts,n_x), u (B,n_pts,n_u) -> (B,n_pts)."""
+        x = to_dev(x).reshape(self.B, -1, self.n_x).contiguous()
+        n_pts = x.shape[1]
+        u = to_dev(u).reshape(self.B, n_pts, self.n_u).contiguous()
+        out = empty((self.B, n_pts))
+        _lib.check(self._lib.dpilqr_cost_eval(self._d, n_pts, ptr(x), ptr(u), int(bool(terminal)), ptr(out),
+                                              stream_handle()))
+        return out
+
+    # ------------------------------------------------------------------ whole solve
+    def workspace(self):
+        if self._ws is None:
+            nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d)
+            _lib.check(nbytes)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device())
+        return self._ws
+
+    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False):
+        """ilqrSolver.solve (control.py:150-225) for all B items at once.
+
+        Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
+        """
+        B, T, n, m = self.B, self.T, self.n_x, self.n_u
+        x0 = self._in(x0, (B, n))
+        U = self._in(U0, (B, T, m)).clone()
+        X = empty((B, T + 1, n)); J = empty((B,))
+        status = empty((B,), torch.int32); n_bwd = empty((B,), torch.int32); n_fwd = empty((B,), torch.int32)
+        tr = torch.full((B, max(n_lqr_iter, 1), 5), float("nan"), dtype=torch.float64, device=device()) if trace else None
+        K = empty((B, T, m, n)) if gains else None
+        d = empty((B, T, m)) if gains else None
+        ws = self.workspace()
+        _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), ptr(ws),
+                                                ws.numel(), ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd),
+                                                ptr(tr), ptr(K), ptr(d), stream_handle()))
+        out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
+        if trace:
+            out["trace"] = tr
+        if gains:
+            out["K"], out["d"] = K, d
+        return out
+
+
+def backward_pass_tiles(tiles, B, T, n_x, n_u, mu, singular=None):
+    """The Riccati sweep on explicit tile records -- the plugin contract (any linearize/quadraticize)."""
+    lib = _lib.load()
+    mu_t = to_dev(np.broadcast_to(np.asarray(mu, dtype=np.float64), (B,))) if not isinstance(mu, torch.Tensor) else mu
+    K = empty((B, T, n_u, n_x)); d = empty((B, T, n_u))
+    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, n_x, n_u, ptr(tiles), ptr(mu_t), ptr(K), ptr(d), ptr(singular),
+                                              None, None, stream_handle()))
+    return K, d
+
+
+def pack_tiles(A, Bm, Lx, Lu, Lxx, Luu, Lux):
+    """Host plugin outputs -> device tile records.
+
+    A (B,T,n,n), Bm (B,T,n,m); Lx (B,T+1,n), Lu (B,T+1,m), Lxx (B,T+1,n,n), Luu (B,T+1,m,m),
+    Lux (B,T+1,m,n), entry T being the terminal quadraticisation.
+    """
+    A = np.asarray(A, dtype=np.float64); Bm = np.asarray(Bm, dtype=np.float64)
+    Bn, T, n, m = Bm.shape
+    off, stride = _lib.tile_layout(n, m)
+    rec = np.zeros((Bn, T + 1, stride))
+    rec[:, :T, off["A"]:off["A"] + n * n] = A.reshape(Bn, T, -1)
+    rec[:, :T, off["B"]:off["B"] + n * m] = Bm.reshape(Bn, T, -1)
+    for key, arr, size in (("Lxx", Lxx, n * n), ("Lux", Lux, m * n), ("Luu", Luu, m * m), ("Lx", Lx, n), ("Lu", Lu, m)):
+        rec[:, :, off[key]:off[key] + size] = np.asarray(arr, dtype=np.float64).reshape(Bn, T + 1, size)
+    return to_dev(rec)

@@ -1,0 +1,430 @@
+// dpilqr_hip.hip -- C ABI (include/dpilqr_hip.h) over the gfx950 kernels.
+//
+// Host side of libdpilqr_hip.so: argument validation, kernel dispatch by per-agent dimension family,
+// and the device-resident iLQR iteration loop (ilqrSolver.solve, control.py:150-225).
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -shared -fPIC ...
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "dpilqr_hip.h"
+#include "forward.hpp"
+#include "models.hpp"
+#include "riccati.hpp"
+#include "tiles.hpp"
+
+using namespace dpilqr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(DPILQR_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+constexpr int kMaxAgents = 64;
+
+int family_nc(int ns) { return ns == 3 ? 2 : ns == 4 ? 2 : ns == 6 ? 3 : ns == 12 ? 4 : -1; }
+
+int32_t check_desc(const dpilqr_batch_desc* d) {
+    if (!d) return fail(DPILQR_EINVAL, "desc is NULL");
+    if (d->B < 0 || d->k < 1 || d->T < 1) return fail(DPILQR_EINVAL, "bad sizes B=%d k=%d T=%d", d->B, d->k, d->T);
+    if (d->k > kMaxAgents) return fail(DPILQR_EUNSUPPORTED, "k=%d agents per sub-problem exceeds %d", d->k, kMaxAgents);
+    if (family_nc(d->n_s) != d->n_c)
+        return fail(DPILQR_EINVAL, "(n_s,n_c)=(%d,%d) is not a model family; expected (3,2),(4,2),(6,3),(12,4)", d->n_s, d->n_c);
+    if (!d->model || !d->n_dims || !d->xf || !d->Q || !d->R || !d->Qf || !d->radius)
+        return fail(DPILQR_EINVAL, "desc holds a NULL device pointer");
+    return DPILQR_OK;
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename Kern>
+int32_t allow_lds(Kern kern, size_t bytes) {
+    if (bytes > (size_t)kMaxLds) return fail(DPILQR_EUNSUPPORTED, "needs %zu B of LDS per workgroup (> %d)", bytes, kMaxLds);
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DPILQR_OK;
+}
+
+// run `body` with the (NS,NC) family as compile-time constants
+#define DISPATCH_FAMILY(ns, BODY)                                                         \
+    switch (ns) {                                                                         \
+    case 3:  { constexpr int NS = 3,  NC = 2; BODY } break;                               \
+    case 4:  { constexpr int NS = 4,  NC = 2; BODY } break;                               \
+    case 6:  { constexpr int NS = 6,  NC = 3; BODY } break;                               \
+    case 12: { constexpr int NS = 12, NC = 4; BODY } break;                               \
+    default: return fail(DPILQR_EINVAL, "unsupported per-agent state dim %d", (int)(ns)); \
+    }
+
+int riccati_threads(int n) { return n <= 24 ? 64 : (n <= 36 ? 128 : 256); }
+
+int forward_threads(int k, int ngrp) {
+    const int t = ((k * ngrp + 63) / 64) * 64;
+    return t;
+}
+
+int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
+                          const int32_t* items, const int32_t* n_items, int grid_items, hipStream_t st) {
+    if (grid_items <= 0) return DPILQR_OK;
+    const size_t lds = make_tiles_lds_bytes(D.k, D.n_s, D.n_c);
+    dim3 grid(D.T + 1, grid_items);
+    DISPATCH_FAMILY(D.n_s, {
+        int32_t rc = allow_lds(k_make_tiles<NS, NC>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_make_tiles<NS, NC>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items);
+    })
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
+                       int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
+                       hipStream_t st) {
+    if (grid_items <= 0) return DPILQR_OK;
+    const size_t lds = riccati_lds_bytes(n, m);
+    int32_t rc = allow_lds(k_riccati_generic, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_riccati_generic, dim3(grid_items), dim3(riccati_threads(n)), lds, st, B, T, n, m, tiles, mu, K,
+                       d, singular, items, n_items);
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
+                       const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
+                       const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
+                       hipStream_t st) {
+    if (grid_items <= 0) return DPILQR_OK;
+    const int n = D.k * D.n_s, m = D.k * D.n_c;
+    const int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
+    if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
+    const size_t lds = forward_lds_bytes(n, m, D.k, ngrp);
+    DISPATCH_FAMILY(D.n_s, {
+        int32_t rc = allow_lds(k_forward<NS, NC>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_forward<NS, NC>), dim3(grid_items), dim3(threads), lds, st, D, mode, x0, X, U, K, d, alphas,
+                           ngrp, Xc, Uc, Jc, S, items, n_items);
+    })
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+// float32-rounded table of control.py:162 (quirk Q1), bit patterns of 1.1 ** (-arange(10, f32) ** 2)
+void alpha_table(double* a) {
+    static const uint32_t bits[DPILQR_N_ALPHA] = {0x3f800000u, 0x3f68ba2eu, 0x3f2ed9f7u, 0x3ed92350u, 0x3e5eda27u,
+                                                  0x3dbd05a8u, 0x3d04808du, 0x3c19864au, 0x3b13029cu, 0x39e8ae70u};
+    for (int i = 0; i < DPILQR_N_ALPHA; ++i) {
+        float f;
+        memcpy(&f, &bits[i], 4);
+        a[i] = (double)f;
+    }
+}
+
+__global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, int32_t* n_bwd, int32_t* n_fwd,
+                             int32_t* singular, int32_t* counts, int n_counts, double* alphas_dev, double a0, double a1,
+                             double a2, double a3, double a4, double a5, double a6, double a7, double a8, double a9) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {  // _reset_regularization, control.py:227-230
+        mu[i] = 1.0; delta[i] = 2.0; status[i] = DPILQR_STATUS_ACTIVE; n_bwd[i] = 0; n_fwd[i] = 0; singular[i] = 0;
+    }
+    if (i < n_counts) counts[i] = (i == 0) ? B : 0;
+    if (i == 0) {
+        alphas_dev[0] = a0; alphas_dev[1] = a1; alphas_dev[2] = a2; alphas_dev[3] = a3; alphas_dev[4] = a4;
+        alphas_dev[5] = a5; alphas_dev[6] = a6; alphas_dev[7] = a7; alphas_dev[8] = a8; alphas_dev[9] = a9;
+    }
+}
+
+__global__ void k_copy_f64(int n, const double* src, double* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+__global__ void k_finish_status(int B, int32_t* status) {  // n_lqr_iter == 0: nothing ran
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B && status[i] == DPILQR_STATUS_ACTIVE) status[i] = DPILQR_STATUS_MAX_ITER;
+}
+
+struct SolveWorkspace {
+    size_t tiles, K, d, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
+    SolveWorkspace(const dpilqr_batch_desc& D, int n_lqr_iter_max) {
+        const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T;
+        const TileLayout L((int)n, (int)m);
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        size_t o = 0;
+        tiles = o;    o = al(o + sizeof(double) * B * (T + 1) * L.stride);
+        K = o;        o = al(o + sizeof(double) * B * T * m * n);
+        d = o;        o = al(o + sizeof(double) * B * T * m);
+        mu = o;       o = al(o + sizeof(double) * B);
+        delta = o;    o = al(o + sizeof(double) * B);
+        J_star = o;   o = al(o + sizeof(double) * B);
+        J_last = o;   o = al(o + sizeof(double) * B);
+        alphas = o;   o = al(o + sizeof(double) * DPILQR_N_ALPHA);
+        singular = o; o = al(o + sizeof(int32_t) * B);
+        lists = o;    o = al(o + sizeof(int32_t) * 2 * B);
+        counts = o;   o = al(o + sizeof(int32_t) * (n_lqr_iter_max + 2));
+        total = o;
+    }
+};
+constexpr int kMaxLqrIter = 4096;
+
+struct Mailbox {  // pinned host words the device-side active counters are copied into
+    int32_t* host = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~Mailbox() {
+        if (host) (void)hipHostFree(host);
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+thread_local Mailbox g_mail;
+
+}  // namespace
+
+extern "C" {
+
+int32_t dpilqr_abi_version(void) { return DPILQR_ABI_VERSION; }
+const char* dpilqr_last_error(void) { return g_err; }
+
+int32_t dpilqr_device_info(int32_t dev, int32_t* n_cu, int32_t* lds_bytes, char* arch, int32_t arch_len) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(DPILQR_ENOGPU, "no HIP device visible");
+    if (dev < 0 || dev >= count) return fail(DPILQR_EINVAL, "device %d out of range (%d visible)", dev, count);
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(DPILQR_ENOGPU, "device %d is %s; this library is built for gfx950 only", dev, p.gcnArchName);
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_model_dims(int32_t model, int32_t* n_s, int32_t* n_c) {
+    if (model < 0 || model >= kNumModels || !n_s || !n_c) return fail(DPILQR_EINVAL, "unknown model %d", model);
+    *n_s = model_ns(model);
+    *n_c = model_nc(model);
+    return DPILQR_OK;
+}
+
+static int32_t model_op(int op, int32_t n, int32_t ns, const int32_t* model, const double* x, const double* u, double dt,
+                        double* o1, double* o2, void* stream) {
+    if (n < 0 || !model || !x || !u || !o1 || (op == 2 && !o2)) return fail(DPILQR_EINVAL, "model op: bad argument");
+    if (n == 0) return DPILQR_OK;
+    const dim3 grid((n + 63) / 64), block(64);
+    DISPATCH_FAMILY(ns, {
+        if (op == 0) hipLaunchKernelGGL((k_model_op<NS, NC, 0>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
+        else if (op == 1) hipLaunchKernelGGL((k_model_op<NS, NC, 1>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
+        else hipLaunchKernelGGL((k_model_op<NS, NC, 2>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
+    })
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_model_f(int32_t n, int32_t family_ns, const int32_t* model, const double* x, const double* u,
+                       double* x_dot, void* stream) {
+    return model_op(0, n, family_ns, model, x, u, 0.0, x_dot, nullptr, stream);
+}
+int32_t dpilqr_model_integrate(int32_t n, int32_t family_ns, const int32_t* model, const double* x, const double* u,
+                               double dt, double* x_new, void* stream) {
+    return model_op(1, n, family_ns, model, x, u, dt, x_new, nullptr, stream);
+}
+int32_t dpilqr_model_linearize(int32_t n, int32_t family_ns, const int32_t* model, const double* x, const double* u,
+                               double dt, double* A, double* B, void* stream) {
+    return model_op(2, n, family_ns, model, x, u, dt, A, B, stream);
+}
+
+int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const double* x, const double* u,
+                         int32_t terminal, double* cost, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (n_pts < 0 || !x || !u || !cost) return fail(DPILQR_EINVAL, "cost_eval: bad argument");
+    const int64_t total = (int64_t)desc->B * n_pts;
+    if (total == 0) return DPILQR_OK;
+    const dim3 grid((unsigned)((total + 63) / 64)), block(64);
+    DISPATCH_FAMILY(desc->n_s, {
+        hipLaunchKernelGGL((k_cost_eval<NS, NC>), grid, block, 0, as_stream(stream), *desc, n_pts, x, u, terminal, cost);
+    })
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t* stride) {
+    if (n_x < 1 || n_u < 1 || !offsets || !stride) return fail(DPILQR_EINVAL, "tile_layout: bad argument");
+    const TileLayout L(n_x, n_u);
+    offsets[0] = L.oA; offsets[1] = L.oB; offsets[2] = L.oLxx; offsets[3] = L.oLux; offsets[4] = L.oLuu;
+    offsets[5] = L.oLx; offsets[6] = L.oLu;
+    *stride = L.stride;
+    return DPILQR_OK;
+}
+
+int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u) {
+    if (B < 0 || T < 1 || n_x < 1 || n_u < 1) return fail(DPILQR_EINVAL, "tiles_bytes: bad argument");
+    return (int64_t)sizeof(double) * B * (T + 1) * TileLayout(n_x, n_u).stride;
+}
+
+int32_t dpilqr_make_tiles(const dpilqr_batch_desc* desc, const double* X, const double* U, double* tiles,
+                          const int32_t* items, const int32_t* n_items, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (!X || !U || !tiles) return fail(DPILQR_EINVAL, "make_tiles: NULL pointer");
+    return launch_make_tiles(*desc, X, U, tiles, items, n_items, desc->B, as_stream(stream));
+}
+
+int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const double* U, double* X, double* J,
+                       void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (!x0 || !U || !X || !J) return fail(DPILQR_EINVAL, "rollout: NULL pointer");
+    SolveState S{};
+    return launch_forward(*desc, kModeRollout, x0, X, const_cast<double*>(U), nullptr, nullptr, nullptr, 1, nullptr,
+                          nullptr, J, S, nullptr, nullptr, desc->B, as_stream(stream));
+}
+
+int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_u, const double* tiles,
+                                   const double* mu, double* K, double* d, int32_t* singular, const int32_t* items,
+                                   const int32_t* n_items, void* stream) {
+    if (B < 0 || T < 1 || n_x < 1 || n_u < 1) return fail(DPILQR_EINVAL, "backward_pass_tiles: bad sizes");
+    if (!tiles || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_tiles: NULL pointer");
+    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, as_stream(stream));
+}
+
+int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
+                             double* K, double* d, double* tiles_workspace, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (!X || !U || !mu || !K || !d || !tiles_workspace) return fail(DPILQR_EINVAL, "backward_pass: NULL pointer");
+    rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, as_stream(stream));
+    if (rc) return rc;
+    return launch_riccati(desc->B, desc->T, desc->k * desc->n_s, desc->k * desc->n_c, tiles_workspace, mu, K, d, nullptr,
+                          nullptr, nullptr, desc->B, as_stream(stream));
+}
+
+int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,
+                            const double* d, const double* alphas, int32_t n_alpha, double* Xn, double* Un, double* Jn,
+                            void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (!X || !U || !K || !d || !alphas || !Xn || !Un || !Jn) return fail(DPILQR_EINVAL, "forward_pass: NULL pointer");
+    if (n_alpha < 1) return fail(DPILQR_EINVAL, "forward_pass: n_alpha=%d", n_alpha);
+    SolveState S{};
+    return launch_forward(*desc, kModeCandidates, nullptr, const_cast<double*>(X), const_cast<double*>(U), K, d, alphas,
+                          n_alpha, Xn, Un, Jn, S, nullptr, nullptr, desc->B, as_stream(stream));
+}
+
+int32_t dpilqr_alphas(double* alphas_host) {
+    if (!alphas_host) return fail(DPILQR_EINVAL, "alphas: NULL pointer");
+    alpha_table(alphas_host);
+    return DPILQR_OK;
+}
+
+int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc) {
+    if (!desc || desc->B < 0 || desc->k < 1 || desc->T < 1) return fail(DPILQR_EINVAL, "solve_workspace_bytes: bad desc");
+    return (int64_t)SolveWorkspace(*desc, kMaxLqrIter).total;
+}
+
+int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
+                           void* workspace, int64_t workspace_bytes, double* X, double* J, int32_t* status,
+                           int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (!x0 || !U || !X || !J || !status || !n_bwd || !n_fwd || !workspace)
+        return fail(DPILQR_EINVAL, "solve_batch: NULL pointer");
+    if (n_lqr_iter < 0 || n_lqr_iter > kMaxLqrIter) return fail(DPILQR_EINVAL, "solve_batch: n_lqr_iter=%d", n_lqr_iter);
+    const dpilqr_batch_desc& D = *desc;
+    const SolveWorkspace W(D, kMaxLqrIter);
+    if (workspace_bytes < (int64_t)W.total)
+        return fail(DPILQR_EWORKSPACE, "solve_batch: workspace %lld B < required %zu B", (long long)workspace_bytes, W.total);
+    if (D.B == 0) return DPILQR_OK;
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    double* tiles = reinterpret_cast<double*>(ws + W.tiles);
+    double* K = K_out ? K_out : reinterpret_cast<double*>(ws + W.K);
+    double* d = d_out ? d_out : reinterpret_cast<double*>(ws + W.d);
+    double* alphas = reinterpret_cast<double*>(ws + W.alphas);
+    int32_t* lists = reinterpret_cast<int32_t*>(ws + W.lists);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + W.counts);
+    int32_t* singular = reinterpret_cast<int32_t*>(ws + W.singular);
+    SolveState S{};
+    S.mu = reinterpret_cast<double*>(ws + W.mu);
+    S.delta = reinterpret_cast<double*>(ws + W.delta);
+    S.J_star = reinterpret_cast<double*>(ws + W.J_star);
+    S.J_last = reinterpret_cast<double*>(ws + W.J_last);
+    S.status = status; S.n_bwd = n_bwd; S.n_fwd = n_fwd; S.trace = trace; S.singular = singular;
+    S.counts = counts; S.n_lqr_iter = n_lqr_iter; S.tol = tol;
+    const int n = D.k * D.n_s, m = D.k * D.n_c;
+
+    if (!g_mail.host) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * (kMaxLqrIter + 2), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[1], hipEventDisableTiming));
+    }
+
+    double a[DPILQR_N_ALPHA];
+    alpha_table(a);
+    const int n_counts = n_lqr_iter + 2;
+    const int init_n = D.B > n_counts ? D.B : n_counts;
+    hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
+                       singular, counts, n_counts, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+    HIP_TRY(hipGetLastError());
+    // X, J* <- rollout(x0, U)   (control.py:164)
+    rc = launch_forward(D, kModeRollout, x0, X, U, nullptr, nullptr, nullptr, 1, nullptr, nullptr, S.J_star, S, nullptr,
+                        nullptr, D.B, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_star, S.J_last);
+
+    // Iteration loop.  The set of active items lives on the device (lists/counts); the host only
+    // needs an upper bound for the grid size, which it reads one iteration late so that a full
+    // iteration of launches is always queued while it waits.
+    int upper = D.B;
+    for (int it = 0; it < n_lqr_iter && upper > 0; ++it) {
+        const int32_t* cur = (it == 0) ? nullptr : lists + (size_t)(it & 1) * D.B;
+        const int32_t* cur_n = counts + it;
+        S.iter = it;
+        S.next_items = lists + (size_t)((it + 1) & 1) * D.B;
+        if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, st))) return rc;
+        if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, st))) return rc;
+        if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, nullptr, nullptr, nullptr,
+                                 S, cur, cur_n, upper, st)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(g_mail.host + it + 1, counts + it + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
+        if (it >= 1) {
+            HIP_TRY(hipEventSynchronize(g_mail.ev[(it - 1) & 1]));
+            upper = g_mail.host[it];  // active items of iteration `it` >= those of iteration it+1
+        }
+    }
+    hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_last, J);
+    if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X, const double* radius,
+                              int32_t* adj, void* stream) {
+    if (S < 0 || N < 1 || k < 1 || n_s < 2 || !X || !radius || !adj) return fail(DPILQR_EINVAL, "pairwise_graph: bad argument");
+    if (S == 0) return DPILQR_OK;
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemsetAsync(adj, 0, sizeof(int32_t) * (size_t)S * k * k, st));
+    const int64_t total = (int64_t)S * (k * (k - 1) / 2 + k);
+    hipLaunchKernelGGL(k_pairwise_graph, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, S, N, k, n_s, X, radius, adj);
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// forward.hpp -- K3: rollouts, the line-searched forward pass and the accept / regularisation logic.
+//
+// Reference: ilqrSolver._rollout (control.py:80-93), _forward_pass (:95-114) and the body of the
+// iteration loop in solve (:179-211) with _decrease_regularization (:232-237).
+//
+// One workgroup per sub-problem; thread (g, a) = (line-search candidate g, agent a).  Every candidate
+// alpha of the reference's sequential search is independent given (X,U,K,d), so all are rolled out at
+// once and the FIRST one (in table order) with J < J* is accepted -- identical to the sequential
+// search, including the count of forward passes it would have made.  The accepted candidate is then
+// rolled out once more, writing X,U in place (no per-candidate trajectory scratch in HBM).
+// Per time step the agents of a candidate exchange dx and positions through LDS; the stage cost is
+// summed in the reference's order (pairs in combinations order, agents in order, then over time).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cost.hpp"
+#include "models.hpp"
+
+namespace dpilqr {
+
+enum ForwardMode : int { kModeRollout = 0, kModeCandidates = 1, kModeLineSearch = 2 };
+
+struct SolveState {  // per-item solver state, device arrays of length B
+    double* mu;
+    double* delta;
+    double* J_star;
+    double* J_last;
+    int32_t* status;
+    int32_t* n_bwd;
+    int32_t* n_fwd;
+    double* trace;            // [B][n_lqr_iter][5] or null
+    const int32_t* singular;  // [B] or null
+    int32_t* counts;          // [n_lqr_iter+1] active-item counters
+    int32_t* next_items;      // list for iteration iter+1
+    int32_t iter, n_lqr_iter;
+    double tol;
+};
+
+struct ForwardLds {
+    int Kt, dt, dx, xs, cref, cpair, J, ctl, total;
+    __host__ __device__ ForwardLds(int n, int m, int k, int ngrp) {
+        const int npairs = k * (k - 1) / 2;
+        int o = 0;
+        // everything staged per time step is double-buffered by the parity of t: one barrier per step
+        Kt = o;    o += 2 * m * n;
+        dt = o;    o += 2 * m;
+        dx = o;    o += 2 * ngrp * n;
+        xs = o;    o += 2 * ngrp * n;
+        cref = o;  o += 2 * ngrp * k;
+        cpair = o; o += 2 * ngrp * (npairs > 0 ? npairs : 1);
+        J = o;     o += ngrp;
+        ctl = o;   o += 2;
+        total = o;
+    }
+};
+inline size_t forward_lds_bytes(int n, int m, int k, int ngrp) { return sizeof(double) * (size_t)ForwardLds(n, m, k, ngrp).total; }
+
+// One pass over the horizon for the calling thread's (candidate g, agent a).
+//   GAINS : u = U + (K dx + alpha d) (control.py:104-107) ; else u = U (control.py:89)
+//   COST  : accumulate J on the a==0 lane of each candidate (returned there)
+//   Xw/Uw : where to write the new trajectory for this candidate (null = do not write); may alias
+//           Xold/Uold (in-place update by the accepted candidate): old X[t+1] is read before it is
+//           overwritten.
+template <int NS, int NC, bool GAINS, bool COST>
+__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int b, bool active, int g,
+                               int a, int ngrp, const double* x_init, const double* Xold,
+                               const double* Uold, const double* __restrict__ Kb,
+                               const double* __restrict__ db, double alpha, double* Xw, double* Uw, double* lds) {
+    const int k = D.k, T = D.T, n = k * NS, m = k * NC;
+    const int npairs = k * (k - 1) / 2, np1 = npairs > 0 ? npairs : 1;
+    const ForwardLds O(n, m, k, ngrp);
+    const int gg = active ? g : 0;
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    double x[NS], xold_next[NS];
+    const int model = active ? P.model[a] : 0;
+    const double* xf = P.xf + a * NS;
+    const double* Qa = P.Q + a * NS * NS;
+    const double* Ra = P.R + a * NC * NC;
+    const double* Qfa = P.Qf + a * NS * NS;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            x[i] = x_init[a * NS + i];
+            xold_next[i] = GAINS ? Xold[a * NS + i] : 0.0;
+        }
+        if (Xw) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) Xw[a * NS + i] = x[i];
+        }
+    }
+    double J = 0.0;
+
+    for (int t = 0; t < T; ++t) {
+        const int par = t & 1;
+        double* sKt = lds + O.Kt + par * m * n;
+        double* sdt = lds + O.dt + par * m;
+        double* sdx = lds + O.dx + (par * ngrp + gg) * n;
+        double* sxs = lds + O.xs + (par * ngrp + gg) * n;
+        if (GAINS) {  // stage K[t], d[t] for the whole workgroup
+            const double* Kt = Kb + (int64_t)t * m * n;
+            for (int e = tid; e < m * n; e += nth) sKt[e] = Kt[e];
+            for (int e = tid; e < m; e += nth) sdt[e] = db[(int64_t)t * m + e];
+        }
+        double u[NC];
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) u[i] = Uold[(int64_t)t * m + a * NC + i];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                if (GAINS) sdx[a * NS + i] = x[i] - xold_next[i];  // dx = X'[t] - X[t]
+                sxs[a * NS + i] = x[i];
+            }
+            if (GAINS) {  // old X[t+1], fetched before anyone may overwrite it
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xold_next[i] = Xold[(int64_t)(t + 1) * n + a * NS + i];
+            }
+        }
+        __syncthreads();
+        if (COST && active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), reference order
+            const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
+            const double* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
+            double prox = 0.0, ref = 0.0;
+            for (int p = 0; p < npairs; ++p) prox += cp[p];
+            for (int i = 0; i < k; ++i) ref += cr[i];
+            J += D.w_prox * prox + D.w_ref * ref;
+        }
+        if (active) {
+            if (GAINS) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double* row = sKt + (a * NC + c) * n;
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s += row[j] * sdx[j];
+                    const double du = s + alpha * sdt[a * NC + c];
+                    u[c] = u[c] + du;
+                }
+            }
+            if (COST) {
+                lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, u, xf, Qa, Ra, false);
+                for (int o = a + 1; o < k; ++o) {
+                    const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
+                    lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
+                        pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
+                }
+            }
+            if (Uw) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Uw[(int64_t)t * m + a * NC + c] = u[c];
+            }
+            double xn[NS];
+            integrate_rt<NS>(model, x, u, D.dt, xn);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = xn[i];
+            if (Xw) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Xw[(int64_t)(t + 1) * n + a * NS + i] = x[i];
+            }
+        }
+    }
+    if (COST) {
+        // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:91,112)
+        const int par = T & 1;
+        double* sxs = lds + O.xs + (par * ngrp + gg) * n;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
+        }
+        __syncthreads();
+        if (active) {
+            if (a == 0 && T > 0) {
+                const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
+                const double* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
+                double prox = 0.0, ref = 0.0;
+                for (int p = 0; p < npairs; ++p) prox += cp[p];
+                for (int i = 0; i < k; ++i) ref += cr[i];
+                J += D.w_prox * prox + D.w_ref * ref;
+            }
+            double uz[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) uz[c] = 0.0;
+            lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, uz, xf, Qfa, Ra, true);
+            for (int o = a + 1; o < k; ++o) {
+                const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
+                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
+                    pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
+            }
+        }
+        __syncthreads();
+        if (active && a == 0) {
+            const double* cr = lds + O.cref + (par * ngrp + g) * k;
+            const double* cp = lds + O.cpair + (par * ngrp + g) * np1;
+            double prox = 0.0, ref = 0.0;
+            for (int p = 0; p < npairs; ++p) prox += cp[p];
+            for (int i = 0; i < k; ++i) ref += cr[i];
+            J += D.w_prox * prox + D.w_ref * ref;
+        }
+    }
+    __syncthreads();
+    return J;
+}
+
+template <int NS, int NC>
+__global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X, double* U,
+                          const double* __restrict__ K, const double* __restrict__ d,
+                          const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc, double* Jc,
+                          SolveState S, const int32_t* __restrict__ items, const int32_t* __restrict__ n_items) {
+    const int slot = blockIdx.x;
+    if (n_items && slot >= *n_items) return;
+    const int b = items ? items[slot] : slot;
+    const int k = D.k, T = D.T, n = k * NS, m = k * NC;
+    const int tid = threadIdx.x;
+    const int g = tid / k, a = tid - g * k;
+    const ItemParams P = item_params(D, b);
+    const bool homog = homogeneous_ndims(P.n_dims, k);
+    extern __shared__ double lds[];
+    const ForwardLds O(n, m, k, ngrp);
+    double* Xb = X + (int64_t)b * (T + 1) * n;
+    double* Ub = U + (int64_t)b * T * m;
+
+    if (mode == kModeRollout) {
+        const bool active = (g == 0);
+        const double J = horizon_pass<NS, NC, false, true>(D, P, homog, b, active, 0, a, 1, x0 + (int64_t)b * n, nullptr,
+                                                           Ub, nullptr, nullptr, 0.0, Xb, nullptr, lds);
+        if (active && a == 0) Jc[b] = J;
+        return;
+    }
+
+    const double* Kb = K + (int64_t)b * T * m * n;
+    const double* db = d + (int64_t)b * T * m;
+    const bool active = (g < ngrp);
+    const double alpha = active ? alphas[g] : 0.0;
+
+    if (mode == kModeCandidates) {
+        double* Xw = active ? Xc + ((int64_t)b * ngrp + g) * (T + 1) * n : nullptr;
+        double* Uw = active ? Uc + ((int64_t)b * ngrp + g) * T * m : nullptr;
+        const double J = horizon_pass<NS, NC, true, true>(D, P, homog, b, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
+                                                          Xw, Uw, lds);
+        if (active && a == 0) Jc[(int64_t)b * ngrp + g] = J;
+        return;
+    }
+
+    // ---- kModeLineSearch: one iLQR iteration's line search + bookkeeping (control.py:179-211)
+    int* ctl = reinterpret_cast<int*>(lds + O.ctl);
+    if (S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
+        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] = S.iter + 1; }
+        return;
+    }
+    const double J = horizon_pass<NS, NC, true, true>(D, P, homog, b, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
+                                                      nullptr, nullptr, lds);
+    if (active && a == 0) lds[O.J + g] = J;
+    __syncthreads();
+    if (tid == 0) {
+        const double J_star = S.J_star[b];
+        int acc = -1;
+        for (int i = 0; i < ngrp; ++i)
+            if (lds[O.J + i] < J_star) { acc = i; break; }  // strict <, NaN rejects (control.py:183)
+        const int n_eval = (acc >= 0) ? acc + 1 : ngrp;
+        const double J_last = lds[O.J + n_eval - 1];         // last EVALUATED cost (quirk Q2)
+        const double mu_before = S.mu[b];
+        int status = DPILQR_STATUS_ACTIVE;
+        double J_new = J_star;
+        if (acc >= 0) {
+            const bool conv = fabs((J_star - J_last) / J_star) < S.tol;  // control.py:184
+            J_new = J_last;
+            // _decrease_regularization, control.py:232-237
+            double delta = fmin(1.0, S.delta[b]) / 2.0;
+            double mu = mu_before * delta;
+            if (mu <= 1e-6) mu = 0.0;
+            S.delta[b] = delta; S.mu[b] = mu; S.J_star[b] = J_new;
+            if (conv) status = DPILQR_STATUS_CONVERGED;
+            else if (S.iter + 1 >= S.n_lqr_iter) status = DPILQR_STATUS_MAX_ITER;
+        } else {
+            status = DPILQR_STATUS_LINESEARCH_FAILED;  // control.py:195-198
+        }
+        S.J_last[b] = J_last;
+        S.n_fwd[b] += n_eval;
+        S.n_bwd[b] = S.iter + 1;
+        S.status[b] = status;
+        if (S.trace) {
+            double* tr = S.trace + ((int64_t)b * S.n_lqr_iter + S.iter) * 5;
+            tr[0] = mu_before; tr[1] = (double)acc; tr[2] = J_last; tr[3] = J_new; tr[4] = (double)n_eval;
+        }
+        if (status == DPILQR_STATUS_ACTIVE && S.next_items) {
+            const int pos = atomicAdd(&S.counts[S.iter + 1], 1);
+            S.next_items[pos] = b;
+        }
+        ctl[0] = acc;
+    }
+    __syncthreads();
+    const int acc = ctl[0];
+    if (acc < 0) return;
+    // accepted: X, U <- the accepted candidate's trajectory, rolled out again in place
+    const bool act0 = (g == 0);
+    horizon_pass<NS, NC, true, false>(D, P, homog, b, act0, 0, a, ngrp, Xb, Xb, Ub, Kb, db, alphas[acc], Xb, Ub, lds);
+}
+
+// ---- small batched entry points ------------------------------------------------------------------
+
+// GameCost.__call__ (cost.py:197-206) for one (item, point) per thread
+template <int NS, int NC>
+__global__ void k_cost_eval(dpilqr_batch_desc D, int n_pts, const double* __restrict__ x, const double* __restrict__ u,
+                            int terminal, double* __restrict__ cost) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)D.B * n_pts) return;
+    const int b = (int)(idx / n_pts);
+    const int k = D.k, n = k * NS, m = k * NC;
+    const ItemParams P = item_params(D, b);
+    const bool homog = homogeneous_ndims(P.n_dims, k);
+    const double* xp = x + idx * n;
+    const double* up = u + idx * m;
+    double ref = 0.0, prox = 0.0;
+    for (int a = 0; a < k; ++a) {
+        double xa[NS], ua[NC];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xa[i] = xp[a * NS + i];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ua[i] = terminal ? 0.0 : up[a * NC + i];
+        ref += ref_cost<NS, NC>(xa, ua, P.xf + a * NS, (terminal ? P.Qf : P.Q) + a * NS * NS, P.R + a * NC * NC,
+                                terminal != 0);
+    }
+    for (int i = 0; i < k; ++i)
+        for (int j = i + 1; j < k; ++j) {
+            const int nd = homog ? 2 : min(P.n_dims[i], P.n_dims[j]);
+            prox += pair_cost(xp + i * NS, xp + j * NS, nd, P.radius);
+        }
+    cost[idx] = D.w_prox * prox + D.w_ref * ref;
+}
+
+template <int NS, int NC, int OP>  // OP 0: f, 1: integrate, 2: linearize
+__global__ void k_model_op(int n_agents, const int32_t* __restrict__ model, const double* __restrict__ x,
+                           const double* __restrict__ u, double dt, double* __restrict__ o1, double* __restrict__ o2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_agents) return;
+    double xa[NS], ua[NC];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) xa[j] = x[(int64_t)i * NS + j];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) ua[j] = u[(int64_t)i * NC + j];
+    if (OP == 2) {
+        double A[NS * NS], Bm[NS * NC];
+        linearize_rt<NS>(model[i], xa, ua, dt, A, Bm);
+#pragma unroll
+        for (int j = 0; j < NS * NS; ++j) o1[(int64_t)i * NS * NS + j] = A[j];
+#pragma unroll
+        for (int j = 0; j < NS * NC; ++j) o2[(int64_t)i * NS * NC + j] = Bm[j];
+    } else {
+        double r[NS];
+        if (OP == 0) f_rt<NS>(model[i], xa, ua, r);
+        else integrate_rt<NS>(model[i], xa, ua, dt, r);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) o1[(int64_t)i * NS + j] = r[j];
+    }
+}
+
+// define_inter_graph_threshold (distributed.py:224-247): thread per (scenario, pair)
+__global__ void k_pairwise_graph(int S, int N, int k, int n_s, const double* __restrict__ X,
+                                 const double* __restrict__ radius, int32_t* __restrict__ adj) {
+    const int npairs = k * (k - 1) / 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)S * (npairs + k);
+    if (idx >= total) return;
+    const int s = (int)(idx / (npairs + k));
+    const int p = (int)(idx - (int64_t)s * (npairs + k));
+    int32_t* A = adj + (int64_t)s * k * k;
+    if (p >= npairs) {  // self loops: graph[id] always contains id (distributed.py:238)
+        const int i = p - npairs;
+        A[i * k + i] = 1;
+        return;
+    }
+    int i = 0, rem = p;
+    while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const double thr = 2 * radius[s];              // planning_radii = 2 * radius (:229)
+    const int step = (N / 10 > 1) ? N / 10 : 1;    // sample_step = max(N // n_samples, 1) (:233-235)
+    const double* Xs = X + (int64_t)s * N * k * n_s;
+    int hit = 0;
+    for (int r = 0; r < N; r += step) {            // slice(0, N+1, step) clipped to N rows
+        const double* row = Xs + (int64_t)r * k * n_s;
+        const double dx = row[i * n_s] - row[j * n_s], dy = row[i * n_s + 1] - row[j * n_s + 1];
+        if (sqrt(dx * dx + dy * dy) < thr) { hit = 1; break; }
+    }
+    A[i * k + j] = hit;
+    A[j * k + i] = hit;
+}
+
+}  // namespace dpilqr

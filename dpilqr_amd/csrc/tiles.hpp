@@ -1,0 +1,187 @@
+// tiles.hpp -- K1: device-side tile producer.
+//
+// For every (item b, time step t) it evaluates what the reference computes per step inside
+// ilqrSolver._backward_pass (control.py:125-133):
+//     GameCost.quadraticize(X[t],U[t])            cost.py:208-239  (+ :85-101, :135-171, :269-315)
+//     MultiDynamicalModel.linearize(X[t],U[t])    dynamics.py:173-186 -> bbdynamics.cpp linearize_*
+// and writes ONE dense tile record (layout: TileLayout) to HBM.  The records are what the Riccati
+// sweep (riccati.hpp) streams back in.  One 64-lane wavefront per (b,t):
+//   phase 1  lanes 0..k-1 linearise "their" agent and form e = x - xf;  lanes stride the i<j pairs
+//            and evaluate the pair gradient/Hessian of the proximity penalty   -> LDS
+//   phase 2  all lanes assemble the dense record and store it with unit-stride 8-byte stores.
+// The record is dense because dense (n_x,n_x) matrices are the reference's plugin contract.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cost.hpp"
+#include "models.hpp"
+
+namespace dpilqr {
+
+struct TileLayout {
+    int n, m;              // n_x, n_u
+    int oA, oB, oLxx, oLux, oLuu, oLx, oLu;
+    int stride;            // doubles per record (even -> 16-byte aligned records)
+    __host__ __device__ TileLayout(int n_x, int n_u) : n(n_x), m(n_u) {
+        oA = 0;
+        oB = oA + n * n;
+        oLxx = oB + n * m;
+        oLux = oLxx + n * n;
+        oLuu = oLux + m * n;
+        oLx = oLuu + m * m;
+        oLu = oLx + n;
+        stride = (oLu + m + 1) & ~1;
+    }
+};
+
+// LDS carve for one (b,t): per-agent blocks + per-pair derivatives
+template <int NS, int NC>
+__global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const double* __restrict__ X,
+                                                    const double* __restrict__ U, double* __restrict__ tiles,
+                                                    const int32_t* __restrict__ items,
+                                                    const int32_t* __restrict__ n_items) {
+    const int slot = blockIdx.y;
+    if (n_items && slot >= *n_items) return;
+    const int b = items ? items[slot] : slot;
+    const int t = blockIdx.x;  // 0..T ; T = terminal record
+    const int k = D.k, T = D.T;
+    const int n = k * NS, m = k * NC;
+    const bool terminal = (t == T);
+    const int lane = threadIdx.x;
+    const int npairs = k * (k - 1) / 2;
+    const ItemParams P = item_params(D, b);
+    const TileLayout L(n, m);
+
+    extern __shared__ double lds[];
+    double* sA = lds;                      // [k][NS*NS]
+    double* sB = sA + k * NS * NS;         // [k][NS*NC]
+    double* sE = sB + k * NS * NC;         // [k*NS]  x - xf
+    double* sU = sE + k * NS;              // [k*NC]
+    double* sG = sU + k * NC;              // [npairs][3]
+    double* sH = sG + npairs * 3;          // [npairs][9]
+
+    const double* xt = X + ((int64_t)b * (T + 1) + t) * n;
+    const double* ut = U + ((int64_t)b * T + (terminal ? 0 : t)) * m;
+
+    // ---- phase 1a: per-agent linearisation and error vector
+    for (int a = lane; a < k; a += 64) {
+        double x[NS], u[NC], A[NS * NS], Bm[NS * NC];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = xt[a * NS + i];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) u[i] = terminal ? 0.0 : ut[a * NC + i];
+        if (!terminal) {
+            linearize_rt<NS>(P.model[a], x, u, D.dt, A, Bm);
+#pragma unroll
+            for (int i = 0; i < NS * NS; ++i) sA[a * NS * NS + i] = A[i];
+#pragma unroll
+            for (int i = 0; i < NS * NC; ++i) sB[a * NS * NC + i] = Bm[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sE[a * NS + i] = x[i] - P.xf[a * NS + i];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) sU[a * NC + i] = u[i];
+    }
+    // ---- phase 1b: pair derivatives, pairs in itertools.combinations order
+    for (int p = lane; p < npairs; p += 64) {
+        int i = 0, rem = p;
+        while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+        const int j = i + 1 + rem;
+        const int nd = min(P.n_dims[i], P.n_dims[j]);  // cost.py:145
+        double g[3], H[9];
+        pair_quadraticize(xt + i * NS, xt + j * NS, nd, P.radius, g, H);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sG[p * 3 + c] = g[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) sH[p * 9 + c] = H[c];
+    }
+    __syncthreads();
+
+    double* rec = tiles + ((int64_t)b * (T + 1) + t) * L.stride;
+    const double wr = D.w_ref, wp = D.w_prox;
+
+    // ---- phase 2: dense record.  A, B only for t < T (record T never has them read).
+    if (!terminal) {
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            const int ai = i / NS, aj = j / NS;
+            rec[L.oA + e] = (ai == aj) ? sA[ai * NS * NS + (i - ai * NS) * NS + (j - aj * NS)] : 0.0;
+        }
+        for (int e = lane; e < n * m; e += 64) {
+            const int i = e / m, j = e - i * m;
+            const int ai = i / NS, aj = j / NC;
+            rec[L.oB + e] = (ai == aj) ? sB[ai * NS * NC + (i - ai * NS) * NC + (j - aj * NC)] : 0.0;
+        }
+        for (int e = lane; e < m * n; e += 64) rec[L.oLux + e] = 0.0;  // L_ux = 0 (cost.py:93,231)
+        for (int e = lane; e < m * m; e += 64) {
+            const int i = e / m, j = e - i * m;
+            const int ai = i / NC, aj = j / NC;
+            double v = 0.0;
+            if (ai == aj) {
+                const double* R = P.R + ai * NC * NC;
+                const int li = i - ai * NC, lj = j - aj * NC;
+                v = wr * (R[li * NC + lj] + R[lj * NC + li]);  // R + R^T (cost.py:63,92)
+            }
+            rec[L.oLuu + e] = v;
+        }
+        for (int j = lane; j < m; j += 64) {
+            const int a = j / NC, lj = j - a * NC;
+            const double* R = P.R + a * NC * NC;
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v += sU[a * NC + i] * (R[i * NC + lj] + R[lj * NC + i]);
+            rec[L.oLu + j] = wr * v;
+        }
+    }
+    // L_xx = w_ref * blockdiag(Q+Q^T) + w_prox * sum_pairs(+-H)   (cost.py:228-237, 160-169)
+    for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        const int ai = i / NS, aj = j / NS, li = i - ai * NS, lj = j - aj * NS;
+        double v = 0.0;
+        if (ai == aj) {
+            const double* M = (terminal ? P.Qf : P.Q) + ai * NS * NS;
+            v = wr * (M[li * NS + lj] + M[lj * NS + li]);
+        }
+        if (k > 1 && li < 3 && lj < 3) {
+            double acc = 0.0;
+            if (ai == aj) {
+                for (int o = 0; o < k; ++o) {  // pairs containing ai, in combinations order
+                    if (o == ai) continue;
+                    const int p = (o < ai) ? pair_index(o, ai, k) : pair_index(ai, o, k);
+                    acc += sH[p * 9 + li * 3 + lj];
+                }
+            } else {
+                const int p = (ai < aj) ? pair_index(ai, aj, k) : pair_index(aj, ai, k);
+                acc += -sH[p * 9 + li * 3 + lj];
+            }
+            v += wp * acc;
+        }
+        rec[L.oLxx + e] = v;
+    }
+    // L_x = w_ref * e^T (Q+Q^T) + w_prox * sum_pairs(+-g)
+    for (int j = lane; j < n; j += 64) {
+        const int a = j / NS, lj = j - a * NS;
+        const double* M = (terminal ? P.Qf : P.Q) + a * NS * NS;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v += sE[a * NS + i] * (M[i * NS + lj] + M[lj * NS + i]);
+        v = wr * v;
+        if (k > 1 && lj < 3) {
+            double acc = 0.0;
+            for (int o = 0; o < k; ++o) {
+                if (o == a) continue;
+                if (o < a) acc += -sG[pair_index(o, a, k) * 3 + lj];
+                else       acc += sG[pair_index(a, o, k) * 3 + lj];
+            }
+            v += wp * acc;
+        }
+        rec[L.oLx + j] = v;
+    }
+}
+
+inline size_t make_tiles_lds_bytes(int k, int ns, int nc) {
+    const int npairs = k * (k - 1) / 2;
+    return sizeof(double) * (size_t)(k * ns * ns + k * ns * nc + k * ns + k * nc + npairs * 12);
+}
+
+}  // namespace dpilqr

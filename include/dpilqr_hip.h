@@ -1,0 +1,173 @@
+/*
+ * dpilqr_hip.h -- C ABI of libdpilqr_hip.so: the MI355X (gfx950) batched iLQR hot path.
+ *
+ * This is the drop-in boundary for the hot path of labicon/dp-ilqr.  It replaces
+ *   - the Cython FFI  dpilqr/bbdynamicswrap.pyx:61-164  (f / integrate / linearize + Model enum :8-16)
+ *     over the static C++ functions of dpilqr/bbdynamics.cpp:39-711, and
+ *   - the Python inner loops that call it: ilqrSolver._rollout / _backward_pass / _forward_pass /
+ *     solve (dpilqr/control.py:80-225), GameCost.__call__/quadraticize (dpilqr/cost.py:197-239),
+ *     and the per-agent sub-problem loop of solve_distributed (dpilqr/distributed.py:55-97).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  Every entry point returns 0 on success or a
+ *     negative DPILQR_E* code and never throws or aborts; dpilqr_last_error() holds the message of
+ *     the calling thread's last failure.
+ *   - every data pointer is a DEVICE pointer owned by the caller (torch.Tensor.data_ptr()); nothing is
+ *     allocated behind the caller's back except one small pinned host mailbox used by
+ *     dpilqr_solve_batch (allocated once per process).  Workspace sizes come from *_workspace_bytes.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); 0 = null stream.
+ *     Launch-only entry points never synchronise; dpilqr_solve_batch synchronises on `stream` because
+ *     the number of iLQR iterations is data dependent.
+ *   - all real data is IEEE fp64, row-major, C-contiguous; integer arrays are int32.
+ *   - a "batch" is B independent sub-problems of identical shape: k agents x (n_s states, n_c controls),
+ *     horizon T.  Joint dims n_x = k*n_s, n_u = k*n_c.  The reference assumes the same uniformity
+ *     (dynamics.py:165-166, util.py:97-109).
+ */
+#ifndef DPILQR_HIP_H
+#define DPILQR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPILQR_ABI_VERSION 1
+
+/* error codes */
+#define DPILQR_OK 0
+#define DPILQR_EINVAL (-1)     /* bad argument (null pointer, size out of range, unknown model)   */
+#define DPILQR_EUNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. n_x too large)   */
+#define DPILQR_EHIP (-3)       /* a HIP runtime call failed                                       */
+#define DPILQR_ENOGPU (-4)     /* no usable gfx950 device                                         */
+#define DPILQR_EWORKSPACE (-5) /* workspace too small                                             */
+
+/* Model enum -- identical values to bbdynamicswrap.pyx:8-16 */
+#define DPILQR_MODEL_DOUBLE_INT_4D 0
+#define DPILQR_MODEL_DOUBLE_INT_6D 1
+#define DPILQR_MODEL_CAR_3D 2
+#define DPILQR_MODEL_UNICYCLE_4D 3
+#define DPILQR_MODEL_QUADCOPTER_6D 4
+#define DPILQR_MODEL_HUMAN_6D 5
+#define DPILQR_MODEL_HUMAN_LIN_6D 6
+#define DPILQR_MODEL_QUADCOPTER_12D 7
+
+/* per-item solve status (written by dpilqr_solve_batch) */
+#define DPILQR_STATUS_ACTIVE 0
+#define DPILQR_STATUS_CONVERGED 1        /* |dJ/J*| < tol on an accepted step, control.py:184,210 */
+#define DPILQR_STATUS_LINESEARCH_FAILED 2 /* all alphas rejected, control.py:195-198             */
+#define DPILQR_STATUS_MAX_ITER 3          /* n_lqr_iter exhausted                                 */
+#define DPILQR_STATUS_SINGULAR 4          /* exactly zero pivot in Q_uu (np.linalg.solve would raise) */
+
+#define DPILQR_N_ALPHA 10 /* ilqrSolver.N_LS_ITER, control.py:51 */
+
+/*
+ * Batch descriptor: the device-side lowering of B ilqrProblem objects (problem.py:15-25) whose
+ * dynamics are MultiDynamicalModel([CppModel...]) (dynamics.py:133-157) and whose cost is
+ * GameCost([ReferenceCost...], ProximityCost) (cost.py:174-195).
+ * `*_bstride` is the element stride between consecutive batch items; 0 shares one copy.
+ */
+typedef struct dpilqr_batch_desc {
+    int32_t B;   /* sub-problems in the batch                                    */
+    int32_t k;   /* agents per sub-problem                                       */
+    int32_t n_s; /* per-agent state dim   (3, 4, 6 or 12)                        */
+    int32_t n_c; /* per-agent control dim (2, 3 or 4)                            */
+    int32_t T;   /* horizon N (control.py:56)                                    */
+    int32_t reserved;
+    double dt;     /* DynamicalModel.dt                                          */
+    double w_ref;  /* GameCost.REF_WEIGHT  = 1   (cost.py:185)                   */
+    double w_prox; /* GameCost.PROX_WEIGHT = 200 (cost.py:186)                   */
+    const int32_t* model;  int64_t model_bstride;  /* [B][k] Model enum per agent                 */
+    const int32_t* n_dims; int64_t n_dims_bstride; /* [B][k] ProximityCost.n_dims (cost.py:111)   */
+    const double* xf;      int64_t xf_bstride;     /* [B][k*n_s] ReferenceCost.xf                 */
+    const double* Q;       int64_t Q_bstride;      /* [B][k][n_s*n_s]                             */
+    const double* R;       int64_t R_bstride;      /* [B][k][n_c*n_c]                             */
+    const double* Qf;      int64_t Qf_bstride;     /* [B][k][n_s*n_s]                             */
+    const double* radius;  int64_t radius_bstride; /* [B] ProximityCost.radius                    */
+} dpilqr_batch_desc;
+
+/* ------------------------------------------------------------------ library */
+int32_t dpilqr_abi_version(void);
+const char* dpilqr_last_error(void);
+/* 0 if device `dev` exists and is gfx950; fills (may be NULL) its CU count and LDS bytes per workgroup */
+int32_t dpilqr_device_info(int32_t dev, int32_t* n_cu, int32_t* lds_bytes, char* arch, int32_t arch_len);
+int32_t dpilqr_model_dims(int32_t model, int32_t* n_s, int32_t* n_c);
+
+/* -------------------------------------------------- (1) model FFI, batched over n agents
+ * replaces bbdynamicswrap.f / integrate / linearize (pyx:61-164).  model[n]; x[n][n_s]; u[n][n_c]
+ * with n_s/n_c taken from `family_ns` (all n agents must belong to models of that state dim).     */
+int32_t dpilqr_model_f(int32_t n, int32_t family_ns, const int32_t* model, const double* x, const double* u,
+                       double* x_dot, void* stream);
+int32_t dpilqr_model_integrate(int32_t n, int32_t family_ns, const int32_t* model, const double* x,
+                               const double* u, double dt, double* x_new, void* stream);
+int32_t dpilqr_model_linearize(int32_t n, int32_t family_ns, const int32_t* model, const double* x,
+                               const double* u, double dt, double* A /*[n][n_s*n_s]*/,
+                               double* B /*[n][n_s*n_c]*/, void* stream);
+
+/* -------------------------------------------------- (2) joint cost, batched over B x n_pts points
+ * replaces GameCost.__call__ / quadraticize (cost.py:197-239).  x[B][n_pts][n_x], u[B][n_pts][n_u].  */
+int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const double* x, const double* u,
+                         int32_t terminal, double* cost /*[B][n_pts]*/, void* stream);
+
+/* -------------------------------------------------- (3) tiles: the plugin contract of the sweep
+ * One "tile record" per (item, time step) holds what DynamicalModel.linearize (dynamics.py:173-186)
+ * and Cost.quadraticize (cost.py:208-239) return at (X[t],U[t]), packed as
+ *     [ A n_x*n_x | B n_x*n_u | L_xx n_x*n_x | L_ux n_u*n_x | L_uu n_u*n_u | L_x n_x | L_u n_u ]
+ * record t = T holds the terminal quadraticisation (only L_xx, L_x are read).
+ * dpilqr_tile_layout returns the 7 offsets (in doubles, order A,B,Lxx,Lux,Luu,Lx,Lu) and the
+ * record stride; a tile buffer is [B][T+1][stride] doubles. */
+int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t* stride);
+/* device-side producer for the recognised plugin types; X[B][T+1][n_x], U[B][T][n_u].
+ * items/n_items select a subset (device int32 list + device count); NULL/NULL = all B items.      */
+int32_t dpilqr_make_tiles(const dpilqr_batch_desc* desc, const double* X, const double* U, double* tiles,
+                          const int32_t* items, const int32_t* n_items, void* stream);
+
+/* -------------------------------------------------- (4) passes
+ * ilqrSolver._rollout (control.py:80-93): X[B][T+1][n_x] (X[:,0] is written from x0), J[B].        */
+int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const double* U, double* X, double* J,
+                       void* stream);
+/* ilqrSolver._backward_pass (control.py:116-148) on tile records: the Riccati sweep.
+ * mu[B] per-item regularisation; K[B][T][n_u][n_x]; d[B][T][n_u]; singular[B] (may be NULL) set to 1
+ * where a pivot was exactly zero.  items/n_items as above.                                          */
+int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_u, const double* tiles,
+                                   const double* mu, double* K, double* d, int32_t* singular,
+                                   const int32_t* items, const int32_t* n_items, void* stream);
+/* convenience: make_tiles + backward_pass_tiles for recognised plugins; workspace = tile buffer      */
+int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u);
+int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
+                             double* K, double* d, double* tiles_workspace, void* stream);
+/* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:
+ * Xn[B][n_alpha][T+1][n_x], Un[B][n_alpha][T][n_u], Jn[B][n_alpha].                                  */
+int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,
+                            const double* d, const double* alphas, int32_t n_alpha, double* Xn, double* Un,
+                            double* Jn, void* stream);
+/* the float32-rounded line-search table of control.py:162 (host array of DPILQR_N_ALPHA doubles) */
+int32_t dpilqr_alphas(double* alphas_host);
+
+/* -------------------------------------------------- (5) the whole solve, device resident
+ * ilqrSolver.solve (control.py:150-225) for every item of the batch; one launch sequence per iLQR
+ * iteration over the items still active (finished items are retired through a device-side list).
+ *   x0[B][n_x]; U[B][T][n_u] in: warm start, out: solution; X[B][T+1][n_x] out;
+ *   J[B] out = last EVALUATED forward-pass cost (reference quirk, control.py:181,225);
+ *   status[B], n_bwd[B], n_fwd[B] out; trace (may be NULL) [B][n_lqr_iter][5] =
+ *   (mu_before, accepted alpha index or -1, J_last, J_star_after, n_forward_passes).
+ *   K_out/d_out (may be NULL): [B][T][n_u][n_x] / [B][T][n_u] gains of each item's LAST backward pass.
+ * Plugins the library does not recognise never reach this entry point: the host solver calls their
+ * linearize/quadraticize itself and feeds dpilqr_backward_pass_tiles.
+ * workspace: dpilqr_solve_workspace_bytes(desc) bytes of device memory.                              */
+int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc);
+int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter,
+                           double tol, void* workspace, int64_t workspace_bytes, double* X, double* J,
+                           int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
+                           double* d_out, void* stream);
+
+/* -------------------------------------------------- (6) dispatch front end ("next" row)
+ * define_inter_graph_threshold (distributed.py:224-247) for S scenarios at once:
+ * X[S][N][k*n_s] sampled trajectories (N may be 1), adjacency out adj[S][k][k] (int32, incl. self). */
+int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X,
+                              const double* radius /*[S]*/, int32_t* adj, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPILQR_HIP_H */
