@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the batched iLQR hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "cfg2"): a batch of 1024 independent 5-agent DoubleIntDynamics4D
+sub-problems per GPU, horizon T=50, fp64, the Monte-Carlo scenario distribution of the reference's
+scripts/analysis.py:45-69,140-143 (seed s: np.random.seed(s); random_setup(5,4,rel_dist=5,var=2.5,
+energy=10); Q=diag(1,1,0,0), R=I, Qf=1000 I, radius 0.5, dt 0.1, U0=0, tol 1e-3, n_lqr_iter 50).
+One "step" = one complete ilqrSolver.solve of every sub-problem of the batch (device resident:
+x0/xf/U0 are in HBM before the clock starts), followed -- for N>1 -- by the path's one collective,
+an RCCL all-gather of the converged (X, U, J, n_bwd) of all ranks.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+K_AGENTS, N_S, N_C, T = 5, 4, 2, 50
+N_X, N_U = K_AGENTS * N_S, K_AGENTS * N_C
+# algorithmic bytes of ONE Riccati backward pass of ONE cfg2 sub-problem, tiles through HBM:
+#   read  8*(T*S + n_x + n_x^2),  S = 2 n_x^2 + 2 n_x n_u + n_u^2 + n_x + n_u = 1330 doubles
+#   write 8*T*(n_u n_x + n_u)
+S_TILE = 2 * N_X * N_X + 2 * N_X * N_U + N_U * N_U + N_X + N_U
+BWD_READ_BYTES = 8 * (T * S_TILE + N_X + N_X * N_X)       # 535 360
+BWD_WRITE_BYTES = 8 * T * (N_U * N_X + N_U)               # 84 000
+HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def scenarios(seed0, B):
+    from dpilqr_amd.util import random_setup
+    x0 = np.zeros((B, N_X)); xf = np.zeros((B, N_X))
+    state = np.random.get_state()
+    for i in range(B):
+        np.random.seed(seed0 + i)
+        a, b = random_setup(K_AGENTS, N_S, is_rotation=False, rel_dist=K_AGENTS, var=K_AGENTS / 2, n_d=2, random=True,
+                            energy=10.0)
+        x0[i], xf[i] = a.ravel(), b.ravel()
+    np.random.set_state(state)
+    return x0, xf
+
+
+def cpu_baseline(x0, xf, sample):
+    """The CPU restatement (oracle/, OpenMP over the batch) on the host cores of this box."""
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    proto = orc.Problem([0] * K_AGENTS, [2] * K_AGENTS, xf[0], Q, R, Qf, 0.5, 0.1, T)
+    orc.solve_batch(proto, x0[:cores], xf[:cores], np.zeros((cores, T, N_U)), n_threads=cores)  # warm
+    t0 = time.perf_counter()
+    o = orc.solve_batch(proto, x0[:sample], xf[:sample], np.zeros((sample, T, N_U)), n_threads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="subproblems/s", cores=cores, kind="port",
+                sample=f"first {sample} sub-problems of the rank-0 batch, oracle/ilqr_oracle.c with OpenMP on {cores} "
+                       f"threads, {dt:.2f} s wall"), o
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import dpilqr_amd
+    from dpilqr_amd import _lib
+    from dpilqr_amd.device import to_dev
+    from dpilqr_amd.sharding import gather_results
+    _lib.require_gpu()
+
+    B = args.batch
+    x0_h, xf_h = scenarios(rank * B, B)                      # weak scaling: every rank its own 1024 seeds
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf_h, Q, R, Qf, 0.5, 0.1, T)
+    x0 = to_dev(x0_h); U0 = torch.zeros((B, T, N_U), dtype=torch.float64, device=x0.device)
+
+    def step():
+        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3)
+        if world > 1:
+            r = gather_results(r)                            # the one collective of the path
+        return r
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        r = step()
+    _lib.profile_enable(True); _lib.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_read(reset=True); _lib.profile_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=x0.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_units = B * world * args.steps
+    value = total_units / elapsed
+
+    if rank == 0:
+        ric = prof["riccati"]
+        ric_bytes = ric["items"] * (BWD_READ_BYTES + BWD_WRITE_BYTES)
+        achieved = ric_bytes / (ric["ms"] * 1e-3) / 1e9 if ric["ms"] > 0 else 0.0
+        traffic = None
+        tf = ROOT / "profiles" / "riccati_traffic.json"   # PMC pass (rocprofv3 --pmc), see profiles/README.md
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy(); st = r["status"].cpu().numpy()
+        out = {
+            "metric": "ilqr_subproblems_per_sec", "value": value, "unit": "subproblems/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2: {B} independent 5-agent DoubleIntDynamics4D iLQR sub-problems per GPU, T=50, "
+                                   "scripts/analysis.py scenario distribution, tol=1e-3, n_lqr_iter=50",
+                       "batch_per_gpu": B, "n_x": N_X, "n_u": N_U, "horizon": T,
+                       "mean_backward_passes": float(nb.mean()), "mean_forward_passes": float(nf.mean()),
+                       "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
+                       "parallelism": f"batch-sharded x{world}, one all-gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_riccati_generic", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
+                         "launches": ric["launches"], "subproblem_passes": ric["items"],
+                         "avg_launch_ms": ric["ms"] / max(ric["launches"], 1)},
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], _ = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, B))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

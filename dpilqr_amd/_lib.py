@@ -53,6 +53,8 @@ SIGNATURES = {
     "dpilqr_alphas": (i32, [C.POINTER(f64 * N_ALPHA)]),
     "dpilqr_solve_workspace_bytes": (i64, [_DP]),
     "dpilqr_solve_batch": (i32, [_DP, vp, vp, i32, f64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_profile_enable": (i32, [i32]),
+    "dpilqr_profile_read": (i32, [C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
     "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
 }
 
@@ -94,6 +96,18 @@ def tile_layout(n_x, n_u):
     stride = i64(0)
     check(load().dpilqr_tile_layout(n_x, n_u, C.byref(off), C.byref(stride)))
     return dict(zip(["A", "B", "Lxx", "Lux", "Luu", "Lx", "Lu"], list(off))), stride.value
+
+
+def profile_enable(on=True):
+    return load().dpilqr_profile_enable(int(bool(on)))
+
+
+def profile_read(reset=True):
+    """Per kernel class (tiles, riccati, forward, rollout): total ms, launches, sub-problems processed."""
+    ms, ln, it = (f64 * 4)(), (i64 * 4)(), (i64 * 4)()
+    check(load().dpilqr_profile_read(C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
+    names = ["tiles", "riccati", "forward", "rollout"]
+    return {n: dict(ms=ms[i], launches=ln[i], items=it[i]) for i, n in enumerate(names)}
 
 
 _device_ok = None

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "dpilqr_hip.h"
 #include "forward.hpp"
@@ -192,6 +193,51 @@ struct Mailbox {  // pinned host words the device-side active counters are copie
     }
 };
 thread_local Mailbox g_mail;
+
+// opt-in per-kernel timing (dpilqr_profile_*): event pairs recorded on the solve's own stream
+struct Profiler {
+    bool on = false;
+    double ms[4] = {0, 0, 0, 0};
+    int64_t launches[4] = {0, 0, 0, 0}, items[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> pool;
+    struct Rec { int cls, iter; size_t e0; };
+    std::vector<Rec> recs;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    void begin(int cls, int iter, hipStream_t st) {
+        if (!on) return;
+        recs.push_back({cls, iter, used});
+        hipEvent_t e = next();
+        if (e) (void)hipEventRecord(e, st);
+    }
+    void end(hipStream_t st) {
+        if (!on) return;
+        hipEvent_t e = next();
+        if (e) (void)hipEventRecord(e, st);
+    }
+    // after the stream has been synchronised; active[it] = items processed by iteration it
+    void collect(const int32_t* active, int B) {
+        if (!on) return;
+        for (const Rec& r : recs) {
+            float t = 0.f;
+            if (r.e0 + 1 < pool.size() && hipEventElapsedTime(&t, pool[r.e0], pool[r.e0 + 1]) == hipSuccess) {
+                ms[r.cls] += t;
+                launches[r.cls] += 1;
+                items[r.cls] += (r.iter <= 0) ? B : active[r.iter];
+            }
+        }
+        recs.clear();
+        used = 0;
+    }
+};
+thread_local Profiler g_prof;
 
 }  // namespace
 
@@ -382,9 +428,11 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                        singular, counts, n_counts, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
     HIP_TRY(hipGetLastError());
     // X, J* <- rollout(x0, U)   (control.py:164)
+    g_prof.begin(3, 0, st);
     rc = launch_forward(D, kModeRollout, x0, X, U, nullptr, nullptr, nullptr, 1, nullptr, nullptr, S.J_star, S, nullptr,
                         nullptr, D.B, st);
     if (rc) return rc;
+    g_prof.end(st);
     hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_star, S.J_last);
 
     // Iteration loop.  The set of active items lives on the device (lists/counts); the host only
@@ -396,11 +444,17 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
         const int32_t* cur_n = counts + it;
         S.iter = it;
         S.next_items = lists + (size_t)((it + 1) & 1) * D.B;
+        g_prof.begin(0, it, st);
         if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, st))) return rc;
+        g_prof.end(st);
+        g_prof.begin(1, it, st);
         if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, st))) return rc;
+        g_prof.end(st);
+        g_prof.begin(2, it, st);
         if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, nullptr, nullptr, nullptr,
                                  S, cur, cur_n, upper, st)))
             return rc;
+        g_prof.end(st);
         HIP_TRY(hipMemcpyAsync(g_mail.host + it + 1, counts + it + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
         if (it >= 1) {
@@ -412,6 +466,23 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    g_mail.host[0] = D.B;
+    g_prof.collect(g_mail.host, D.B);
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_profile_enable(int32_t enable) {
+    const int32_t prev = g_prof.on ? 1 : 0;
+    g_prof.on = enable != 0;
+    return prev;
+}
+
+int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset) {
+    if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read: NULL pointer");
+    for (int c = 0; c < 4; ++c) {
+        ms[c] = g_prof.ms[c]; launches[c] = g_prof.launches[c]; items[c] = g_prof.items[c];
+        if (reset) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; g_prof.items[c] = 0; }
+    }
     return DPILQR_OK;
 }
 

@@ -161,6 +161,14 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                            int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
                            double* d_out, void* stream);
 
+/* -------------------------------------------------- measurement hooks (bench.py's roofline leg)
+ * When enabled, dpilqr_solve_batch brackets every kernel launch of its iteration loop with HIP events
+ * recorded on `stream` and accumulates, per calling thread, for each kernel class c
+ * (0 = tile producer, 1 = Riccati sweep, 2 = line search / forward pass, 3 = initial rollout):
+ * total milliseconds, number of launches, and number of sub-problems those launches processed.      */
+int32_t dpilqr_profile_enable(int32_t enable);
+int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset);
+
 /* -------------------------------------------------- (6) dispatch front end ("next" row)
  * define_inter_graph_threshold (distributed.py:224-247) for S scenarios at once:
  * X[S][N][k*n_s] sampled trajectories (N may be 1), adjacency out adj[S][k][k] (int32, incl. self). */

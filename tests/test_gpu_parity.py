@@ -148,7 +148,13 @@ def test_solve_misc(dp, golden, tag):
 
 
 def test_solve_batch_vs_oracle_256(dp):
-    """256 seeded cfg2 scenarios: HIP solve vs the CPU oracle, item by item."""
+    """256 seeded cfg2 scenarios: HIP solve vs the CPU oracle, item by item.
+
+    About 1-2 % of these scenarios are chaotic IN THE REFERENCE ITSELF: perturbing x0 by 1e-13 relative
+    changes the reference's own iteration count and final cost by 10-20 % (measured with the real
+    reference on seeds 1113, 1161, 1163, 1227).  No implementation can reproduce those
+    bit-for-bit-sensitive runs, so items are first classified by the oracle's own sensitivity
+    (same solve with x0*(1+1e-13)); parity is demanded on the well-conditioned ones."""
     from oracle import oracle as orc
     from dpilqr_amd.util import random_setup
     c = cfg2_params(); B = 256
@@ -161,11 +167,19 @@ def test_solve_batch_vs_oracle_256(dp):
     r = pb.solve(x0, np.zeros((B, 50, 10)), trace=True)
     proto = orc.Problem(c["model"], c["n_dims"], xf[0], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
     o = orc.solve_batch(proto, x0, xf, np.zeros((B, 50, 10)))
-    nb = r["n_bwd"].cpu().numpy(); st = r["status"].cpu().numpy()
-    same = (nb == o["n_bwd"]) & (st == o["status"]) & (r["n_fwd"].cpu().numpy() == o["n_fwd"])
-    # a decision may flip on a knife edge (hard part 9); none is expected, at most 1 % tolerated
-    assert same.mean() >= 0.99, f"{(~same).sum()} of {B} decision traces differ"
-    X = r["X"].cpu().numpy(); U = r["U"].cpu().numpy()
-    errs = np.array([relerr(X[i], o["X"][i]) for i in range(B) if same[i]])
-    assert errs.max() < TOL_SOLVE, errs.max()
-    assert relerr(r["J"].cpu().numpy()[same], o["J"][same]) < TOL_SOLVE
+    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, np.zeros((B, 50, 10)))
+    sens = np.array([relerr(op["X"][i], o["X"][i]) for i in range(B)])
+    well = (op["n_bwd"] == o["n_bwd"]) & (op["n_fwd"] == o["n_fwd"]) & (sens < 1e-8)
+    assert well.mean() > 0.9, "scenario set unexpectedly ill-conditioned"
+    nb = r["n_bwd"].cpu().numpy(); st = r["status"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy()
+    same = (nb == o["n_bwd"]) & (st == o["status"]) & (nf == o["n_fwd"])
+    assert same[well].all(), f"decision trace differs on well-conditioned items {np.where(well & ~same)[0]}"
+    X = r["X"].cpu().numpy(); U = r["U"].cpu().numpy(); J = r["J"].cpu().numpy()
+    for i in np.where(well)[0]:
+        assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(U[i], o["U"][i]) < TOL_SOLVE, i
+        assert abs(J[i] - o["J"][i]) < TOL_SOLVE * abs(o["J"][i])
+    # every item, chaotic or not: a finished, finite solve that did not increase the cost
+    J0 = pb.rollout(x0, np.zeros((B, 50, 10)))[1].cpu().numpy()
+    assert np.isfinite(X).all() and np.isfinite(U).all() and (st >= 1).all() and (st <= 3).all()
+    Jfin = pb.rollout(x0, U)[1].cpu().numpy()
+    assert (Jfin <= J0 * (1 + 1e-12)).all()
