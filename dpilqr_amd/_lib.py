@@ -43,7 +43,7 @@ SIGNATURES = {
     "dpilqr_model_integrate": (i32, [i32, i32, vp, vp, vp, f64, vp, vp]),
     "dpilqr_model_linearize": (i32, [i32, i32, vp, vp, vp, f64, vp, vp, vp]),
     "dpilqr_cost_eval": (i32, [_DP, i32, vp, vp, i32, vp, vp]),
-    "dpilqr_tile_layout": (i32, [i32, i32, C.POINTER(i64 * 7), C.POINTER(i64)]),
+    "dpilqr_tile_layout": (i32, [i32, i32, C.POINTER(i64 * 7), C.POINTER(i64 * 7), C.POINTER(i64)]),
     "dpilqr_make_tiles": (i32, [_DP, vp, vp, vp, vp, vp, vp]),
     "dpilqr_rollout": (i32, [_DP, vp, vp, vp, vp, vp]),
     "dpilqr_backward_pass_tiles": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -91,11 +91,15 @@ def alphas():
     return list(a)
 
 
+TILE_PARTS = ["A", "B", "Lxx", "Lux", "Luu", "Lx", "Lu"]
+
+
 def tile_layout(n_x, n_u):
-    off = (i64 * 7)()
+    """-> ({part: (offset, row_stride)}, record_stride), all in doubles."""
+    off, ld = (i64 * 7)(), (i64 * 7)()
     stride = i64(0)
-    check(load().dpilqr_tile_layout(n_x, n_u, C.byref(off), C.byref(stride)))
-    return dict(zip(["A", "B", "Lxx", "Lux", "Luu", "Lx", "Lu"], list(off))), stride.value
+    check(load().dpilqr_tile_layout(n_x, n_u, C.byref(off), C.byref(ld), C.byref(stride)))
+    return {p: (off[i], ld[i]) for i, p in enumerate(TILE_PARTS)}, stride.value
 
 
 def profile_enable(on=True):

@@ -106,11 +106,15 @@ class ProblemBatch:
 
     def unpack_tiles(self, tiles):
         """Tile records -> dict of host arrays shaped like the plugin returns (per item, per step)."""
-        t = tiles.cpu().numpy(); o = self.tile_offsets; n, m = self.n_x, self.n_u
-        cut = lambda key, size, shape: t[:, :, o[key]:o[key] + size].reshape((self.B, self.T + 1) + shape)
-        return dict(A=cut("A", n * n, (n, n)), B=cut("B", n * m, (n, m)), Lxx=cut("Lxx", n * n, (n, n)),
-                    Lux=cut("Lux", m * n, (m, n)), Luu=cut("Luu", m * m, (m, m)), Lx=cut("Lx", n, (n,)),
-                    Lu=cut("Lu", m, (m,)))
+        t = tiles.cpu().numpy(); n, m = self.n_x, self.n_u
+        shapes = dict(A=(n, n), B=(n, m), Lxx=(n, n), Lux=(m, n), Luu=(m, m), Lx=(1, n), Lu=(1, m))
+        out = {}
+        for key, (rows, cols) in shapes.items():
+            off, ld = self.tile_offsets[key]
+            idx = off + (np.arange(rows) * ld)[:, None] + np.arange(cols)[None, :]
+            a = t[:, :, idx]
+            out[key] = a[:, :, 0, :] if key in ("Lx", "Lu") else a
+        return out
 
     def backward_pass(self, X, U, mu, tiles=None):
         """control.py:116-148: K (B,T,n_u,n_x), d (B,T,n_u)."""
@@ -188,10 +192,15 @@ def pack_tiles(A, Bm, Lx, Lu, Lxx, Luu, Lux):
     """
     A = np.asarray(A, dtype=np.float64); Bm = np.asarray(Bm, dtype=np.float64)
     Bn, T, n, m = Bm.shape
-    off, stride = _lib.tile_layout(n, m)
+    lay, stride = _lib.tile_layout(n, m)
     rec = np.zeros((Bn, T + 1, stride))
-    rec[:, :T, off["A"]:off["A"] + n * n] = A.reshape(Bn, T, -1)
-    rec[:, :T, off["B"]:off["B"] + n * m] = Bm.reshape(Bn, T, -1)
-    for key, arr, size in (("Lxx", Lxx, n * n), ("Lux", Lux, m * n), ("Luu", Luu, m * m), ("Lx", Lx, n), ("Lu", Lu, m)):
-        rec[:, :, off[key]:off[key] + size] = np.asarray(arr, dtype=np.float64).reshape(Bn, T + 1, size)
+
+    def put(key, arr, rows, cols, steps):
+        off, ld = lay[key]
+        idx = off + (np.arange(rows) * ld)[:, None] + np.arange(cols)[None, :]
+        rec[:, :steps, idx] = np.asarray(arr, dtype=np.float64).reshape(Bn, steps, rows, cols)
+
+    put("A", A, n, n, T); put("B", Bm, n, m, T)
+    put("Lxx", Lxx, n, n, T + 1); put("Lux", Lux, m, n, T + 1); put("Luu", Luu, m, m, T + 1)
+    put("Lx", Lx, 1, n, T + 1); put("Lu", Lu, 1, m, T + 1)
     return to_dev(rec)

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -14,6 +15,7 @@
 #include "forward.hpp"
 #include "models.hpp"
 #include "riccati.hpp"
+#include "riccati_tiled.hpp"
 #include "tiles.hpp"
 
 using namespace dpilqr;
@@ -93,10 +95,26 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
     return DPILQR_OK;
 }
 
+// compile-time-sized sweeps (one wavefront per sub-problem); everything else takes the generic kernel
+#define DPILQR_TILED_SIZES(X) X(4, 2) X(8, 4) X(12, 6) X(16, 8) X(20, 10)
+
 int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
                        hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
+    static const bool force_generic = getenv("DPILQR_FORCE_GENERIC_RICCATI") != nullptr;
+    if (!force_generic) {
+#define DPILQR_TRY_TILED(NN, MM)                                                                                   \
+    if (n == NN && m == MM) {                                                                                      \
+        static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
+        hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3(grid_items), dim3(64), 0, st, B, T, tiles, mu, K, d,     \
+                           singular, items, n_items);                                                              \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+        DPILQR_TILED_SIZES(DPILQR_TRY_TILED)
+#undef DPILQR_TRY_TILED
+    }
     const size_t lds = riccati_lds_bytes(n, m);
     int32_t rc = allow_lds(k_riccati_generic, lds);
     if (rc) return rc;
@@ -309,11 +327,13 @@ int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const dou
     return DPILQR_OK;
 }
 
-int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t* stride) {
-    if (n_x < 1 || n_u < 1 || !offsets || !stride) return fail(DPILQR_EINVAL, "tile_layout: bad argument");
+int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t row_strides[7], int64_t* stride) {
+    if (n_x < 1 || n_u < 1 || !offsets || !row_strides || !stride) return fail(DPILQR_EINVAL, "tile_layout: bad argument");
     const TileLayout L(n_x, n_u);
     offsets[0] = L.oA; offsets[1] = L.oB; offsets[2] = L.oLxx; offsets[3] = L.oLux; offsets[4] = L.oLuu;
     offsets[5] = L.oLx; offsets[6] = L.oLu;
+    row_strides[0] = L.ldAB; row_strides[1] = L.ldAB; row_strides[2] = n_x; row_strides[3] = n_x; row_strides[4] = n_u;
+    row_strides[5] = 1; row_strides[6] = 1;
     *stride = L.stride;
     return DPILQR_OK;
 }

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
     const TileLayout L(n, m);
     const RiccatiLds O(n, m);
     extern __shared__ double lds[];
-    double* sA = lds + O.AB;
-    double* sB = sA + n * n;
+    double* sAB = lds + O.AB;   // rows [A[l][:] | B[l][:]], leading dimension n+m (as in the record)
+    const int ld = n + m;
+    const double* sA = sAB;
+    const double* sB = sAB + n;
     double* bufX = lds + O.X;
     double* bufY = lds + O.Y;
     double* sT2 = lds + O.T2;
@@ -91,14 +93,14 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
     for (int t = T - 1; t >= 0; --t) {
         const double* rec = base + (int64_t)t * L.stride;
         // stage A | B (contiguous in the record) -- the only tile parts used more than once
-        for (int e = tid; e < n * n + n * m; e += nth) sA[e] = rec[L.oA + e];
+        for (int e = tid; e < n * ld; e += nth) sAB[e] = rec[L.oA + e];
         __syncthreads();
 
         // (1) W = A^T P ; T2 = B^T (P + mu I) ; Q_x, Q_u
         for (int e = tid; e < n * n; e += nth) {
             const int i = e / n, j = e - i * n;
             double s = 0.0;
-            for (int l = 0; l < n; ++l) s = fma(sA[l * n + i], P[l * n + j], s);
+            for (int l = 0; l < n; ++l) s = fma(sA[l * ld + i], P[l * n + j], s);
             W[e] = s;
         }
         for (int e = tid; e < m * n; e += nth) {
@@ -106,18 +108,18 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
             double s = 0.0;
             for (int l = 0; l < n; ++l) {
                 const double pv = (l == j) ? P[l * n + j] + mu : P[l * n + j];
-                s = fma(sB[l * m + a], pv, s);
+                s = fma(sB[l * ld + a], pv, s);
             }
             sT2[e] = s;
         }
         for (int i = tid; i < n + m; i += nth) {
             double s = 0.0;
             if (i < n) {
-                for (int l = 0; l < n; ++l) s = fma(sA[l * n + i], sp[l], s);
+                for (int l = 0; l < n; ++l) s = fma(sA[l * ld + i], sp[l], s);
                 sQx[i] = rec[L.oLx + i] + s;
             } else {
                 const int a = i - n;
-                for (int l = 0; l < n; ++l) s = fma(sB[l * m + a], sp[l], s);
+                for (int l = 0; l < n; ++l) s = fma(sB[l * ld + a], sp[l], s);
                 sQu[a] = rec[L.oLu + a] + s;
             }
         }
@@ -127,13 +129,13 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
         for (int e = tid; e < n * n; e += nth) {
             const int i = e / n, j = e - i * n;
             double s = 0.0;
-            for (int l = 0; l < n; ++l) s = fma(W[i * n + l], sA[l * n + j], s);
+            for (int l = 0; l < n; ++l) s = fma(W[i * n + l], sA[l * ld + j], s);
             P[e] = rec[L.oLxx + e] + s;
         }
         for (int e = tid; e < m * n; e += nth) {
             const int a = e / n, j = e - a * n;
             double s = 0.0;
-            for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sA[l * n + j], s);
+            for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sA[l * ld + j], s);
             const double q = rec[L.oLux + e] + s;
             sQux[e] = q;
             sK[a * n1 + j] = q;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
         for (int e = tid; e < m * m; e += nth) {
             const int a = e / m, c = e - a * m;
             double s = 0.0;
-            for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sB[l * m + c], s);
+            for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sB[l * ld + c], s);
             const double q = rec[L.oLuu + e] + s;
             sQuu[e] = q;
             sLU[e] = q;

@@ -1,0 +1,388 @@
+// riccati_tiled.hpp -- K2, compile-time-sized: the Riccati backward sweep with ONE WAVEFRONT per
+// sub-problem (ilqrSolver._backward_pass, control.py:116-148).
+//
+// Same recursion as riccati.hpp (see the equations there); this kernel is the fast path for the
+// sizes it is instantiated for.  Design, for n = n_x, m = n_u known at compile time:
+//
+//  * the value function [P | p] (and a copy with mu on the diagonal, for the two products that the
+//    reference regularises) stays in LDS for the whole horizon; nothing but the tile records is read
+//    from HBM and nothing but K[t], d[t] is written.
+//  * each step's record is fetched ONE STEP AHEAD straight into registers (16-byte loads issued at the
+//    top of step t for record t-1, consumed at the top of step t-1), so the HBM latency hides under
+//    the arithmetic of a whole step; only [A|B] (used by two products) is then parked in LDS.
+//  * the dense products run as register-blocked outer products: a lane owns an RB x CB block of the
+//    output, reads RB + CB operands per reduction step with ds_read_b128 and issues RB*CB fp64 FMAs.
+//    Products are STACKED so that one pass serves several of the reference's expressions:
+//        S1  [A|B]^T [P|p]      -> A^T P, B^T (P + mu I), A^T p, B^T p          ((n+m) x (n+1))
+//        S2  [T1;T2] [A|B]      -> (A^T P) A, (B^T P~) A, (B^T P~) B           ((n+m) x (n+m))
+//        S5  T3 [K|d], K^T [Q_ux|Q_u], Q_ux^T [K|d]   -> P and p updates       (n x (n+1), three sums)
+//    Operands are kept in LDS in the orientation that makes every operand read contiguous.
+//  * the Q_uu solve is LU with partial pivoting held entirely in registers: lane c owns column c of
+//    the augmented matrix [Q_uu | Q_ux | Q_u]; pivot row and multipliers travel by v_readlane.
+//  * no workgroup barriers: a single wave executes its LDS operations in order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tiles.hpp"
+
+namespace dpilqr {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define DPILQR_LDS_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+template <int N, int M>
+struct TiledCfg {
+    static constexpr int NM = N + M;
+    static constexpr int RB = (N % 4 == 0) ? 4 : 2;   // block edge of the stacked products (divides N)
+    static constexpr int CB = RB;
+    static constexpr int NMP = round_up(NM, RB);      // padded stacked dimension
+    static constexpr int LAB = NMP;                   // leading dim of sAB and sT
+    static constexpr int LP = round_up(N + 1, CB);    // [P | p | pad]
+    static constexpr int NP = round_up(N + 1, 2);     // [K | d | pad], [Q_xx | Q_x | pad] logical width
+    static constexpr int LQ = NP;
+    static constexpr int LK = NP;
+    static constexpr int LG = round_up(M + N + 2, 4); // [Q_uu | Q_ux | Q_u | pad]
+    // LDS carve (doubles)
+    static constexpr int oAB = 0;
+    static constexpr int oP = oAB + N * LAB;
+    static constexpr int oPt = oP + N * LP;
+    static constexpr int oT = oPt + N * LP;
+    static constexpr int oQ = oT + N * LAB;
+    static constexpr int oG = oQ + N * LQ;
+    static constexpr int oK = oG + M * LG;
+    static constexpr int oT3 = oK + M * LK;
+    static constexpr int total = oT3 + M * N;
+    static constexpr bool supported = (N % 2 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 64 * 1024);
+    // per-lane prefetch of [A|B]: 16-byte pairs, round-robin over the wave
+    static constexpr int AB_PAIRS = N * NM / 2;
+    static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
+};
+
+// acc[r][c] += sum_l X[l*LDX + r] * Y[l*LDY + c]   (X, Y already offset to the block's first row/col)
+template <int RBK, int CBK, int L, int LDX, int LDY>
+__device__ __forceinline__ void block_product(const double* __restrict__ X, const double* __restrict__ Y,
+                                              double (&acc)[RBK][CBK]) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        double a[RBK], b[CBK];
+#pragma unroll
+        for (int r = 0; r < RBK; r += 2) {
+            const v2d t = *reinterpret_cast<const v2d*>(X + l * LDX + r);
+            a[r] = t.x; a[r + 1] = t.y;
+        }
+#pragma unroll
+        for (int c = 0; c < CBK; c += 2) {
+            const v2d t = *reinterpret_cast<const v2d*>(Y + l * LDY + c);
+            b[c] = t.x; b[c + 1] = t.y;
+        }
+#pragma unroll
+        for (int r = 0; r < RBK; ++r)
+#pragma unroll
+            for (int c = 0; c < CBK; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+    }
+}
+
+template <int N, int M>
+__global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double* __restrict__ tiles,
+                                                       const double* __restrict__ mu_arr, double* __restrict__ Kout,
+                                                       double* __restrict__ dout, int32_t* __restrict__ singular,
+                                                       const int32_t* __restrict__ items,
+                                                       const int32_t* __restrict__ n_items) {
+    using C = TiledCfg<N, M>;
+    constexpr int NM = C::NM, RB = C::RB, CB = C::CB, NMP = C::NMP, LAB = C::LAB, LP = C::LP, NP = C::NP;
+    constexpr int LQ = C::LQ, LK = C::LK, LG = C::LG;
+    const int slot = blockIdx.x;
+    if (n_items && slot >= *n_items) return;
+    const int b = items ? items[slot] : slot;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const TileLayout L(N, M);
+
+    __shared__ __attribute__((aligned(16))) double lds[C::total];
+    double* sAB = lds + C::oAB;
+    double* sP = lds + C::oP;
+    double* sPt = lds + C::oPt;
+    double* sT = lds + C::oT;
+    double* sQ = lds + C::oQ;
+    double* sG = lds + C::oG;
+    double* sK = lds + C::oK;
+    double* sT3 = lds + C::oT3;
+
+    const double mu = mu_arr[b];
+    const double* base = tiles + (int64_t)b * (T + 1) * L.stride;
+    int sing = 0;
+
+    // ---- one-time LDS initialisation: zero everything (pads must stay finite), then P, p from record T
+    for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
+    DPILQR_LDS_FENCE();
+    {
+        const double* rec = base + (int64_t)T * L.stride;
+        for (int e = lane; e < N * N; e += 64) {
+            const int i = e / N, j = e - i * N;
+            const double v = rec[L.oLxx + e];
+            sP[i * LP + j] = v;
+            sPt[i * LP + j] = (i == j) ? v + mu : v;
+        }
+        for (int i = lane; i < N; i += 64) {
+            const double v = rec[L.oLx + i];
+            sP[i * LP + N] = v;
+            sPt[i * LP + N] = v;
+        }
+    }
+
+    // ---- per-lane block coordinates (constant over the horizon)
+    // S1: rows of [A|B]^T (NMP/RB) x cols of [P|p] (LP/CB)
+    constexpr int S1_CB = LP / CB, S1_BLOCKS = (NMP / RB) * S1_CB;
+    const int s1 = lane < S1_BLOCKS ? lane : S1_BLOCKS - 1;
+    const int s1_i0 = (s1 / S1_CB) * RB, s1_j0 = (s1 % S1_CB) * CB;
+    static_assert(S1_BLOCKS <= 64, "S1 needs one block per lane");
+    // S2: (NMP/RB) x (NMP/CB)
+    constexpr int S2_CB = NMP / CB, S2_BLOCKS = (NMP / RB) * S2_CB;
+    static_assert(S2_BLOCKS <= 64, "S2 needs one block per lane");
+    const int s2 = lane < S2_BLOCKS ? lane : S2_BLOCKS - 1;
+    const int s2_i0 = (s2 / S2_CB) * RB, s2_j0 = (s2 % S2_CB) * CB;
+    // region of the S2 block: 0 Q_xx, 1 Q_ux, 2 Q_uu, 3 unused (T1 B)
+    const int s2_reg = (s2_i0 < N) ? ((s2_j0 < N) ? 0 : 3) : ((s2_j0 < N) ? 1 : 2);
+    // record offset of the block's first l-value and its row stride
+    int s2_loff, s2_lld;
+    if (s2_reg == 0) { s2_loff = L.oLxx + s2_i0 * N + s2_j0; s2_lld = N; }
+    else if (s2_reg == 1) { s2_loff = L.oLux + (s2_i0 - N) * N + s2_j0; s2_lld = N; }
+    else { s2_loff = L.oLuu + (s2_i0 - N) * M + (s2_j0 - N); s2_lld = M; }
+    // S4: T3^T (M x N) in 2x2 blocks ; S5/S6: N x NP in RB x 2 blocks
+    constexpr int S4_CB = N / 2, S4_BLOCKS = (M / 2) * S4_CB;
+    static_assert(S4_BLOCKS <= 64, "S4 needs one block per lane");
+    const int s4 = lane < S4_BLOCKS ? lane : S4_BLOCKS - 1;
+    const int s4_c0 = (s4 / S4_CB) * 2, s4_i0 = (s4 % S4_CB) * 2;
+    constexpr int S5_CB = NP / 2, S5_BLOCKS = (N / RB) * S5_CB;
+    static_assert(S5_BLOCKS <= 64, "S5 needs one block per lane");
+    const int s5 = lane < S5_BLOCKS ? lane : S5_BLOCKS - 1;
+    const int s5_i0 = (s5 / S5_CB) * RB, s5_j0 = (s5 % S5_CB) * 2;
+    // [A|B] prefetch: pair q of this lane -> LDS destination
+    int ab_dst[C::AB_ROUNDS];
+#pragma unroll
+    for (int q = 0; q < C::AB_ROUNDS; ++q) {
+        const int e = 2 * (lane + 64 * q);
+        const int row = e / NM, col = e - row * NM;
+        ab_dst[q] = (e < N * NM) ? row * LAB + col : -1;
+    }
+
+    // ---- prefetch registers
+    v2d nAB[C::AB_ROUNDS];
+    v2d nL[RB][CB / 2];      // l-values of the S2 block
+    v2d nLxu[RB / 2];        // [l_x ; l_u][s1_i0 .. s1_i0+RB)
+    auto prefetch = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
+#pragma unroll
+        for (int q = 0; q < C::AB_ROUNDS; ++q)
+            if (ab_dst[q] >= 0) nAB[q] = *reinterpret_cast<const v2d*>(rec + L.oA + 2 * (lane + 64 * q));
+        if (s2_reg != 3) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < CB / 2; ++c) {
+                    const bool ok = (s2_i0 + r < NM) && (s2_j0 + 2 * c < NM);
+                    nL[r][c] = ok ? *reinterpret_cast<const v2d*>(rec + s2_loff + r * s2_lld + 2 * c) : v2d{0.0, 0.0};
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < RB / 2; ++r)
+            nLxu[r] = (s1_i0 + 2 * r < NM) ? *reinterpret_cast<const v2d*>(rec + L.oLx + s1_i0 + 2 * r) : v2d{0.0, 0.0};
+    };
+    prefetch(T - 1);
+
+    for (int t = T - 1; t >= 0; --t) {
+        // ---- S0: park [A|B] of record t in LDS, take over the l-values, fetch record t-1
+        v2d cL[RB][CB / 2], cLxu[RB / 2];
+#pragma unroll
+        for (int q = 0; q < C::AB_ROUNDS; ++q)
+            if (ab_dst[q] >= 0) *reinterpret_cast<v2d*>(sAB + ab_dst[q]) = nAB[q];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB / 2; ++c) cL[r][c] = nL[r][c];
+#pragma unroll
+        for (int r = 0; r < RB / 2; ++r) cLxu[r] = nLxu[r];
+        if (t > 0) prefetch(t - 1);
+        DPILQR_LDS_FENCE();
+
+        // ---- S1: [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (B rows against P + mu I)
+        {
+            double acc[RB][CB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) acc[r][c] = 0.0;
+            const double* Pm = (s1_i0 < N) ? sP : sPt;
+            block_product<RB, CB, N, LAB, LP>(sAB + s1_i0, Pm + s1_j0, acc);
+            if (lane < S1_BLOCKS) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int j = s1_j0 + c;
+                    if (j < N) {  // T^T[j][i'] : the operand orientation S2 wants
+#pragma unroll
+                        for (int r = 0; r < RB; r += 2)
+                            *reinterpret_cast<v2d*>(sT + j * LAB + s1_i0 + r) = v2d{acc[r][c], acc[r + 1][c]};
+                    } else if (j == N) {  // Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) {
+                            const int i = s1_i0 + r;
+                            const double lv = (r & 1) ? cLxu[r / 2].y : cLxu[r / 2].x;
+                            if (i < N) sQ[i * LQ + N] = lv + acc[r][c];
+                            else if (i < NM) sG[(i - N) * LG + M + N] = lv + acc[r][c];
+                        }
+                    }
+                }
+            }
+        }
+        DPILQR_LDS_FENCE();
+
+        // ---- S2: [T1;T2][A|B] -> Q_xx, Q_ux, Q_uu
+        {
+            double acc[RB][CB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) acc[r][c] = 0.0;
+            block_product<RB, CB, N, LAB, LAB>(sT + s2_i0, sAB + s2_j0, acc);
+            if (lane < S2_BLOCKS && s2_reg != 3) {
+                double* dst;
+                int ld;
+                if (s2_reg == 0) { dst = sQ + s2_i0 * LQ + s2_j0; ld = LQ; }
+                else if (s2_reg == 1) { dst = sG + (s2_i0 - N) * LG + M + s2_j0; ld = LG; }
+                else { dst = sG + (s2_i0 - N) * LG + (s2_j0 - N); ld = LG; }
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int c = 0; c < CB; c += 2)
+                        if (s2_i0 + r < NM && s2_j0 + c < NM)
+                            *reinterpret_cast<v2d*>(dst + r * ld + c) =
+                                v2d{cL[r][c / 2].x + acc[r][c], cL[r][c / 2].y + acc[r][c + 1]};
+            }
+        }
+        DPILQR_LDS_FENCE();
+
+        // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers
+        {
+            const int col = lane < M + N + 1 ? lane : M + N;
+            double v[M], invd[M];
+#pragma unroll
+            for (int r = 0; r < M; ++r) v[r] = sG[r * LG + col];
+#pragma unroll
+            for (int kk = 0; kk < M; ++kk) {
+                int piv = kk;
+                double best = fabs(v[kk]);
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r) {
+                    const double av = fabs(v[r]);
+                    if (av > best) { best = av; piv = r; }
+                }
+                piv = __builtin_amdgcn_readlane(piv, kk);  // column kk decides the pivot row
+                if (piv != kk) {                           // wave-uniform
+#pragma unroll
+                    for (int r = kk + 1; r < M; ++r)
+                        if (r == piv) { const double tv = v[r]; v[r] = v[kk]; v[kk] = tv; }
+                }
+                const double pv = readlane_f64(v[kk], kk);
+                if (pv == 0.0) sing = 1;
+                const double inv = 1.0 / pv;
+                invd[kk] = inv;
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r) {
+                    const double l = readlane_f64(v[r], kk) * inv;
+                    v[r] = fma(-l, v[kk], v[r]);
+                }
+            }
+#pragma unroll
+            for (int r = M - 1; r >= 0; --r) {
+                double s = v[r];
+#pragma unroll
+                for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
+                v[r] = s * invd[r];
+            }
+            // K = -X (lanes M..M+N-1 hold its columns), d = -x (lane M+N)
+            if (lane >= M && lane <= M + N) {
+                const int j = lane - M;
+                double* Kt = Kout + ((int64_t)b * T + t) * M * N;
+                double* dt_ = dout + ((int64_t)b * T + t) * M;
+#pragma unroll
+                for (int a = 0; a < M; ++a) {
+                    const double kv = -v[a];
+                    sK[a * LK + j] = kv;
+                    if (j < N) Kt[a * N + j] = kv; else dt_[a] = kv;
+                }
+            }
+        }
+        DPILQR_LDS_FENCE();
+
+        // ---- S4: T3^T = Q_uu^T-contracted K : T3T[c][i] = sum_a Q_uu[a][c] K[a][i]
+        {
+            double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+            block_product<2, 2, M, LG, LK>(sG + s4_c0, sK + s4_i0, acc);
+            if (lane < S4_BLOCKS) {
+                *reinterpret_cast<v2d*>(sT3 + s4_c0 * N + s4_i0) = v2d{acc[0][0], acc[0][1]};
+                *reinterpret_cast<v2d*>(sT3 + (s4_c0 + 1) * N + s4_i0) = v2d{acc[1][0], acc[1][1]};
+            }
+        }
+        DPILQR_LDS_FENCE();
+
+        // ---- S5: V = ((Q_xx + T3 K) + K^T Q_ux) + Q_ux^T K, with [K|d] and [Q_ux|Q_u] carrying the p update
+        double vb[RB][2];
+        {
+            double a1[RB][2], a2[RB][2], a3[RB][2];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) { a1[r][0] = a1[r][1] = a2[r][0] = a2[r][1] = a3[r][0] = a3[r][1] = 0.0; }
+            block_product<RB, 2, M, N, LK>(sT3 + s5_i0, sK + s5_j0, a1);
+            block_product<RB, 2, M, LK, LG>(sK + s5_i0, sG + M + s5_j0, a2);
+            block_product<RB, 2, M, LG, LK>(sG + M + s5_i0, sK + s5_j0, a3);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const v2d q = *reinterpret_cast<const v2d*>(sQ + (s5_i0 + r) * LQ + s5_j0);
+                vb[r][0] = ((q.x + a1[r][0]) + a2[r][0]) + a3[r][0];
+                vb[r][1] = ((q.y + a1[r][1]) + a2[r][1]) + a3[r][1];
+            }
+            DPILQR_LDS_FENCE();
+            if (lane < S5_BLOCKS) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    *reinterpret_cast<v2d*>(sQ + (s5_i0 + r) * LQ + s5_j0) = v2d{vb[r][0], vb[r][1]};
+            }
+        }
+        DPILQR_LDS_FENCE();
+
+        // ---- S6: P <- (V + V^T)/2 (and its regularised copy) ; p <- V[:, n]
+        if (lane < S5_BLOCKS) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = s5_j0 + c;
+                if (j < N) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const int i = s5_i0 + r;
+                        const double pn = 0.5 * (vb[r][c] + sQ[j * LQ + i]);
+                        sP[i * LP + j] = pn;
+                        sPt[i * LP + j] = (i == j) ? pn + mu : pn;
+                    }
+                } else if (j == N) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        sP[(s5_i0 + r) * LP + N] = vb[r][c];
+                        sPt[(s5_i0 + r) * LP + N] = vb[r][c];
+                    }
+                }
+            }
+        }
+        DPILQR_LDS_FENCE();
+    }
+    if (singular && sing && lane == 0) singular[b] = 1;
+}
+
+}  // namespace dpilqr

@@ -19,18 +19,24 @@
 namespace dpilqr {
 
 struct TileLayout {
+    // One record = [ AB n x (n+m) | L_xx n x n | L_ux m x n | L_uu m x m | L_x n | L_u m ], every component
+    // starting on a 16-byte boundary.  A and B are stored INTERLEAVED, row l = [A[l][0..n) | B[l][0..m)],
+    // so that the sweep's stacked products ([A|B]^T P and [T1;T2][A|B]) stream contiguous rows.
     int n, m;              // n_x, n_u
-    int oA, oB, oLxx, oLux, oLuu, oLx, oLu;
+    int oA, oB, ldAB;      // A[l][i] at oA + l*ldAB + i ; B[l][a] at oB + l*ldAB + a (oB = oA + n)
+    int oLxx, oLux, oLuu, oLx, oLu;
     int stride;            // doubles per record (even -> 16-byte aligned records)
+    __host__ __device__ static int even(int x) { return (x + 1) & ~1; }
     __host__ __device__ TileLayout(int n_x, int n_u) : n(n_x), m(n_u) {
+        ldAB = n + m;
         oA = 0;
-        oB = oA + n * n;
-        oLxx = oB + n * m;
-        oLux = oLxx + n * n;
-        oLuu = oLux + m * n;
-        oLx = oLuu + m * m;
-        oLu = oLx + n;
-        stride = (oLu + m + 1) & ~1;
+        oB = n;
+        oLxx = even(n * ldAB);
+        oLux = even(oLxx + n * n);
+        oLuu = even(oLux + m * n);
+        oLx = even(oLuu + m * m);
+        oLu = oLx + n;     // [L_x | L_u] contiguous: the sweep reads them as one (n+m)-vector
+        stride = even(oLu + m);
     }
 };
 
@@ -105,12 +111,12 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
         for (int e = lane; e < n * n; e += 64) {
             const int i = e / n, j = e - i * n;
             const int ai = i / NS, aj = j / NS;
-            rec[L.oA + e] = (ai == aj) ? sA[ai * NS * NS + (i - ai * NS) * NS + (j - aj * NS)] : 0.0;
+            rec[L.oA + i * L.ldAB + j] = (ai == aj) ? sA[ai * NS * NS + (i - ai * NS) * NS + (j - aj * NS)] : 0.0;
         }
         for (int e = lane; e < n * m; e += 64) {
             const int i = e / m, j = e - i * m;
             const int ai = i / NS, aj = j / NC;
-            rec[L.oB + e] = (ai == aj) ? sB[ai * NS * NC + (i - ai * NS) * NC + (j - aj * NC)] : 0.0;
+            rec[L.oB + i * L.ldAB + j] = (ai == aj) ? sB[ai * NS * NC + (i - ai * NS) * NC + (j - aj * NC)] : 0.0;
         }
         for (int e = lane; e < m * n; e += 64) rec[L.oLux + e] = 0.0;  // L_ux = 0 (cost.py:93,231)
         for (int e = lane; e < m * m; e += 64) {

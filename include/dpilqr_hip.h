@@ -112,11 +112,13 @@ int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const dou
 /* -------------------------------------------------- (3) tiles: the plugin contract of the sweep
  * One "tile record" per (item, time step) holds what DynamicalModel.linearize (dynamics.py:173-186)
  * and Cost.quadraticize (cost.py:208-239) return at (X[t],U[t]), packed as
- *     [ A n_x*n_x | B n_x*n_u | L_xx n_x*n_x | L_ux n_u*n_x | L_uu n_u*n_u | L_x n_x | L_u n_u ]
- * record t = T holds the terminal quadraticisation (only L_xx, L_x are read).
- * dpilqr_tile_layout returns the 7 offsets (in doubles, order A,B,Lxx,Lux,Luu,Lx,Lu) and the
- * record stride; a tile buffer is [B][T+1][stride] doubles. */
-int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t* stride);
+ *     [ AB n_x*(n_x+n_u) | L_xx n_x*n_x | L_ux n_u*n_x | L_uu n_u*n_u | L_x n_x | L_u n_u ]
+ * where AB stores A and B interleaved by row: row l = [ A[l][0..n_x) | B[l][0..n_u) ].
+ * Record t = T holds the terminal quadraticisation (only L_xx, L_x are read).
+ * dpilqr_tile_layout returns, for the 7 components in the order A,B,Lxx,Lux,Luu,Lx,Lu, the offset of
+ * element [0][0] and the row stride (both in doubles), plus the record stride; a tile buffer is
+ * [B][T+1][stride] doubles.  Component offsets and the record stride are 16-byte aligned. */
+int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t row_strides[7], int64_t* stride);
 /* device-side producer for the recognised plugin types; X[B][T+1][n_x], U[B][T][n_u].
  * items/n_items select a subset (device int32 list + device count); NULL/NULL = all B items.      */
 int32_t dpilqr_make_tiles(const dpilqr_batch_desc* desc, const double* X, const double* U, double* tiles,

@@ -169,7 +169,7 @@ def test_solve_batch_vs_oracle_256(dp):
     o = orc.solve_batch(proto, x0, xf, np.zeros((B, 50, 10)))
     op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, np.zeros((B, 50, 10)))
     sens = np.array([relerr(op["X"][i], o["X"][i]) for i in range(B)])
-    well = (op["n_bwd"] == o["n_bwd"]) & (op["n_fwd"] == o["n_fwd"]) & (sens < 1e-8)
+    well = (op["n_bwd"] == o["n_bwd"]) & (op["n_fwd"] == o["n_fwd"]) & (sens < 1e-6)
     assert well.mean() > 0.9, "scenario set unexpectedly ill-conditioned"
     nb = r["n_bwd"].cpu().numpy(); st = r["status"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy()
     same = (nb == o["n_bwd"]) & (st == o["status"]) & (nf == o["n_fwd"])
