@@ -22,6 +22,9 @@ __device__ inline double pair_cost(const double* a, const double* b, int nd, dou
         const double df = a[c] - b[c];
         s += df * df;
     }
+    // far pairs contribute exactly 0: skip the fp64 square root when d^2 is safely beyond r^2
+    // (fmin(0, d - r) = 0 whenever d > r; the 1e-12 margin covers the rounding of r*r and of sqrt)
+    if (s > radius * radius * (1.0 + 1e-12)) return 0.0;
     const double m = fmin(0.0, sqrt(s) - radius);
     return m * m;
 }

@@ -133,6 +133,8 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     const int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
     if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
     const size_t lds = forward_lds_bytes(n, m, D.k, ngrp);
+    if ((m * n + threads - 1) / threads > kMaxStage)
+        return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
     DISPATCH_FAMILY(D.n_s, {
         int32_t rc = allow_lds(k_forward<NS, NC>, lds);
         if (rc) return rc;
@@ -179,7 +181,7 @@ __global__ void k_finish_status(int B, int32_t* status) {  // n_lqr_iter == 0: n
 }
 
 struct SolveWorkspace {
-    size_t tiles, K, d, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
+    size_t tiles, K, d, Xc, Uc, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
     SolveWorkspace(const dpilqr_batch_desc& D, int n_lqr_iter_max) {
         const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T;
         const TileLayout L((int)n, (int)m);
@@ -188,6 +190,9 @@ struct SolveWorkspace {
         tiles = o;    o = al(o + sizeof(double) * B * (T + 1) * L.stride);
         K = o;        o = al(o + sizeof(double) * B * T * m * n);
         d = o;        o = al(o + sizeof(double) * B * T * m);
+        // line-search candidates: every alpha's trajectory, so that accepting one is a copy, not a re-roll
+        Xc = o;       o = al(o + sizeof(double) * B * DPILQR_N_ALPHA * (T + 1) * n);
+        Uc = o;       o = al(o + sizeof(double) * B * DPILQR_N_ALPHA * T * m);
         mu = o;       o = al(o + sizeof(double) * B);
         delta = o;    o = al(o + sizeof(double) * B);
         J_star = o;   o = al(o + sizeof(double) * B);
@@ -422,6 +427,8 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     double* K = K_out ? K_out : reinterpret_cast<double*>(ws + W.K);
     double* d = d_out ? d_out : reinterpret_cast<double*>(ws + W.d);
     double* alphas = reinterpret_cast<double*>(ws + W.alphas);
+    double* Xc = reinterpret_cast<double*>(ws + W.Xc);
+    double* Uc = reinterpret_cast<double*>(ws + W.Uc);
     int32_t* lists = reinterpret_cast<int32_t*>(ws + W.lists);
     int32_t* counts = reinterpret_cast<int32_t*>(ws + W.counts);
     int32_t* singular = reinterpret_cast<int32_t*>(ws + W.singular);
@@ -471,7 +478,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
         if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, st))) return rc;
         g_prof.end(st);
         g_prof.begin(2, it, st);
-        if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, nullptr, nullptr, nullptr,
+        if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr,
                                  S, cur, cur_n, upper, st)))
             return rc;
         g_prof.end(st);

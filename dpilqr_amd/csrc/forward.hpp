@@ -55,69 +55,100 @@ struct ForwardLds {
 };
 inline size_t forward_lds_bytes(int n, int m, int k, int ngrp) { return sizeof(double) * (size_t)ForwardLds(n, m, k, ngrp).total; }
 
+// Workgroup-wide LDS hand-off.  A single-wave workgroup executes its LDS operations in order, so a
+// compiler fence is enough; larger workgroups use a bare s_barrier behind an LDS-only wait (NOT
+// __syncthreads(), whose vmcnt(0) would drain the global prefetches that are meant to stay in flight).
+__device__ __forceinline__ void lds_handoff(bool single_wave) {
+    if (single_wave) asm volatile("" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step: ceil(n_u*n_x / threads) must not exceed this
+
 // One pass over the horizon for the calling thread's (candidate g, agent a).
 //   GAINS : u = U + (K dx + alpha d) (control.py:104-107) ; else u = U (control.py:89)
-//   COST  : accumulate J on the a==0 lane of each candidate (returned there)
-//   Xw/Uw : where to write the new trajectory for this candidate (null = do not write); may alias
-//           Xold/Uold (in-place update by the accepted candidate): old X[t+1] is read before it is
-//           overwritten.
-template <int NS, int NC, bool GAINS, bool COST>
-__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int b, bool active, int g,
-                               int a, int ngrp, const double* x_init, const double* Xold,
-                               const double* Uold, const double* __restrict__ Kb,
-                               const double* __restrict__ db, double alpha, double* Xw, double* Uw, double* lds) {
+//   Xw/Uw : where to write this candidate's trajectory (null = nowhere); never aliases Xold/Uold.
+// Everything a step needs from HBM (K[t], d[t], X[t], U[t]) is fetched one step ahead into registers.
+// Returns J on the a == 0 lane of each candidate.
+template <int NS, int NC, bool GAINS>
+__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, bool active, int g, int a,
+                               int ngrp, const double* x_init, const double* __restrict__ Xold,
+                               const double* __restrict__ Uold, const double* __restrict__ Kb,
+                               const double* __restrict__ db, double alpha, double* __restrict__ Xw,
+                               double* __restrict__ Uw, double* lds) {
     const int k = D.k, T = D.T, n = k * NS, m = k * NC;
     const int npairs = k * (k - 1) / 2, np1 = npairs > 0 ? npairs : 1;
     const ForwardLds O(n, m, k, ngrp);
     const int gg = active ? g : 0;
     const int tid = threadIdx.x, nth = blockDim.x;
+    const bool single_wave = nth <= 64;
+    const int mn = m * n;
 
-    double x[NS], xold_next[NS];
+    double x[NS], xold[NS], u[NC], stK[kMaxStage], std_ = 0.0;
     const int model = active ? P.model[a] : 0;
     const double* xf = P.xf + a * NS;
     const double* Qa = P.Q + a * NS * NS;
     const double* Ra = P.R + a * NC * NC;
     const double* Qfa = P.Qf + a * NS * NS;
+
+    auto fetch = [&](int t) {  // registers <- HBM for step t
+        if (GAINS) {
+            const double* Kt = Kb + (int64_t)t * mn;
+#pragma unroll
+            for (int q = 0; q < kMaxStage; ++q) {
+                const int e = tid + q * nth;
+                if (e < mn) stK[q] = Kt[e];
+            }
+            if (tid < m) std_ = db[(int64_t)t * m + tid];
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) u[i] = Uold[(int64_t)t * m + a * NC + i];
+            if (GAINS) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xold[i] = Xold[(int64_t)t * n + a * NS + i];
+            }
+        }
+    };
+
     if (active) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            x[i] = x_init[a * NS + i];
-            xold_next[i] = GAINS ? Xold[a * NS + i] : 0.0;
-        }
+        for (int i = 0; i < NS; ++i) x[i] = x_init[a * NS + i];
         if (Xw) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) Xw[a * NS + i] = x[i];
         }
     }
+    fetch(0);
     double J = 0.0;
 
     for (int t = 0; t < T; ++t) {
         const int par = t & 1;
-        double* sKt = lds + O.Kt + par * m * n;
+        double* sKt = lds + O.Kt + par * mn;
         double* sdt = lds + O.dt + par * m;
         double* sdx = lds + O.dx + (par * ngrp + gg) * n;
         double* sxs = lds + O.xs + (par * ngrp + gg) * n;
-        if (GAINS) {  // stage K[t], d[t] for the whole workgroup
-            const double* Kt = Kb + (int64_t)t * m * n;
-            for (int e = tid; e < m * n; e += nth) sKt[e] = Kt[e];
-            for (int e = tid; e < m; e += nth) sdt[e] = db[(int64_t)t * m + e];
+        double ut[NC];
+        if (GAINS) {
+#pragma unroll
+            for (int q = 0; q < kMaxStage; ++q) {
+                const int e = tid + q * nth;
+                if (e < mn) sKt[e] = stK[q];
+            }
+            if (tid < m) sdt[tid] = std_;
         }
-        double u[NC];
         if (active) {
 #pragma unroll
-            for (int i = 0; i < NC; ++i) u[i] = Uold[(int64_t)t * m + a * NC + i];
+            for (int i = 0; i < NC; ++i) ut[i] = u[i];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                if (GAINS) sdx[a * NS + i] = x[i] - xold_next[i];  // dx = X'[t] - X[t]
+                if (GAINS) sdx[a * NS + i] = x[i] - xold[i];  // dx = X'[t] - X[t]
                 sxs[a * NS + i] = x[i];
             }
-            if (GAINS) {  // old X[t+1], fetched before anyone may overwrite it
-#pragma unroll
-                for (int i = 0; i < NS; ++i) xold_next[i] = Xold[(int64_t)(t + 1) * n + a * NS + i];
-            }
         }
-        __syncthreads();
-        if (COST && active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), reference order
+        if (t + 1 < T) fetch(t + 1);
+        lds_handoff(single_wave);
+        if (active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), summed in the reference's order
             const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
             const double* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
             double prox = 0.0, ref = 0.0;
@@ -126,30 +157,48 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
             J += D.w_prox * prox + D.w_ref * ref;
         }
         if (active) {
-            if (GAINS) {
+            if (GAINS) {  // du = K[t] dx + alpha d[t] (control.py:106), this agent's NC rows, j ascending
+                double sum[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+                const double* rows = sKt + (a * NC) * n;
+                if ((n & 1) == 0) {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+#pragma unroll 2
+                    for (int j = 0; j < n; j += 2) {
+                        const v2d dx2 = *reinterpret_cast<const v2d*>(sdx + j);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
+                            sum[c] += kr.x * dx2.x;
+                            sum[c] += kr.y * dx2.y;
+                        }
+                    }
+                } else {
+                    for (int j = 0; j < n; ++j) {
+                        const double dxj = sdx[j];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double* row = sKt + (a * NC + c) * n;
-                    double s = 0.0;
-                    for (int j = 0; j < n; ++j) s += row[j] * sdx[j];
-                    const double du = s + alpha * sdt[a * NC + c];
-                    u[c] = u[c] + du;
+                    const double du = sum[c] + alpha * sdt[a * NC + c];
+                    ut[c] = ut[c] + du;
                 }
             }
-            if (COST) {
-                lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, u, xf, Qa, Ra, false);
-                for (int o = a + 1; o < k; ++o) {
-                    const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
-                    lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
-                        pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
-                }
+            lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, ut, xf, Qa, Ra, false);
+            for (int o = a + 1; o < k; ++o) {
+                const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
+                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
+                    pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
             }
             if (Uw) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) Uw[(int64_t)t * m + a * NC + c] = u[c];
+                for (int c = 0; c < NC; ++c) Uw[(int64_t)t * m + a * NC + c] = ut[c];
             }
             double xn[NS];
-            integrate_rt<NS>(model, x, u, D.dt, xn);
+            integrate_rt<NS>(model, x, ut, D.dt, xn);
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = xn[i];
             if (Xw) {
@@ -158,7 +207,7 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
             }
         }
     }
-    if (COST) {
+    {
         // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:91,112)
         const int par = T & 1;
         double* sxs = lds + O.xs + (par * ngrp + gg) * n;
@@ -166,7 +215,7 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
 #pragma unroll
             for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
         }
-        __syncthreads();
+        lds_handoff(single_wave);
         if (active) {
             if (a == 0 && T > 0) {
                 const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
@@ -186,7 +235,7 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
                     pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
             }
         }
-        __syncthreads();
+        lds_handoff(single_wave);
         if (active && a == 0) {
             const double* cr = lds + O.cref + (par * ngrp + g) * k;
             const double* cp = lds + O.cpair + (par * ngrp + g) * np1;
@@ -196,15 +245,20 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
             J += D.w_prox * prox + D.w_ref * ref;
         }
     }
-    __syncthreads();
+    lds_handoff(single_wave);
     return J;
 }
 
+// kModeRollout    : X, J <- rollout(x0, U)                                  (control.py:80-93)
+// kModeCandidates : Xc, Uc, Jc <- forward_pass(X, U, K, d, alpha_g) for every g (control.py:95-114)
+// kModeLineSearch : the same, followed by the accept / regularisation logic of one solver iteration
+//                   (control.py:179-211) and the copy of the accepted candidate into X, U.
 template <int NS, int NC>
-__global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X, double* U,
-                          const double* __restrict__ K, const double* __restrict__ d,
-                          const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc, double* Jc,
-                          SolveState S, const int32_t* __restrict__ items, const int32_t* __restrict__ n_items) {
+__global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X,
+                                                  double* U, const double* __restrict__ K, const double* __restrict__ d,
+                                                  const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc,
+                                                  double* Jc, SolveState S, const int32_t* __restrict__ items,
+                                                  const int32_t* __restrict__ n_items) {
     const int slot = blockIdx.x;
     if (n_items && slot >= *n_items) return;
     const int b = items ? items[slot] : slot;
@@ -220,36 +274,34 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
 
     if (mode == kModeRollout) {
         const bool active = (g == 0);
-        const double J = horizon_pass<NS, NC, false, true>(D, P, homog, b, active, 0, a, 1, x0 + (int64_t)b * n, nullptr,
-                                                           Ub, nullptr, nullptr, 0.0, Xb, nullptr, lds);
+        const double J = horizon_pass<NS, NC, false>(D, P, homog, active, 0, a, 1, x0 + (int64_t)b * n, nullptr, Ub,
+                                                     nullptr, nullptr, 0.0, Xb, nullptr, lds);
         if (active && a == 0) Jc[b] = J;
         return;
     }
 
+    if (mode == kModeLineSearch && S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
+        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] = S.iter + 1; }
+        return;
+    }
     const double* Kb = K + (int64_t)b * T * m * n;
     const double* db = d + (int64_t)b * T * m;
     const bool active = (g < ngrp);
     const double alpha = active ? alphas[g] : 0.0;
-
+    // candidate trajectories: slot of this item in the scratch (solve) or the caller's buffers (API)
+    const int64_t cslot = (mode == kModeLineSearch) ? slot : b;
+    double* Xw = active ? Xc + (cslot * ngrp + g) * (int64_t)(T + 1) * n : nullptr;
+    double* Uw = active ? Uc + (cslot * ngrp + g) * (int64_t)T * m : nullptr;
+    const double J = horizon_pass<NS, NC, true>(D, P, homog, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha, Xw, Uw, lds);
     if (mode == kModeCandidates) {
-        double* Xw = active ? Xc + ((int64_t)b * ngrp + g) * (T + 1) * n : nullptr;
-        double* Uw = active ? Uc + ((int64_t)b * ngrp + g) * T * m : nullptr;
-        const double J = horizon_pass<NS, NC, true, true>(D, P, homog, b, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
-                                                          Xw, Uw, lds);
         if (active && a == 0) Jc[(int64_t)b * ngrp + g] = J;
         return;
     }
 
-    // ---- kModeLineSearch: one iLQR iteration's line search + bookkeeping (control.py:179-211)
+    // ---- one iLQR iteration's line-search decision + bookkeeping (control.py:179-211)
     int* ctl = reinterpret_cast<int*>(lds + O.ctl);
-    if (S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
-        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] = S.iter + 1; }
-        return;
-    }
-    const double J = horizon_pass<NS, NC, true, true>(D, P, homog, b, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
-                                                      nullptr, nullptr, lds);
     if (active && a == 0) lds[O.J + g] = J;
-    __syncthreads();
+    __syncthreads();  // also makes every candidate's trajectory stores visible to the whole workgroup
     if (tid == 0) {
         const double J_star = S.J_star[b];
         int acc = -1;
@@ -290,9 +342,11 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
     __syncthreads();
     const int acc = ctl[0];
     if (acc < 0) return;
-    // accepted: X, U <- the accepted candidate's trajectory, rolled out again in place
-    const bool act0 = (g == 0);
-    horizon_pass<NS, NC, true, false>(D, P, homog, b, act0, 0, a, ngrp, Xb, Xb, Ub, Kb, db, alphas[acc], Xb, Ub, lds);
+    // accepted: X, U <- the accepted candidate's trajectory (a coalesced copy out of the scratch)
+    const double* Xa = Xc + (cslot * ngrp + acc) * (int64_t)(T + 1) * n;
+    const double* Ua = Uc + (cslot * ngrp + acc) * (int64_t)T * m;
+    for (int e = tid; e < (T + 1) * n; e += blockDim.x) Xb[e] = Xa[e];
+    for (int e = tid; e < T * m; e += blockDim.x) Ub[e] = Ua[e];
 }
 
 // ---- small batched entry points ------------------------------------------------------------------

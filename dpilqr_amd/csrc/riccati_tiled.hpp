@@ -55,12 +55,13 @@ struct TiledCfg {
     static constexpr int oAB = 0;
     static constexpr int oP = oAB + N * LAB;
     static constexpr int oPt = oP + N * LP;
-    static constexpr int oT = oPt + N * LP;
-    static constexpr int oQ = oT + N * LAB;
-    static constexpr int oG = oQ + N * LQ;
-    static constexpr int oK = oG + M * LG;
+    static constexpr int oT = oPt + N * LP;            // T^T: LP rows (rows >= N are write-only dummies)
+    static constexpr int oQ = oT + LP * LAB;
+    static constexpr int oG = oQ + N * LQ;             // NMP-N rows (rows >= M are write-only dummies)
+    static constexpr int oK = oG + (NMP - N) * LG;
     static constexpr int oT3 = oK + M * LK;
-    static constexpr int total = oT3 + M * N;
+    static constexpr int oTrash = oT3 + M * N;         // where masked-out stores go (never read)
+    static constexpr int total = oTrash + 2;
     static constexpr bool supported = (N % 2 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 64 * 1024);
     // per-lane prefetch of [A|B]: 16-byte pairs, round-robin over the wave
     static constexpr int AB_PAIRS = N * NM / 2;
@@ -68,26 +69,35 @@ struct TiledCfg {
 };
 
 // acc[r][c] += sum_l X[l*LDX + r] * Y[l*LDY + c]   (X, Y already offset to the block's first row/col)
+// Software-pipelined by hand: the operands of reduction step l+1 are requested before the FMAs of
+// step l issue, and a scheduling barrier per step keeps the compiler from hoisting every ds_read of
+// the (fully unrolled) loop to the top, which would blow the 256-VGPR budget into AGPR copies.
 template <int RBK, int CBK, int L, int LDX, int LDY>
 __device__ __forceinline__ void block_product(const double* __restrict__ X, const double* __restrict__ Y,
                                               double (&acc)[RBK][CBK]) {
+    v2d xa[2][RBK / 2], yb[2][CBK / 2];
+#pragma unroll
+    for (int r = 0; r < RBK / 2; ++r) xa[0][r] = *reinterpret_cast<const v2d*>(X + 2 * r);
+#pragma unroll
+    for (int c = 0; c < CBK / 2; ++c) yb[0][c] = *reinterpret_cast<const v2d*>(Y + 2 * c);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        double a[RBK], b[CBK];
+        const int cur = l & 1, nxt = cur ^ 1;
+        if (l + 1 < L) {
 #pragma unroll
-        for (int r = 0; r < RBK; r += 2) {
-            const v2d t = *reinterpret_cast<const v2d*>(X + l * LDX + r);
-            a[r] = t.x; a[r + 1] = t.y;
-        }
+            for (int r = 0; r < RBK / 2; ++r) xa[nxt][r] = *reinterpret_cast<const v2d*>(X + (l + 1) * LDX + 2 * r);
 #pragma unroll
-        for (int c = 0; c < CBK; c += 2) {
-            const v2d t = *reinterpret_cast<const v2d*>(Y + l * LDY + c);
-            b[c] = t.x; b[c + 1] = t.y;
+            for (int c = 0; c < CBK / 2; ++c) yb[nxt][c] = *reinterpret_cast<const v2d*>(Y + (l + 1) * LDY + 2 * c);
         }
 #pragma unroll
         for (int r = 0; r < RBK; ++r)
 #pragma unroll
-            for (int c = 0; c < CBK; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+            for (int c = 0; c < CBK; ++c) {
+                const double av = (r & 1) ? xa[cur][r / 2].y : xa[cur][r / 2].x;
+                const double bv = (c & 1) ? yb[cur][c / 2].y : yb[cur][c / 2].x;
+                acc[r][c] = fma(av, bv, acc[r][c]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -116,6 +126,7 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     double* sG = lds + C::oG;
     double* sK = lds + C::oK;
     double* sT3 = lds + C::oT3;
+    double* sTrash = lds + C::oTrash;
 
     const double mu = mu_arr[b];
     const double* base = tiles + (int64_t)b * (T + 1) * L.stride;
@@ -139,108 +150,133 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
         }
     }
 
-    // ---- per-lane block coordinates (constant over the horizon)
+    // ---- per-lane block coordinates and addresses, constant over the horizon.  The time loop below is
+    // branch-free: lanes beyond a phase's block count recompute the last block (identical values to
+    // identical addresses), and elements that must not be stored go to sTrash.
     // S1: rows of [A|B]^T (NMP/RB) x cols of [P|p] (LP/CB)
     constexpr int S1_CB = LP / CB, S1_BLOCKS = (NMP / RB) * S1_CB;
+    static_assert(S1_BLOCKS <= 64, "S1 needs one block per lane");
     const int s1 = lane < S1_BLOCKS ? lane : S1_BLOCKS - 1;
     const int s1_i0 = (s1 / S1_CB) * RB, s1_j0 = (s1 % S1_CB) * CB;
-    static_assert(S1_BLOCKS <= 64, "S1 needs one block per lane");
-    // S2: (NMP/RB) x (NMP/CB)
+    const double* s1_x = sAB + s1_i0;
+    const double* s1_y = ((s1_i0 < N) ? sP : sPt) + s1_j0;          // B rows see P + mu I (quirk Q6)
+    double* s1_t = sT + s1_j0 * LAB + s1_i0;                         // T^T[j0 + c][i0 + r]
+    double* s1_q[RB];                                                // Q_x / Q_u slots of the p column
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = s1_i0 + r;
+        s1_q[r] = (s1_j0 != N || i >= NM) ? sTrash : (i < N ? sQ + i * LQ + N : sG + (i - N) * LG + M + N);
+    }
+    int s1_lsrc[RB / 2];                                             // [l_x ; l_u] pairs (safe offset for padded rows)
+#pragma unroll
+    for (int r = 0; r < RB / 2; ++r) s1_lsrc[r] = L.oLx + ((s1_i0 + 2 * r < NM) ? s1_i0 + 2 * r : 0);
+    // S2: (NMP/RB) x (NMP/CB) blocks of [T1;T2][A|B]; region 0 Q_xx, 1 Q_ux, 2 Q_uu, 3 unused (T1 B)
     constexpr int S2_CB = NMP / CB, S2_BLOCKS = (NMP / RB) * S2_CB;
     static_assert(S2_BLOCKS <= 64, "S2 needs one block per lane");
     const int s2 = lane < S2_BLOCKS ? lane : S2_BLOCKS - 1;
     const int s2_i0 = (s2 / S2_CB) * RB, s2_j0 = (s2 % S2_CB) * CB;
-    // region of the S2 block: 0 Q_xx, 1 Q_ux, 2 Q_uu, 3 unused (T1 B)
     const int s2_reg = (s2_i0 < N) ? ((s2_j0 < N) ? 0 : 3) : ((s2_j0 < N) ? 1 : 2);
-    // record offset of the block's first l-value and its row stride
-    int s2_loff, s2_lld;
-    if (s2_reg == 0) { s2_loff = L.oLxx + s2_i0 * N + s2_j0; s2_lld = N; }
-    else if (s2_reg == 1) { s2_loff = L.oLux + (s2_i0 - N) * N + s2_j0; s2_lld = N; }
-    else { s2_loff = L.oLuu + (s2_i0 - N) * M + (s2_j0 - N); s2_lld = M; }
-    // S4: T3^T (M x N) in 2x2 blocks ; S5/S6: N x NP in RB x 2 blocks
+    const double* s2_x = sT + s2_i0;
+    const double* s2_y = sAB + s2_j0;
+    double* s2_dst[RB][CB / 2];
+    int s2_src[RB][CB / 2];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB / 2; ++c) {
+            const int i = s2_i0 + r, j = s2_j0 + 2 * c;
+            const bool ok = (s2_reg != 3) && (i < NM) && (j < NM);
+            double* d;
+            int o;
+            if (s2_reg == 0) { d = sQ + i * LQ + j; o = L.oLxx + i * N + j; }
+            else if (s2_reg == 1) { d = sG + (i - N) * LG + M + j; o = L.oLux + (i - N) * N + j; }
+            else { d = sG + (i - N) * LG + (j - N); o = L.oLuu + (i - N) * M + (j - N); }
+            s2_dst[r][c] = ok ? d : sTrash;
+            s2_src[r][c] = ok ? o : 0;
+        }
+    // S4: T3^T (M x N) in 2x2 blocks
     constexpr int S4_CB = N / 2, S4_BLOCKS = (M / 2) * S4_CB;
     static_assert(S4_BLOCKS <= 64, "S4 needs one block per lane");
     const int s4 = lane < S4_BLOCKS ? lane : S4_BLOCKS - 1;
     const int s4_c0 = (s4 / S4_CB) * 2, s4_i0 = (s4 % S4_CB) * 2;
+    // S5/S6: N x NP in RB x 2 blocks
     constexpr int S5_CB = NP / 2, S5_BLOCKS = (N / RB) * S5_CB;
     static_assert(S5_BLOCKS <= 64, "S5 needs one block per lane");
     const int s5 = lane < S5_BLOCKS ? lane : S5_BLOCKS - 1;
     const int s5_i0 = (s5 / S5_CB) * RB, s5_j0 = (s5 % S5_CB) * 2;
+    // S6 per element: P'[i][j] = wa*V[i][j] + wb*V[j][i]  with (wa,wb) = (1/2,1/2) for j < n, (1,0) for the p column
+    double* s6_dst[2];          // &sP[i0][j] (or trash for the pad column); sPt sits at a constant offset
+    const double* s6_vt[2];     // &V[j][i0]  (transposed operand; any finite address when unused)
+    double s6_wa[2], s6_wb[2], s6_mu[RB][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int j = s5_j0 + c;
+        s6_dst[c] = (j <= N) ? sP + s5_i0 * LP + j : sTrash;
+        s6_vt[c] = (j < N) ? sQ + j * LQ + s5_i0 : sQ;
+        s6_wa[c] = (j < N) ? 0.5 : 1.0;
+        s6_wb[c] = (j < N) ? 0.5 : 0.0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) s6_mu[r][c] = (s5_i0 + r == j) ? mu : 0.0;
+    }
+    constexpr int PT_OFF = C::oPt - C::oP;
     // [A|B] prefetch: pair q of this lane -> LDS destination
-    int ab_dst[C::AB_ROUNDS];
+    double* ab_dst[C::AB_ROUNDS];
+    int ab_src[C::AB_ROUNDS];
 #pragma unroll
     for (int q = 0; q < C::AB_ROUNDS; ++q) {
         const int e = 2 * (lane + 64 * q);
         const int row = e / NM, col = e - row * NM;
-        ab_dst[q] = (e < N * NM) ? row * LAB + col : -1;
+        ab_dst[q] = (e < N * NM) ? sAB + row * LAB + col : sTrash;
+        ab_src[q] = (e < N * NM) ? L.oA + e : 0;
     }
 
-    // ---- prefetch registers
+    // ---- prefetch registers (one record ahead)
     v2d nAB[C::AB_ROUNDS];
     v2d nL[RB][CB / 2];      // l-values of the S2 block
     v2d nLxu[RB / 2];        // [l_x ; l_u][s1_i0 .. s1_i0+RB)
     auto prefetch = [&](int t) {
         const double* rec = base + (int64_t)t * L.stride;
 #pragma unroll
-        for (int q = 0; q < C::AB_ROUNDS; ++q)
-            if (ab_dst[q] >= 0) nAB[q] = *reinterpret_cast<const v2d*>(rec + L.oA + 2 * (lane + 64 * q));
-        if (s2_reg != 3) {
+        for (int q = 0; q < C::AB_ROUNDS; ++q) nAB[q] = *reinterpret_cast<const v2d*>(rec + ab_src[q]);
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int c = 0; c < CB / 2; ++c) {
-                    const bool ok = (s2_i0 + r < NM) && (s2_j0 + 2 * c < NM);
-                    nL[r][c] = ok ? *reinterpret_cast<const v2d*>(rec + s2_loff + r * s2_lld + 2 * c) : v2d{0.0, 0.0};
-                }
-        }
+            for (int c = 0; c < CB / 2; ++c) nL[r][c] = *reinterpret_cast<const v2d*>(rec + s2_src[r][c]);
 #pragma unroll
-        for (int r = 0; r < RB / 2; ++r)
-            nLxu[r] = (s1_i0 + 2 * r < NM) ? *reinterpret_cast<const v2d*>(rec + L.oLx + s1_i0 + 2 * r) : v2d{0.0, 0.0};
+        for (int r = 0; r < RB / 2; ++r) nLxu[r] = *reinterpret_cast<const v2d*>(rec + s1_lsrc[r]);
     };
     prefetch(T - 1);
 
     for (int t = T - 1; t >= 0; --t) {
-        // ---- S0: park [A|B] of record t in LDS, take over the l-values, fetch record t-1
+        // ---- S0: park [A|B] of record t in LDS, take over its l-values
         v2d cL[RB][CB / 2], cLxu[RB / 2];
 #pragma unroll
-        for (int q = 0; q < C::AB_ROUNDS; ++q)
-            if (ab_dst[q] >= 0) *reinterpret_cast<v2d*>(sAB + ab_dst[q]) = nAB[q];
+        for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB / 2; ++c) cL[r][c] = nL[r][c];
 #pragma unroll
         for (int r = 0; r < RB / 2; ++r) cLxu[r] = nLxu[r];
-        if (t > 0) prefetch(t - 1);
         DPILQR_LDS_FENCE();
 
-        // ---- S1: [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (B rows against P + mu I)
+        // ---- S1: [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]
         {
             double acc[RB][CB];
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < CB; ++c) acc[r][c] = 0.0;
-            const double* Pm = (s1_i0 < N) ? sP : sPt;
-            block_product<RB, CB, N, LAB, LP>(sAB + s1_i0, Pm + s1_j0, acc);
-            if (lane < S1_BLOCKS) {
+            block_product<RB, CB, N, LAB, LP>(s1_x, s1_y, acc);
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const int j = s1_j0 + c;
-                    if (j < N) {  // T^T[j][i'] : the operand orientation S2 wants
+            for (int c = 0; c < CB; ++c)   // T^T[j][i']: the operand orientation S2 wants (rows >= n are dummies)
 #pragma unroll
-                        for (int r = 0; r < RB; r += 2)
-                            *reinterpret_cast<v2d*>(sT + j * LAB + s1_i0 + r) = v2d{acc[r][c], acc[r + 1][c]};
-                    } else if (j == N) {  // Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+                for (int r = 0; r < RB; r += 2)
+                    *reinterpret_cast<v2d*>(s1_t + c * LAB + r) = v2d{acc[r][c], acc[r + 1][c]};
 #pragma unroll
-                        for (int r = 0; r < RB; ++r) {
-                            const int i = s1_i0 + r;
-                            const double lv = (r & 1) ? cLxu[r / 2].y : cLxu[r / 2].x;
-                            if (i < N) sQ[i * LQ + N] = lv + acc[r][c];
-                            else if (i < NM) sG[(i - N) * LG + M + N] = lv + acc[r][c];
-                        }
-                    }
-                }
+            for (int r = 0; r < RB; ++r) {  // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+                const double lv = (r & 1) ? cLxu[r / 2].y : cLxu[r / 2].x;
+                *s1_q[r] = lv + acc[r][0];
             }
         }
         DPILQR_LDS_FENCE();
@@ -252,23 +288,15 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < CB; ++c) acc[r][c] = 0.0;
-            block_product<RB, CB, N, LAB, LAB>(sT + s2_i0, sAB + s2_j0, acc);
-            if (lane < S2_BLOCKS && s2_reg != 3) {
-                double* dst;
-                int ld;
-                if (s2_reg == 0) { dst = sQ + s2_i0 * LQ + s2_j0; ld = LQ; }
-                else if (s2_reg == 1) { dst = sG + (s2_i0 - N) * LG + M + s2_j0; ld = LG; }
-                else { dst = sG + (s2_i0 - N) * LG + (s2_j0 - N); ld = LG; }
+            block_product<RB, CB, N, LAB, LAB>(s2_x, s2_y, acc);
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int c = 0; c < CB; c += 2)
-                        if (s2_i0 + r < NM && s2_j0 + c < NM)
-                            *reinterpret_cast<v2d*>(dst + r * ld + c) =
-                                v2d{cL[r][c / 2].x + acc[r][c], cL[r][c / 2].y + acc[r][c + 1]};
-            }
+                for (int c = 0; c < CB / 2; ++c)
+                    *reinterpret_cast<v2d*>(s2_dst[r][c]) = v2d{cL[r][c].x + acc[r][2 * c], cL[r][c].y + acc[r][2 * c + 1]};
         }
         DPILQR_LDS_FENCE();
+        if (t > 0) prefetch(t - 1);   // record t-1 lands while S3..S6 run; consumed at the top of the next step
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers
         {
@@ -281,19 +309,24 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                 int piv = kk;
                 double best = fabs(v[kk]);
 #pragma unroll
-                for (int r = kk + 1; r < M; ++r) {
+                for (int r = kk + 1; r < M; ++r) {   // first row of maximal |.| (LAPACK idamax)
                     const double av = fabs(v[r]);
-                    if (av > best) { best = av; piv = r; }
+                    piv = (av > best) ? r : piv;
+                    best = fmax(best, av);
                 }
                 piv = __builtin_amdgcn_readlane(piv, kk);  // column kk decides the pivot row
-                if (piv != kk) {                           // wave-uniform
+                if (piv != kk) {                           // wave-uniform, and rare: keep it a real branch
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int r = kk + 1; r < M; ++r)
                         if (r == piv) { const double tv = v[r]; v[r] = v[kk]; v[kk] = tv; }
                 }
                 const double pv = readlane_f64(v[kk], kk);
                 if (pv == 0.0) sing = 1;
-                const double inv = 1.0 / pv;
+                // 1/pivot: hardware reciprocal seed + two Newton steps (<= 1 ulp; LAPACK scales by a reciprocal too)
+                double inv = __builtin_amdgcn_rcp(pv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
                 invd[kk] = inv;
 #pragma unroll
                 for (int r = kk + 1; r < M; ++r) {
@@ -323,14 +356,12 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
         }
         DPILQR_LDS_FENCE();
 
-        // ---- S4: T3^T = Q_uu^T-contracted K : T3T[c][i] = sum_a Q_uu[a][c] K[a][i]
+        // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
         {
             double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
             block_product<2, 2, M, LG, LK>(sG + s4_c0, sK + s4_i0, acc);
-            if (lane < S4_BLOCKS) {
-                *reinterpret_cast<v2d*>(sT3 + s4_c0 * N + s4_i0) = v2d{acc[0][0], acc[0][1]};
-                *reinterpret_cast<v2d*>(sT3 + (s4_c0 + 1) * N + s4_i0) = v2d{acc[1][0], acc[1][1]};
-            }
+            *reinterpret_cast<v2d*>(sT3 + s4_c0 * N + s4_i0) = v2d{acc[0][0], acc[0][1]};
+            *reinterpret_cast<v2d*>(sT3 + (s4_c0 + 1) * N + s4_i0) = v2d{acc[1][0], acc[1][1]};
         }
         DPILQR_LDS_FENCE();
 
@@ -350,35 +381,27 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                 vb[r][1] = ((q.y + a1[r][1]) + a2[r][1]) + a3[r][1];
             }
             DPILQR_LDS_FENCE();
-            if (lane < S5_BLOCKS) {
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
-                    *reinterpret_cast<v2d*>(sQ + (s5_i0 + r) * LQ + s5_j0) = v2d{vb[r][0], vb[r][1]};
-            }
+            for (int r = 0; r < RB; ++r)
+                *reinterpret_cast<v2d*>(sQ + (s5_i0 + r) * LQ + s5_j0) = v2d{vb[r][0], vb[r][1]};
         }
         DPILQR_LDS_FENCE();
 
         // ---- S6: P <- (V + V^T)/2 (and its regularised copy) ; p <- V[:, n]
-        if (lane < S5_BLOCKS) {
+        {
+            double pn[RB][2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int j = s5_j0 + c;
-                if (j < N) {
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) {
-                        const int i = s5_i0 + r;
-                        const double pn = 0.5 * (vb[r][c] + sQ[j * LQ + i]);
-                        sP[i * LP + j] = pn;
-                        sPt[i * LP + j] = (i == j) ? pn + mu : pn;
-                    }
-                } else if (j == N) {
+                for (int r = 0; r < RB; ++r) pn[r][c] = fma(s6_wb[c], s6_vt[c][r], s6_wa[c] * vb[r][c]);
+            DPILQR_LDS_FENCE();
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) {
-                        sP[(s5_i0 + r) * LP + N] = vb[r][c];
-                        sPt[(s5_i0 + r) * LP + N] = vb[r][c];
-                    }
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    s6_dst[c][r * LP] = pn[r][c];
+                    s6_dst[c][r * LP + PT_OFF] = pn[r][c] + s6_mu[r][c];
                 }
-            }
         }
         DPILQR_LDS_FENCE();
     }
