@@ -5,9 +5,13 @@ Workload (BASELINE.json configs[1], "cfg2"): a batch of 1024 independent 5-agent
 sub-problems per GPU, horizon T=50, fp64, the Monte-Carlo scenario distribution of the reference's
 scripts/analysis.py:45-69,140-143 (seed s: np.random.seed(s); random_setup(5,4,rel_dist=5,var=2.5,
 energy=10); Q=diag(1,1,0,0), R=I, Qf=1000 I, radius 0.5, dt 0.1, U0=0, tol 1e-3, n_lqr_iter 50).
-One "step" = one complete ilqrSolver.solve of every sub-problem of the batch (device resident:
-x0/xf/U0 are in HBM before the clock starts), followed -- for N>1 -- by the path's one collective,
-an RCCL all-gather of the converged (X, U, J, n_bwd) of all ranks.
+One "step" = one complete ilqrSolver.solve of every sub-problem of one such batch (device resident:
+x0/xf/U0 of all K steps are in HBM before the clock starts).  The K batches (K x 1024 different seeds per
+GPU) are handed to the solver together, the way a Monte-Carlo driver would, and it keeps a WINDOW of 1024
+sub-problems in flight: sub-problems need 1..25 iLQR iterations, so finished ones are retired on the device
+and replaced by not-yet-started ones, and every launch of the hot kernels works on ~1024 sub-problems.  All
+K x 1024 solves complete inside the timed region.  For N>1 the region also contains the path's one
+collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) of all ranks.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -94,13 +98,21 @@ def main():
     _lib.require_gpu()
 
     B = args.batch
-    x0_h, xf_h = scenarios(rank * B, B)                      # weak scaling: every rank its own 1024 seeds
-    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
-    pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf_h, Q, R, Qf, 0.5, 0.1, T)
-    x0 = to_dev(x0_h); U0 = torch.zeros((B, T, N_U), dtype=torch.float64, device=x0.device)
 
-    def step():
-        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3)
+    def make_job(n_steps, seed0):
+        """n_steps batches of B scenarios each, resident in HBM; seeds are disjoint across ranks and steps."""
+        x0_h, xf_h = scenarios(seed0, n_steps * B)
+        pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf_h, Q, R, Qf, 0.5, 0.1, T)
+        return pb, to_dev(x0_h), torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda"), x0_h, xf_h
+
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    seeds_per_rank = (args.steps + args.warmup) * B
+    job = make_job(args.steps, rank * seeds_per_rank)                     # weak scaling: every rank its own seeds
+    warm = make_job(args.warmup, rank * seeds_per_rank + args.steps * B) if args.warmup > 0 else None
+
+    def run(j):
+        pb, x0, U0 = j[0], j[1], j[2]
+        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3, window=B)
         if world > 1:
             r = gather_results(r)                            # the one collective of the path
         return r
@@ -111,16 +123,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        r = step()
+    if warm is not None:
+        run(warm)
     _lib.profile_enable(True); _lib.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
+    r = run(job)
     fence()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_read(reset=True); _lib.profile_enable(False)
+    x0_h, xf_h = job[3], job[4]
+    x0 = job[1]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=x0.device)
     if world > 1:
@@ -142,13 +155,14 @@ def main():
             "metric": "ilqr_subproblems_per_sec", "value": value, "unit": "subproblems/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg2: {B} independent 5-agent DoubleIntDynamics4D iLQR sub-problems per GPU, T=50, "
-                                   "scripts/analysis.py scenario distribution, tol=1e-3, n_lqr_iter=50",
-                       "batch_per_gpu": B, "n_x": N_X, "n_u": N_U, "horizon": T,
+            "config": {"workload": f"cfg2: batches of {B} independent 5-agent DoubleIntDynamics4D iLQR sub-problems per GPU "
+                                   "per step, T=50, scripts/analysis.py scenario distribution, tol=1e-3, n_lqr_iter=50; "
+                                   f"{args.steps} steps = {args.steps * B} distinct seeds per GPU, window of {B} in flight",
+                       "batch_per_gpu": B, "window": B, "n_x": N_X, "n_u": N_U, "horizon": T,
                        "mean_backward_passes": float(nb.mean()), "mean_forward_passes": float(nf.mean()),
                        "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_riccati_generic", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_riccati_tiled<20,10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
                          "launches": ric["launches"], "subproblem_passes": ric["items"],

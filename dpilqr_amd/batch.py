@@ -142,19 +142,23 @@ class ProblemBatch:
         return out
 
     # ------------------------------------------------------------------ whole solve
-    def workspace(self):
-        if self._ws is None:
-            nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d)
+    def workspace(self, window, gains_in_ws):
+        key = (int(window), bool(gains_in_ws))
+        if self._ws is None or self._ws[0] != key:
+            nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d, key[0], int(key[1]))
             _lib.check(nbytes)
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device())
-        return self._ws
+            self._ws = (key, torch.empty(nbytes, dtype=torch.uint8, device=device()))
+        return self._ws[1]
 
-    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False):
-        """ilqrSolver.solve (control.py:150-225) for all B items at once.
+    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None):
+        """ilqrSolver.solve (control.py:150-225) for all B items.
 
+        window: most items in flight at once (default min(B, 1024)); finished items are retired on the
+        device and replaced by not-yet-started ones, so launches stay full and memory is bounded.
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
+        window = min(B, 1024) if window is None else int(window)
         x0 = self._in(x0, (B, n))
         U = self._in(U0, (B, T, m)).clone()
         X = empty((B, T + 1, n)); J = empty((B,))
@@ -162,8 +166,8 @@ class ProblemBatch:
         tr = torch.full((B, max(n_lqr_iter, 1), 5), float("nan"), dtype=torch.float64, device=device()) if trace else None
         K = empty((B, T, m, n)) if gains else None
         d = empty((B, T, m)) if gains else None
-        ws = self.workspace()
-        _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), ptr(ws),
+        ws = self.workspace(window, not gains)
+        _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws),
                                                 ws.numel(), ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd),
                                                 ptr(tr), ptr(K), ptr(d), stream_handle()))
         out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -100,7 +101,7 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
 
 int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
-                       hipStream_t st) {
+                       int gains_by_item, hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
     static const bool force_generic = getenv("DPILQR_FORCE_GENERIC_RICCATI") != nullptr;
     if (!force_generic) {
@@ -108,7 +109,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     if (n == NN && m == MM) {                                                                                      \
         static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
         hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3(grid_items), dim3(64), 0, st, B, T, tiles, mu, K, d,     \
-                           singular, items, n_items);                                                              \
+                           singular, items, n_items, gains_by_item);                                               \
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
@@ -119,7 +120,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     int32_t rc = allow_lds(k_riccati_generic, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_riccati_generic, dim3(grid_items), dim3(riccati_threads(n)), lds, st, B, T, n, m, tiles, mu, K,
-                       d, singular, items, n_items);
+                       d, singular, items, n_items, gains_by_item);
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;
 }
@@ -163,11 +164,20 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
     if (i < B) {  // _reset_regularization, control.py:227-230
         mu[i] = 1.0; delta[i] = 2.0; status[i] = DPILQR_STATUS_ACTIVE; n_bwd[i] = 0; n_fwd[i] = 0; singular[i] = 0;
     }
-    if (i < n_counts) counts[i] = (i == 0) ? B : 0;
+    if (i < n_counts) counts[i] = 0;
     if (i == 0) {
         alphas_dev[0] = a0; alphas_dev[1] = a1; alphas_dev[2] = a2; alphas_dev[3] = a3; alphas_dev[4] = a4;
         alphas_dev[5] = a5; alphas_dev[6] = a6; alphas_dev[7] = a7; alphas_dev[8] = a8; alphas_dev[9] = a9;
     }
+}
+
+// Append the not-yet-started items [first, first+n_new) to the active list behind the survivors that
+// the previous iteration's line search pushed, and clear the counter the NEXT iteration will push into.
+__global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int first, int n_new) {
+    const int base = *count;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
+    if (threadIdx.x == 0) { *count = base + n_new; *next_count = 0; }
 }
 
 __global__ void k_copy_f64(int n, const double* src, double* dst) {
@@ -180,34 +190,42 @@ __global__ void k_finish_status(int B, int32_t* status) {  // n_lqr_iter == 0: n
     if (i < B && status[i] == DPILQR_STATUS_ACTIVE) status[i] = DPILQR_STATUS_MAX_ITER;
 }
 
+constexpr int kCountRing = 4;
+
 struct SolveWorkspace {
+    // W = window = most sub-problems in flight at once: the big per-iteration buffers (tile records, gains,
+    // line-search candidates) are indexed by position in the active list and sized by W, not by B.
     size_t tiles, K, d, Xc, Uc, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
-    SolveWorkspace(const dpilqr_batch_desc& D, int n_lqr_iter_max) {
-        const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T;
+    SolveWorkspace(const dpilqr_batch_desc& D, int W, bool gains_in_ws) {
+        const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T, Wn = W;
         const TileLayout L((int)n, (int)m);
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         size_t o = 0;
-        tiles = o;    o = al(o + sizeof(double) * B * (T + 1) * L.stride);
-        K = o;        o = al(o + sizeof(double) * B * T * m * n);
-        d = o;        o = al(o + sizeof(double) * B * T * m);
+        tiles = o;    o = al(o + sizeof(double) * Wn * (T + 1) * L.stride);
+        K = o;        o = al(o + (gains_in_ws ? sizeof(double) * Wn * T * m * n : 0));
+        d = o;        o = al(o + (gains_in_ws ? sizeof(double) * Wn * T * m : 0));
         // line-search candidates: every alpha's trajectory, so that accepting one is a copy, not a re-roll
-        Xc = o;       o = al(o + sizeof(double) * B * DPILQR_N_ALPHA * (T + 1) * n);
-        Uc = o;       o = al(o + sizeof(double) * B * DPILQR_N_ALPHA * T * m);
+        Xc = o;       o = al(o + sizeof(double) * Wn * DPILQR_N_ALPHA * (T + 1) * n);
+        Uc = o;       o = al(o + sizeof(double) * Wn * DPILQR_N_ALPHA * T * m);
         mu = o;       o = al(o + sizeof(double) * B);
         delta = o;    o = al(o + sizeof(double) * B);
         J_star = o;   o = al(o + sizeof(double) * B);
         J_last = o;   o = al(o + sizeof(double) * B);
         alphas = o;   o = al(o + sizeof(double) * DPILQR_N_ALPHA);
         singular = o; o = al(o + sizeof(int32_t) * B);
-        lists = o;    o = al(o + sizeof(int32_t) * 2 * B);
-        counts = o;   o = al(o + sizeof(int32_t) * (n_lqr_iter_max + 2));
+        lists = o;    o = al(o + sizeof(int32_t) * 2 * Wn);
+        counts = o;   o = al(o + sizeof(int32_t) * kCountRing);
         total = o;
     }
 };
 constexpr int kMaxLqrIter = 4096;
+constexpr int kMaxGlobalIter = 1 << 20;  // launches of the iteration loop one solve_batch call may make
+
+int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || window > D.B) ? (D.B > 0 ? D.B : 1) : window; }
 
 struct Mailbox {  // pinned host words the device-side active counters are copied into
     int32_t* host = nullptr;
+    std::vector<int32_t> hist;  // exact active-list length of every global iteration of the last solve
     hipEvent_t ev[2] = {nullptr, nullptr};
     ~Mailbox() {
         if (host) (void)hipHostFree(host);
@@ -246,14 +264,14 @@ struct Profiler {
         if (e) (void)hipEventRecord(e, st);
     }
     // after the stream has been synchronised; active[it] = items processed by iteration it
-    void collect(const int32_t* active, int B) {
+    void collect(const std::vector<int32_t>& active, int B) {
         if (!on) return;
         for (const Rec& r : recs) {
             float t = 0.f;
             if (r.e0 + 1 < pool.size() && hipEventElapsedTime(&t, pool[r.e0], pool[r.e0 + 1]) == hipSuccess) {
                 ms[r.cls] += t;
                 launches[r.cls] += 1;
-                items[r.cls] += (r.iter <= 0) ? B : active[r.iter];
+                items[r.cls] += (r.iter < 0) ? B : (r.iter < (int)active.size() ? active[r.iter] : 0);
             }
         }
         recs.clear();
@@ -371,7 +389,7 @@ int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_
                                    const int32_t* n_items, void* stream) {
     if (B < 0 || T < 1 || n_x < 1 || n_u < 1) return fail(DPILQR_EINVAL, "backward_pass_tiles: bad sizes");
     if (!tiles || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_tiles: NULL pointer");
-    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, as_stream(stream));
+    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, 0, as_stream(stream));
 }
 
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
@@ -382,7 +400,7 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
     rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, as_stream(stream));
     if (rc) return rc;
     return launch_riccati(desc->B, desc->T, desc->k * desc->n_s, desc->k * desc->n_c, tiles_workspace, mu, K, d, nullptr,
-                          nullptr, nullptr, desc->B, as_stream(stream));
+                          nullptr, nullptr, desc->B, 0, as_stream(stream));
 }
 
 int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,
@@ -403,29 +421,33 @@ int32_t dpilqr_alphas(double* alphas_host) {
     return DPILQR_OK;
 }
 
-int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc) {
+int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace) {
     if (!desc || desc->B < 0 || desc->k < 1 || desc->T < 1) return fail(DPILQR_EINVAL, "solve_workspace_bytes: bad desc");
-    return (int64_t)SolveWorkspace(*desc, kMaxLqrIter).total;
+    return (int64_t)SolveWorkspace(*desc, window_of(*desc, window), gains_in_workspace != 0).total;
 }
 
 int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
-                           void* workspace, int64_t workspace_bytes, double* X, double* J, int32_t* status,
-                           int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out, void* stream) {
+                           int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
+                           int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out,
+                           void* stream) {
     int32_t rc = check_desc(desc);
     if (rc) return rc;
     if (!x0 || !U || !X || !J || !status || !n_bwd || !n_fwd || !workspace)
         return fail(DPILQR_EINVAL, "solve_batch: NULL pointer");
+    if ((K_out == nullptr) != (d_out == nullptr)) return fail(DPILQR_EINVAL, "solve_batch: K_out and d_out go together");
     if (n_lqr_iter < 0 || n_lqr_iter > kMaxLqrIter) return fail(DPILQR_EINVAL, "solve_batch: n_lqr_iter=%d", n_lqr_iter);
     const dpilqr_batch_desc& D = *desc;
-    const SolveWorkspace W(D, kMaxLqrIter);
+    const int Wn = window_of(D, window);
+    const bool gains_by_item = K_out != nullptr;
+    const SolveWorkspace W(D, Wn, !gains_by_item);
     if (workspace_bytes < (int64_t)W.total)
         return fail(DPILQR_EWORKSPACE, "solve_batch: workspace %lld B < required %zu B", (long long)workspace_bytes, W.total);
     if (D.B == 0) return DPILQR_OK;
     hipStream_t st = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
     double* tiles = reinterpret_cast<double*>(ws + W.tiles);
-    double* K = K_out ? K_out : reinterpret_cast<double*>(ws + W.K);
-    double* d = d_out ? d_out : reinterpret_cast<double*>(ws + W.d);
+    double* K = gains_by_item ? K_out : reinterpret_cast<double*>(ws + W.K);
+    double* d = gains_by_item ? d_out : reinterpret_cast<double*>(ws + W.d);
     double* alphas = reinterpret_cast<double*>(ws + W.alphas);
     double* Xc = reinterpret_cast<double*>(ws + W.Xc);
     double* Uc = reinterpret_cast<double*>(ws + W.Uc);
@@ -438,63 +460,90 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     S.J_star = reinterpret_cast<double*>(ws + W.J_star);
     S.J_last = reinterpret_cast<double*>(ws + W.J_last);
     S.status = status; S.n_bwd = n_bwd; S.n_fwd = n_fwd; S.trace = trace; S.singular = singular;
-    S.counts = counts; S.n_lqr_iter = n_lqr_iter; S.tol = tol;
+    S.n_lqr_iter = n_lqr_iter; S.tol = tol; S.gains_by_item = gains_by_item ? 1 : 0;
     const int n = D.k * D.n_s, m = D.k * D.n_c;
 
     if (!g_mail.host) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * (kMaxLqrIter + 2), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 2, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[1], hipEventDisableTiming));
     }
+    g_mail.hist.clear();
 
     double a[DPILQR_N_ALPHA];
     alpha_table(a);
-    const int n_counts = n_lqr_iter + 2;
-    const int init_n = D.B > n_counts ? D.B : n_counts;
+    const int init_n = D.B > kCountRing ? D.B : kCountRing;
     hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
-                       singular, counts, n_counts, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+                       singular, counts, kCountRing, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
     HIP_TRY(hipGetLastError());
-    // X, J* <- rollout(x0, U)   (control.py:164)
-    g_prof.begin(3, 0, st);
+    // X, J* <- rollout(x0, U) for every item up front (control.py:164)
+    g_prof.begin(3, -1, st);
     rc = launch_forward(D, kModeRollout, x0, X, U, nullptr, nullptr, nullptr, 1, nullptr, nullptr, S.J_star, S, nullptr,
                         nullptr, D.B, st);
     if (rc) return rc;
     g_prof.end(st);
     hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_star, S.J_last);
 
-    // Iteration loop.  The set of active items lives on the device (lists/counts); the host only
-    // needs an upper bound for the grid size, which it reads one iteration late so that a full
-    // iteration of launches is always queued while it waits.
-    int upper = D.B;
-    for (int it = 0; it < n_lqr_iter && upper > 0; ++it) {
-        const int32_t* cur = (it == 0) ? nullptr : lists + (size_t)(it & 1) * D.B;
-        const int32_t* cur_n = counts + it;
-        S.iter = it;
-        S.next_items = lists + (size_t)((it + 1) & 1) * D.B;
-        g_prof.begin(0, it, st);
-        if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, st))) return rc;
-        g_prof.end(st);
-        g_prof.begin(1, it, st);
-        if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, st))) return rc;
-        g_prof.end(st);
-        g_prof.begin(2, it, st);
-        if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr,
-                                 S, cur, cur_n, upper, st)))
-            return rc;
-        g_prof.end(st);
-        HIP_TRY(hipMemcpyAsync(g_mail.host + it + 1, counts + it + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
-        if (it >= 1) {
-            HIP_TRY(hipEventSynchronize(g_mail.ev[(it - 1) & 1]));
-            upper = g_mail.host[it];  // active items of iteration `it` >= those of iteration it+1
+    // Iteration loop with continuous admission.  At most Wn sub-problems are in flight; one global
+    // iteration = one backward pass + one line search for every active item.  Items that finish are
+    // retired by the line-search kernel (it pushes only the survivors onto the next list) and their
+    // places are refilled from the not-yet-started items, so every launch stays close to Wn items
+    // although the items need very different numbers of iterations.  The active set lives on the
+    // device; the host only needs an UPPER BOUND of its size for the grid and reads the exact size
+    // one iteration late, so a full iteration of launches is always queued while it waits.
+    int admitted = 0;      // items [0, admitted) have been started
+    int bound_prev = 0;    // upper bound of the previous iteration's list length (= of this one's survivors)
+    int n_new_prev = 0;
+    if (n_lqr_iter > 0) {
+        for (int it = 0; it < kMaxGlobalIter; ++it) {
+            int32_t* cur = lists + (size_t)(it & 1) * Wn;
+            int32_t* cur_n = counts + (it % kCountRing);
+            int32_t* nxt_n = counts + ((it + 1) % kCountRing);
+            const int n_new = std::min(D.B - admitted, Wn - bound_prev);
+            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted, n_new);
+            admitted += n_new;
+            const int upper = bound_prev + n_new;
+            if (upper == 0 && admitted == D.B) break;
+            S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
+            S.next_count = nxt_n;
+            g_prof.begin(0, it, st);
+            if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, st))) return rc;
+            g_prof.end(st);
+            g_prof.begin(1, it, st);
+            if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, st)))
+                return rc;
+            g_prof.end(st);
+            g_prof.begin(2, it, st);
+            if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr, S,
+                                     cur, cur_n, upper, st)))
+                return rc;
+            g_prof.end(st);
+            // exact list length of this iteration -> host, read back one iteration later
+            if (it >= 1) {
+                HIP_TRY(hipEventSynchronize(g_mail.ev[(it - 1) & 1]));
+                g_mail.hist.push_back(g_mail.host[(it - 1) & 1]);
+            }
+            HIP_TRY(hipMemcpyAsync(g_mail.host + (it & 1), cur_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
+            // survivors of this iteration <= its list length <= min(upper, exact length of it-1 + n_new)
+            int bound = upper;
+            if (it >= 1) bound = std::min(bound, g_mail.hist[it - 1] + n_new);
+            bound_prev = bound;
+            n_new_prev = n_new;
+            if (it + 1 == kMaxGlobalIter) return fail(DPILQR_EUNSUPPORTED, "solve_batch: more than %d global iterations", kMaxGlobalIter);
         }
     }
+    (void)n_new_prev;
     hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_last, J);
     if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    g_mail.host[0] = D.B;
-    g_prof.collect(g_mail.host, D.B);
+    if (!g_mail.hist.empty() || n_lqr_iter > 0) {
+        // the last iteration's exact length was copied but not yet consumed
+        const size_t have = g_mail.hist.size();
+        g_mail.hist.push_back(g_mail.host[have & 1]);
+    }
+    g_prof.collect(g_mail.hist, D.B);
     return DPILQR_OK;
 }
 

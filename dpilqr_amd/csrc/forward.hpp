@@ -30,9 +30,10 @@ struct SolveState {  // per-item solver state, device arrays of length B
     int32_t* n_fwd;
     double* trace;            // [B][n_lqr_iter][5] or null
     const int32_t* singular;  // [B] or null
-    int32_t* counts;          // [n_lqr_iter+1] active-item counters
-    int32_t* next_items;      // list for iteration iter+1
-    int32_t iter, n_lqr_iter;
+    int32_t* next_count;      // number of items pushed onto next_items so far
+    int32_t* next_items;      // active list of the next iteration
+    int32_t n_lqr_iter;
+    int32_t gains_by_item;    // K, d indexed by item id (caller asked for them) instead of list position
     double tol;
 };
 
@@ -281,11 +282,12 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
     }
 
     if (mode == kModeLineSearch && S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
-        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] = S.iter + 1; }
+        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] += 1; }
         return;
     }
-    const double* Kb = K + (int64_t)b * T * m * n;
-    const double* db = d + (int64_t)b * T * m;
+    const int64_t gslot = (mode == kModeLineSearch && !S.gains_by_item) ? slot : b;
+    const double* Kb = K + gslot * T * m * n;
+    const double* db = d + gslot * T * m;
     const bool active = (g < ngrp);
     const double alpha = active ? alphas[g] : 0.0;
     // candidate trajectories: slot of this item in the scratch (solve) or the caller's buffers (API)
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
     if (active && a == 0) lds[O.J + g] = J;
     __syncthreads();  // also makes every candidate's trajectory stores visible to the whole workgroup
     if (tid == 0) {
+        const int iter = S.n_bwd[b];   // this item's own iteration index (items join the batch at different times)
         const double J_star = S.J_star[b];
         int acc = -1;
         for (int i = 0; i < ngrp; ++i)
@@ -321,20 +324,20 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
             if (mu <= 1e-6) mu = 0.0;
             S.delta[b] = delta; S.mu[b] = mu; S.J_star[b] = J_new;
             if (conv) status = DPILQR_STATUS_CONVERGED;
-            else if (S.iter + 1 >= S.n_lqr_iter) status = DPILQR_STATUS_MAX_ITER;
+            else if (iter + 1 >= S.n_lqr_iter) status = DPILQR_STATUS_MAX_ITER;
         } else {
             status = DPILQR_STATUS_LINESEARCH_FAILED;  // control.py:195-198
         }
         S.J_last[b] = J_last;
         S.n_fwd[b] += n_eval;
-        S.n_bwd[b] = S.iter + 1;
+        S.n_bwd[b] = iter + 1;
         S.status[b] = status;
         if (S.trace) {
-            double* tr = S.trace + ((int64_t)b * S.n_lqr_iter + S.iter) * 5;
+            double* tr = S.trace + ((int64_t)b * S.n_lqr_iter + iter) * 5;
             tr[0] = mu_before; tr[1] = (double)acc; tr[2] = J_last; tr[3] = J_new; tr[4] = (double)n_eval;
         }
         if (status == DPILQR_STATUS_ACTIVE && S.next_items) {
-            const int pos = atomicAdd(&S.counts[S.iter + 1], 1);
+            const int pos = atomicAdd(S.next_count, 1);
             S.next_items[pos] = b;
         }
         ctl[0] = acc;

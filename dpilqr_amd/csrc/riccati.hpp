@@ -49,11 +49,13 @@ inline size_t riccati_lds_bytes(int n, int m) { return sizeof(double) * (size_t)
 __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, int m, const double* __restrict__ tiles,
                                   const double* __restrict__ mu_arr, double* __restrict__ Kout,
                                   double* __restrict__ dout, int32_t* __restrict__ singular,
-                                  const int32_t* __restrict__ items, const int32_t* __restrict__ n_items) {
+                                  const int32_t* __restrict__ items, const int32_t* __restrict__ n_items,
+                                  int gains_by_item) {
     const int slot = blockIdx.x;
     if (n_items && slot >= *n_items) return;
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
+    const int64_t gslot = gains_by_item ? b : slot;   // where K, d of this sub-problem go
     const int tid = threadIdx.x, nth = blockDim.x;
     const TileLayout L(n, m);
     const RiccatiLds O(n, m);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
     int* sflag = reinterpret_cast<int*>(lds + O.misc);
 
     const double mu = mu_arr[b];
-    const double* base = tiles + (int64_t)b * (T + 1) * L.stride;
+    const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
     const int n1 = n + 1;
 
     // terminal condition: p = l_x(T), P = l_xx(T)   (control.py:125-129)
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
 
         // stream the gains out: K[b][t] (m x n), d[b][t] (m)
         {
-            double* Kt = Kout + ((int64_t)b * T + t) * m * n;
-            double* dt_ = dout + ((int64_t)b * T + t) * m;
+            double* Kt = Kout + (gslot * T + t) * m * n;
+            double* dt_ = dout + (gslot * T + t) * m;
             for (int e = tid; e < m * n; e += nth) {
                 const int a = e / n, j = e - a * n;
                 Kt[e] = sK[a * n1 + j];

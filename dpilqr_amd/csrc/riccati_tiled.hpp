@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                                                        const double* __restrict__ mu_arr, double* __restrict__ Kout,
                                                        double* __restrict__ dout, int32_t* __restrict__ singular,
                                                        const int32_t* __restrict__ items,
-                                                       const int32_t* __restrict__ n_items) {
+                                                       const int32_t* __restrict__ n_items, int gains_by_item) {
     using C = TiledCfg<N, M>;
     constexpr int NM = C::NM, RB = C::RB, CB = C::CB, NMP = C::NMP, LAB = C::LAB, LP = C::LP, NP = C::NP;
     constexpr int LQ = C::LQ, LK = C::LK, LG = C::LG;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     if (n_items && slot >= *n_items) return;
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
+    const int64_t gslot = gains_by_item ? b : slot;   // where K, d of this sub-problem go
     const int lane = threadIdx.x;
     const TileLayout L(N, M);
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     double* sTrash = lds + C::oTrash;
 
     const double mu = mu_arr[b];
-    const double* base = tiles + (int64_t)b * (T + 1) * L.stride;
+    const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
     int sing = 0;
 
     // ---- one-time LDS initialisation: zero everything (pads must stay finite), then P, p from record T
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
             // K = -X (lanes M..M+N-1 hold its columns), d = -x (lane M+N)
             if (lane >= M && lane <= M + N) {
                 const int j = lane - M;
-                double* Kt = Kout + ((int64_t)b * T + t) * M * N;
-                double* dt_ = dout + ((int64_t)b * T + t) * M;
+                double* Kt = Kout + (gslot * T + t) * M * N;
+                double* dt_ = dout + (gslot * T + t) * M;
 #pragma unroll
                 for (int a = 0; a < M; ++a) {
                     const double kv = -v[a];

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
     }
     __syncthreads();
 
-    double* rec = tiles + ((int64_t)b * (T + 1) + t) * L.stride;
+    double* rec = tiles + ((int64_t)slot * (T + 1) + t) * L.stride;  // records are indexed by list position
     const double wr = D.w_ref, wp = D.w_prox;
 
     // ---- phase 2: dense record.  A, B only for t < T (record T never has them read).

@@ -120,7 +120,8 @@ int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const dou
  * [B][T+1][stride] doubles.  Component offsets and the record stride are 16-byte aligned. */
 int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t row_strides[7], int64_t* stride);
 /* device-side producer for the recognised plugin types; X[B][T+1][n_x], U[B][T][n_u].
- * items/n_items select a subset (device int32 list + device count); NULL/NULL = all B items.      */
+ * items/n_items select a subset (device int32 list + device count); NULL/NULL = all B items.  Record
+ * r of the output belongs to the r-th LISTED item.                                                   */
 int32_t dpilqr_make_tiles(const dpilqr_batch_desc* desc, const double* X, const double* U, double* tiles,
                           const int32_t* items, const int32_t* n_items, void* stream);
 
@@ -130,7 +131,8 @@ int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const do
                        void* stream);
 /* ilqrSolver._backward_pass (control.py:116-148) on tile records: the Riccati sweep.
  * mu[B] per-item regularisation; K[B][T][n_u][n_x]; d[B][T][n_u]; singular[B] (may be NULL) set to 1
- * where a pivot was exactly zero.  items/n_items as above.                                          */
+ * where a pivot was exactly zero.  With an item list (items/n_items as above) the tile records, K and
+ * d are indexed by POSITION in the list (mu, singular by item id); without one the two coincide.     */
 int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_u, const double* tiles,
                                    const double* mu, double* K, double* d, int32_t* singular,
                                    const int32_t* items, const int32_t* n_items, void* stream);
@@ -156,10 +158,15 @@ int32_t dpilqr_alphas(double* alphas_host);
  *   K_out/d_out (may be NULL): [B][T][n_u][n_x] / [B][T][n_u] gains of each item's LAST backward pass.
  * Plugins the library does not recognise never reach this entry point: the host solver calls their
  * linearize/quadraticize itself and feeds dpilqr_backward_pass_tiles.
- * workspace: dpilqr_solve_workspace_bytes(desc) bytes of device memory.                              */
-int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc);
+ * window (<= 0: B): the most sub-problems in flight at once.  Sub-problems need very different numbers
+ *   of iterations (1..25 at cfg2), so finished ones are retired on the device and their places refilled
+ *   from the not-yet-started items of the batch: every launch stays near `window` items, and the large
+ *   per-iteration buffers (tile records, gains, line-search candidates) are sized by `window`, not B.
+ *   Hand the solver the whole Monte-Carlo batch and let `window` bound the memory.
+ * workspace: dpilqr_solve_workspace_bytes(desc, window, K_out == NULL) bytes of device memory.           */
+int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
 int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter,
-                           double tol, void* workspace, int64_t workspace_bytes, double* X, double* J,
+                           double tol, int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
                            int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
                            double* d_out, void* stream);
 

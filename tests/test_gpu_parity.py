@@ -183,3 +183,24 @@ def test_solve_batch_vs_oracle_256(dp):
     assert np.isfinite(X).all() and np.isfinite(U).all() and (st >= 1).all() and (st <= 3).all()
     Jfin = pb.rollout(x0, U)[1].cpu().numpy()
     assert (Jfin <= J0 * (1 + 1e-12)).all()
+
+
+def test_window_invariance(dp):
+    """Continuous admission (a window of sub-problems in flight, finished ones replaced by new ones) is pure
+    scheduling: every item's result must be BIT-identical to the all-at-once solve."""
+    from dpilqr_amd.util import random_setup
+    c = cfg2_params(); B = 300
+    x0 = np.zeros((B, 20)); xf = np.zeros((B, 20))
+    for s in range(B):
+        np.random.seed(5000 + s)
+        a, b = random_setup(5, 4, is_rotation=False, rel_dist=5, var=2.5, n_d=2, random=True, energy=10.0)
+        x0[s], xf[s] = a.ravel(), b.ravel()
+    pb = dp.ProblemBatch(c["model"], c["n_dims"], xf, c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    U0 = np.zeros((B, 50, 10))
+    full = pb.solve(x0, U0, trace=True, window=B)
+    for w in (64, 7, 1):
+        part = pb.solve(x0, U0, trace=True, window=w)
+        for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
+            assert (full[key] == part[key]).all().item(), (w, key)
+    g = pb.solve(x0, U0, gains=True, window=50)      # gains requested: K, d indexed by item
+    assert (g["X"] == full["X"]).all().item()
