@@ -171,13 +171,15 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
     }
 }
 
-// Append the not-yet-started items [first, first+n_new) to the active list behind the survivors that
-// the previous iteration's line search pushed, and clear the counter the NEXT iteration will push into.
-__global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int first, int n_new) {
-    const int base = *count;
+// Admission, decided on the device where the exact number of survivors is known: behind the survivors
+// that the previous iteration's line search pushed, append as many not-yet-started items as fit in the
+// window, and clear the counter the NEXT iteration will push into.  ctl = {count, admitted} mailbox copy.
+__global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window) {
+    const int base = *count, first = *admitted;
+    const int n_new = min(B - first, window - base);
     __syncthreads();
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
-    if (threadIdx.x == 0) { *count = base + n_new; *next_count = 0; }
+    if (threadIdx.x == 0) { *count = base + n_new; *admitted = first + n_new; *next_count = 0; }
 }
 
 __global__ void k_copy_f64(int n, const double* src, double* dst) {
@@ -214,7 +216,7 @@ struct SolveWorkspace {
         alphas = o;   o = al(o + sizeof(double) * DPILQR_N_ALPHA);
         singular = o; o = al(o + sizeof(int32_t) * B);
         lists = o;    o = al(o + sizeof(int32_t) * 2 * Wn);
-        counts = o;   o = al(o + sizeof(int32_t) * kCountRing);
+        counts = o;   o = al(o + sizeof(int32_t) * (kCountRing + 1));   // ring + the `admitted` counter
         total = o;
     }
 };
@@ -464,7 +466,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     const int n = D.k * D.n_s, m = D.k * D.n_c;
 
     if (!g_mail.host) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 2, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 4, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[1], hipEventDisableTiming));
     }
@@ -472,9 +474,9 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
 
     double a[DPILQR_N_ALPHA];
     alpha_table(a);
-    const int init_n = D.B > kCountRing ? D.B : kCountRing;
+    const int init_n = D.B > kCountRing + 1 ? D.B : kCountRing + 1;
     hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
-                       singular, counts, kCountRing, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+                       singular, counts, kCountRing + 1, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
     HIP_TRY(hipGetLastError());
     // X, J* <- rollout(x0, U) for every item up front (control.py:164)
     g_prof.begin(3, -1, st);
@@ -486,24 +488,20 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
 
     // Iteration loop with continuous admission.  At most Wn sub-problems are in flight; one global
     // iteration = one backward pass + one line search for every active item.  Items that finish are
-    // retired by the line-search kernel (it pushes only the survivors onto the next list) and their
-    // places are refilled from the not-yet-started items, so every launch stays close to Wn items
-    // although the items need very different numbers of iterations.  The active set lives on the
-    // device; the host only needs an UPPER BOUND of its size for the grid and reads the exact size
-    // one iteration late, so a full iteration of launches is always queued while it waits.
-    int admitted = 0;      // items [0, admitted) have been started
-    int bound_prev = 0;    // upper bound of the previous iteration's list length (= of this one's survivors)
-    int n_new_prev = 0;
+    // retired by the line-search kernel (it pushes only the survivors onto the next list) and k_admit
+    // refills their places from the not-yet-started items, so every launch stays at Wn items although
+    // the items need very different numbers of iterations.  The active set lives on the device; the
+    // host launches Wn-wide grids (surplus workgroups exit at once) and only reads {active, admitted}
+    // one iteration late -- a full iteration of launches is always queued while it waits -- to learn
+    // when everything has been started and nothing is left active.
+    int32_t* admitted_dev = counts + kCountRing;
     if (n_lqr_iter > 0) {
+        int upper = Wn;
         for (int it = 0; it < kMaxGlobalIter; ++it) {
             int32_t* cur = lists + (size_t)(it & 1) * Wn;
             int32_t* cur_n = counts + (it % kCountRing);
             int32_t* nxt_n = counts + ((it + 1) % kCountRing);
-            const int n_new = std::min(D.B - admitted, Wn - bound_prev);
-            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted, n_new);
-            admitted += n_new;
-            const int upper = bound_prev + n_new;
-            if (upper == 0 && admitted == D.B) break;
+            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn);
             S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
             S.next_count = nxt_n;
             g_prof.begin(0, it, st);
@@ -518,30 +516,31 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                                      cur, cur_n, upper, st)))
                 return rc;
             g_prof.end(st);
-            // exact list length of this iteration -> host, read back one iteration later
-            if (it >= 1) {
+            bool done = false;
+            if (it >= 1) {  // {active, admitted} of iteration it-1
                 HIP_TRY(hipEventSynchronize(g_mail.ev[(it - 1) & 1]));
-                g_mail.hist.push_back(g_mail.host[(it - 1) & 1]);
+                const int32_t act = g_mail.host[2 * ((it - 1) & 1)], adm = g_mail.host[2 * ((it - 1) & 1) + 1];
+                g_mail.hist.push_back(act);
+                // everything started and the list already empty one iteration ago: iteration `it` was a no-op
+                done = (adm >= D.B && act == 0);
+                // once everything is admitted the list can only shrink: tighten the grid
+                upper = (adm >= D.B) ? std::min(Wn, std::max(act, 1)) : Wn;
             }
-            HIP_TRY(hipMemcpyAsync(g_mail.host + (it & 1), cur_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(g_mail.host + 2 * (it & 1), cur_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(g_mail.host + 2 * (it & 1) + 1, admitted_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
-            // survivors of this iteration <= its list length <= min(upper, exact length of it-1 + n_new)
-            int bound = upper;
-            if (it >= 1) bound = std::min(bound, g_mail.hist[it - 1] + n_new);
-            bound_prev = bound;
-            n_new_prev = n_new;
+            if (done) break;
             if (it + 1 == kMaxGlobalIter) return fail(DPILQR_EUNSUPPORTED, "solve_batch: more than %d global iterations", kMaxGlobalIter);
         }
     }
-    (void)n_new_prev;
     hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_last, J);
     if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    if (!g_mail.hist.empty() || n_lqr_iter > 0) {
+    if (n_lqr_iter > 0) {
         // the last iteration's exact length was copied but not yet consumed
         const size_t have = g_mail.hist.size();
-        g_mail.hist.push_back(g_mail.host[have & 1]);
+        g_mail.hist.push_back(g_mail.host[2 * (have & 1)]);
     }
     g_prof.collect(g_mail.hist, D.B);
     return DPILQR_OK;
