@@ -53,6 +53,7 @@ SIGNATURES = {
     "dpilqr_alphas": (i32, [C.POINTER(f64 * N_ALPHA)]),
     "dpilqr_solve_workspace_bytes": (i64, [_DP, i32, i32]),
     "dpilqr_solve_batch": (i32, [_DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_debug_stamps": (i32, [vp]),
     "dpilqr_profile_enable": (i32, [i32]),
     "dpilqr_profile_read": (i32, [C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
     "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),

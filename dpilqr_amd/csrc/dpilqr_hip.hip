@@ -108,8 +108,12 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
 #define DPILQR_TRY_TILED(NN, MM)                                                                                   \
     if (n == NN && m == MM) {                                                                                      \
         static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
-        hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3(grid_items), dim3(64), 0, st, B, T, tiles, mu, K, d,     \
-                           singular, items, n_items, gains_by_item);                                               \
+        const size_t lds_t = sizeof(double) * TiledCfg<NN, MM>::total * kTiledWaves;                              \
+        int32_t rc_t = allow_lds(k_riccati_tiled<NN, MM>, lds_t);                                                  \
+        if (rc_t) return rc_t;                                                                                     \
+        hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3((grid_items + kTiledWaves - 1) / kTiledWaves),          \
+                           dim3(64 * kTiledWaves), lds_t, st, B, T, tiles, mu, K, d, singular, items, n_items,     \
+                           gains_by_item);                                                                         \
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
@@ -131,16 +135,20 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
                        hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
     const int n = D.k * D.n_s, m = D.k * D.n_c;
-    const int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
+    int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
     if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
-    const size_t lds = forward_lds_bytes(n, m, D.k, ngrp);
+    const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
     if ((m * n + threads - 1) / threads > kMaxStage)
         return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
+    // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp
+    const int ipb = (threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;
+    const size_t lds = lds_item * ipb;
+    threads *= ipb;
     DISPATCH_FAMILY(D.n_s, {
         int32_t rc = allow_lds(k_forward<NS, NC>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_forward<NS, NC>), dim3(grid_items), dim3(threads), lds, st, D, mode, x0, X, U, K, d, alphas,
-                           ngrp, Xc, Uc, Jc, S, items, n_items);
+        hipLaunchKernelGGL((k_forward<NS, NC>), dim3((grid_items + ipb - 1) / ipb), dim3(threads), lds, st, D, mode, x0, X, U,
+                           K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, ipb, (int)(lds_item / sizeof(double)));
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;
@@ -543,6 +551,12 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
         g_mail.hist.push_back(g_mail.host[2 * (have & 1)]);
     }
     g_prof.collect(g_mail.hist, D.B);
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_debug_stamps(void* buf) {
+    void* p = buf;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)));
     return DPILQR_OK;
 }
 

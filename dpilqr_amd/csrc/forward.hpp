@@ -72,8 +72,8 @@ constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step: ceil(n
 // Everything a step needs from HBM (K[t], d[t], X[t], U[t]) is fetched one step ahead into registers.
 // Returns J on the a == 0 lane of each candidate.
 template <int NS, int NC, bool GAINS>
-__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, bool active, int g, int a,
-                               int ngrp, const double* x_init, const double* __restrict__ Xold,
+__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int tid, int nth, bool active,
+                               int g, int a, int ngrp, const double* x_init, const double* __restrict__ Xold,
                                const double* __restrict__ Uold, const double* __restrict__ Kb,
                                const double* __restrict__ db, double alpha, double* __restrict__ Xw,
                                double* __restrict__ Uw, double* lds) {
@@ -81,7 +81,6 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
     const int npairs = k * (k - 1) / 2, np1 = npairs > 0 ? npairs : 1;
     const ForwardLds O(n, m, k, ngrp);
     const int gg = active ? g : 0;
-    const int tid = threadIdx.x, nth = blockDim.x;
     const bool single_wave = nth <= 64;
     const int mn = m * n;
 
@@ -254,28 +253,35 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
 // kModeCandidates : Xc, Uc, Jc <- forward_pass(X, U, K, d, alpha_g) for every g (control.py:95-114)
 // kModeLineSearch : the same, followed by the accept / regularisation logic of one solver iteration
 //                   (control.py:179-211) and the copy of the accepted candidate into X, U.
+// Workgroup layout: `ipb` sub-problems per workgroup.  When a sub-problem's threads fit one wavefront
+// (n_alpha * k <= 64, e.g. cfg2's 50) four of them share a 256-thread workgroup, one wave each with its own
+// LDS slice and no workgroup barrier -- the same SIMD-placement argument as for the sweep (riccati_tiled.hpp).
 template <int NS, int NC>
 __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X,
                                                   double* U, const double* __restrict__ K, const double* __restrict__ d,
                                                   const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc,
                                                   double* Jc, SolveState S, const int32_t* __restrict__ items,
-                                                  const int32_t* __restrict__ n_items) {
-    const int slot = blockIdx.x;
-    if (n_items && slot >= *n_items) return;
+                                                  const int32_t* __restrict__ n_items, int ipb, int lds_per_item) {
+    const int nth = (ipb > 1) ? 64 : (int)blockDim.x;
+    const int sub = (ipb > 1) ? (int)(threadIdx.x >> 6) : 0;
+    const int tid = (ipb > 1) ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int slot = blockIdx.x * ipb + sub;
+    if (slot >= (n_items ? *n_items : D.B)) return;
     const int b = items ? items[slot] : slot;
     const int k = D.k, T = D.T, n = k * NS, m = k * NC;
-    const int tid = threadIdx.x;
     const int g = tid / k, a = tid - g * k;
     const ItemParams P = item_params(D, b);
     const bool homog = homogeneous_ndims(P.n_dims, k);
-    extern __shared__ double lds[];
+    extern __shared__ double lds_all[];
+    double* lds = lds_all + (size_t)sub * lds_per_item;
+    const bool single_wave = nth <= 64;
     const ForwardLds O(n, m, k, ngrp);
     double* Xb = X + (int64_t)b * (T + 1) * n;
     double* Ub = U + (int64_t)b * T * m;
 
     if (mode == kModeRollout) {
         const bool active = (g == 0);
-        const double J = horizon_pass<NS, NC, false>(D, P, homog, active, 0, a, 1, x0 + (int64_t)b * n, nullptr, Ub,
+        const double J = horizon_pass<NS, NC, false>(D, P, homog, tid, nth, active, 0, a, 1, x0 + (int64_t)b * n, nullptr, Ub,
                                                      nullptr, nullptr, 0.0, Xb, nullptr, lds);
         if (active && a == 0) Jc[b] = J;
         return;
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
     const int64_t cslot = (mode == kModeLineSearch) ? slot : b;
     double* Xw = active ? Xc + (cslot * ngrp + g) * (int64_t)(T + 1) * n : nullptr;
     double* Uw = active ? Uc + (cslot * ngrp + g) * (int64_t)T * m : nullptr;
-    const double J = horizon_pass<NS, NC, true>(D, P, homog, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha, Xw, Uw, lds);
+    const double J = horizon_pass<NS, NC, true>(D, P, homog, tid, nth, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha, Xw, Uw,
+                                                lds);
     if (mode == kModeCandidates) {
         if (active && a == 0) Jc[(int64_t)b * ngrp + g] = J;
         return;
@@ -303,7 +310,8 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
     // ---- one iLQR iteration's line-search decision + bookkeeping (control.py:179-211)
     int* ctl = reinterpret_cast<int*>(lds + O.ctl);
     if (active && a == 0) lds[O.J + g] = J;
-    __syncthreads();  // also makes every candidate's trajectory stores visible to the whole workgroup
+    // hand-off that also makes every candidate's trajectory stores visible to the threads that copy them
+    if (single_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); else __syncthreads();
     if (tid == 0) {
         const int iter = S.n_bwd[b];   // this item's own iteration index (items join the batch at different times)
         const double J_star = S.J_star[b];
@@ -342,14 +350,14 @@ __global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, 
         }
         ctl[0] = acc;
     }
-    __syncthreads();
+    if (single_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); else __syncthreads();
     const int acc = ctl[0];
     if (acc < 0) return;
     // accepted: X, U <- the accepted candidate's trajectory (a coalesced copy out of the scratch)
     const double* Xa = Xc + (cslot * ngrp + acc) * (int64_t)(T + 1) * n;
     const double* Ua = Uc + (cslot * ngrp + acc) * (int64_t)T * m;
-    for (int e = tid; e < (T + 1) * n; e += blockDim.x) Xb[e] = Xa[e];
-    for (int e = tid; e < T * m; e += blockDim.x) Ub[e] = Ua[e];
+    for (int e = tid; e < (T + 1) * n; e += nth) Xb[e] = Xa[e];
+    for (int e = tid; e < T * m; e += nth) Ub[e] = Ua[e];
 }
 
 // ---- small batched entry points ------------------------------------------------------------------

@@ -37,6 +37,23 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Global stores issued through inline asm, on purpose.  hipcc's wait-count pass treats a vmcnt with both
+// loads and stores pending as out of order and answers every wait on a prefetched load with vmcnt(0),
+// which would also wait for loads issued a few instructions earlier.  gfx950 retires vector-memory
+// operations in issue order (MI355X guide, s_waitcnt notes), so hiding these fire-and-forget stores from
+// the pass keeps its counted vmcnt(N) waits: they merely become conservative by the number of stores
+// in flight.  Nothing ever reads the stored data back inside the kernel.
+__device__ __forceinline__ void store_v2d_nt(double* p, v2d v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_f64_nt(double* p, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// Diagnostic stamps (dpilqr_debug_stamps): when a buffer is registered, lane 0 of every sweep workgroup
+// records {start, end} of s_memrealtime (100 MHz) and its XCC / CU / SIMD ids.  Never read by any kernel.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+
 constexpr int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 template <int N, int M>
@@ -61,7 +78,7 @@ struct TiledCfg {
     static constexpr int oK = oG + (NMP - N) * LG;
     static constexpr int oT3 = oK + M * LK;
     static constexpr int oTrash = oT3 + M * N;         // where masked-out stores go (never read)
-    static constexpr int total = oTrash + 2;
+    static constexpr int total = round_up(oTrash + M * LK, 2);   // trash: a whole masked-out [K | d] column write
     static constexpr bool supported = (N % 2 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 64 * 1024);
     // per-lane prefetch of [A|B]: 16-byte pairs, round-robin over the wave
     static constexpr int AB_PAIRS = N * NM / 2;
@@ -101,8 +118,16 @@ __device__ __forceinline__ void block_product(const double* __restrict__ X, cons
     }
 }
 
+// Workgroup = kTiledWaves independent wavefronts, each sweeping its own sub-problem out of its own LDS
+// slice (no barriers, no sharing).  Packing four of them into one 256-thread workgroup is placement
+// control, not cooperation: a workgroup's waves are dealt one per SIMD, whereas 1024 single-wave
+// workgroups were observed (in-kernel HW_ID stamps) to land two-on-a-SIMD on ~17 % of the CUs whenever the
+// preceding kernel had left the dispatcher's SIMD rotation in an odd state -- and this kernel is
+// issue-bound, so two waves on one SIMD run at half speed and the launch takes 1.4x as long.
+constexpr int kTiledWaves = 4;
+
 template <int N, int M>
-__global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double* __restrict__ tiles,
+__global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T, const double* __restrict__ tiles,
                                                        const double* __restrict__ mu_arr, double* __restrict__ Kout,
                                                        double* __restrict__ dout, int32_t* __restrict__ singular,
                                                        const int32_t* __restrict__ items,
@@ -110,15 +135,17 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     using C = TiledCfg<N, M>;
     constexpr int NM = C::NM, RB = C::RB, CB = C::CB, NMP = C::NMP, LAB = C::LAB, LP = C::LP, NP = C::NP;
     constexpr int LQ = C::LQ, LK = C::LK, LG = C::LG;
-    const int slot = blockIdx.x;
-    if (n_items && slot >= *n_items) return;
+    const int wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * kTiledWaves + wave;
+    if (slot >= (n_items ? *n_items : B)) return;
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
     const int64_t gslot = gains_by_item ? b : slot;   // where K, d of this sub-problem go
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const TileLayout L(N, M);
 
-    __shared__ __attribute__((aligned(16))) double lds[C::total];
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds = lds_all + wave * C::total;
     double* sAB = lds + C::oAB;
     double* sP = lds + C::oP;
     double* sPt = lds + C::oPt;
@@ -132,6 +159,9 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     const double mu = mu_arr[b];
     const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
     int sing = 0;
+    unsigned long long* const stamps = g_stamp_buf;
+    unsigned long long t_start = 0;
+    if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
 
     // ---- one-time LDS initialisation: zero everything (pads must stay finite), then P, p from record T
     for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
@@ -220,6 +250,17 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
         for (int r = 0; r < RB; ++r) s6_mu[r][c] = (s5_i0 + r == j) ? mu : 0.0;
     }
     constexpr int PT_OFF = C::oPt - C::oP;
+    // S3 epilogue: where this lane's column of -X goes in [K | d], and the coalesced copy-out pattern
+    double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sTrash;
+    constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
+    int k_in[K_ROUNDS], k_out[K_ROUNDS];
+#pragma unroll
+    for (int q = 0; q < K_ROUNDS; ++q) {
+        const int e2 = min(lane + 64 * q, K_PAIRS - 1), e = 2 * e2;
+        k_out[q] = e;
+        k_in[q] = (e / N) * LK + (e % N);
+    }
+    const int d_idx = min(lane, M - 1);
     // [A|B] prefetch: pair q of this lane -> LDS destination
     double* ab_dst[C::AB_ROUNDS];
     int ab_src[C::AB_ROUNDS];
@@ -235,31 +276,43 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
     v2d nAB[C::AB_ROUNDS];
     v2d nL[RB][CB / 2];      // l-values of the S2 block
     v2d nLxu[RB / 2];        // [l_x ; l_u][s1_i0 .. s1_i0+RB)
-    auto prefetch = [&](int t) {
+    // Three prefetch points per step, each a full step ahead of its use and each re-filling registers
+    // that were consumed the instruction before (no second register set):
+    //   after S0 (AB of record t parked in LDS)        -> [A|B] of record t-1
+    //   after S1 (l_x, l_u of record t folded in)      -> [l_x; l_u] of record t-1
+    //   after S2 (l_xx/l_ux/l_uu of record t folded in) -> the same block of record t-1
+    auto prefetch_ab = [&](int t) {
         const double* rec = base + (int64_t)t * L.stride;
 #pragma unroll
         for (int q = 0; q < C::AB_ROUNDS; ++q) nAB[q] = *reinterpret_cast<const v2d*>(rec + ab_src[q]);
+    };
+    auto prefetch_lxu = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
+#pragma unroll
+        for (int r = 0; r < RB / 2; ++r) nLxu[r] = *reinterpret_cast<const v2d*>(rec + s1_lsrc[r]);
+    };
+    auto prefetch_l = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB / 2; ++c) nL[r][c] = *reinterpret_cast<const v2d*>(rec + s2_src[r][c]);
-#pragma unroll
-        for (int r = 0; r < RB / 2; ++r) nLxu[r] = *reinterpret_cast<const v2d*>(rec + s1_lsrc[r]);
     };
-    prefetch(T - 1);
+    prefetch_ab(T - 1);
+    prefetch_lxu(T - 1);
+    prefetch_l(T - 1);
+    // Drain the prologue's loads here, once.  Otherwise the loop header merges "prologue order" (which the
+    // scheduler is free to permute) with the loop's own issue order, and the only wait that is safe for both
+    // is vmcnt(0) on every iteration; with nothing pending on entry the in-loop waits stay counted.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
     for (int t = T - 1; t >= 0; --t) {
-        // ---- S0: park [A|B] of record t in LDS, take over its l-values
-        v2d cL[RB][CB / 2], cLxu[RB / 2];
+        const int tn = t > 0 ? t - 1 : 0;   // record to prefetch (the last step re-reads record 0: harmless)
+        // ---- S0: park [A|B] of record t in LDS
 #pragma unroll
         for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < CB / 2; ++c) cL[r][c] = nL[r][c];
-#pragma unroll
-        for (int r = 0; r < RB / 2; ++r) cLxu[r] = nLxu[r];
         DPILQR_LDS_FENCE();
+        prefetch_ab(tn);
 
         // ---- S1: [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]
         {
@@ -276,11 +329,12 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                     *reinterpret_cast<v2d*>(s1_t + c * LAB + r) = v2d{acc[r][c], acc[r + 1][c]};
 #pragma unroll
             for (int r = 0; r < RB; ++r) {  // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
-                const double lv = (r & 1) ? cLxu[r / 2].y : cLxu[r / 2].x;
+                const double lv = (r & 1) ? nLxu[r / 2].y : nLxu[r / 2].x;
                 *s1_q[r] = lv + acc[r][0];
             }
         }
         DPILQR_LDS_FENCE();
+        prefetch_lxu(tn);
 
         // ---- S2: [T1;T2][A|B] -> Q_xx, Q_ux, Q_uu
         {
@@ -294,10 +348,10 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < CB / 2; ++c)
-                    *reinterpret_cast<v2d*>(s2_dst[r][c]) = v2d{cL[r][c].x + acc[r][2 * c], cL[r][c].y + acc[r][2 * c + 1]};
+                    *reinterpret_cast<v2d*>(s2_dst[r][c]) = v2d{nL[r][c].x + acc[r][2 * c], nL[r][c].y + acc[r][2 * c + 1]};
         }
         DPILQR_LDS_FENCE();
-        if (t > 0) prefetch(t - 1);   // record t-1 lands while S3..S6 run; consumed at the top of the next step
+        prefetch_l(tn);
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers
         {
@@ -320,7 +374,10 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int r = kk + 1; r < M; ++r)
-                        if (r == piv) { const double tv = v[r]; v[r] = v[kk]; v[kk] = tv; }
+                        if (r == piv) {
+                            asm volatile("" ::: "memory");   // keep it a scalar branch, not 4 selects per row
+                            const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
+                        }
                 }
                 const double pv = readlane_f64(v[kk], kk);
                 if (pv == 0.0) sing = 1;
@@ -342,18 +399,20 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
                 for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
                 v[r] = s * invd[r];
             }
-            // K = -X (lanes M..M+N-1 hold its columns), d = -x (lane M+N)
-            if (lane >= M && lane <= M + N) {
-                const int j = lane - M;
-                double* Kt = Kout + (gslot * T + t) * M * N;
-                double* dt_ = dout + (gslot * T + t) * M;
+            // K = -X (lanes M..M+N-1 hold its columns), d = -x (lane M+N): into LDS as [K | d]
 #pragma unroll
-                for (int a = 0; a < M; ++a) {
-                    const double kv = -v[a];
-                    sK[a * LK + j] = kv;
-                    if (j < N) Kt[a * N + j] = kv; else dt_[a] = kv;
-                }
-            }
+            for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];   // lanes outside the range write to sTrash
+        }
+        DPILQR_LDS_FENCE();
+        // stream K[t] (M x N, contiguous) and d[t] out with unconditional, coalesced stores: every lane
+        // stores (surplus lanes repeat the last element) so that the number of outstanding stores is
+        // static and the waits on the prefetched loads stay counted instead of collapsing to vmcnt(0)
+        {
+            double* Kt = Kout + (gslot * T + t) * M * N;
+            double* dt_ = dout + (gslot * T + t) * M;
+#pragma unroll
+            for (int q = 0; q < K_ROUNDS; ++q) store_v2d_nt(Kt + k_out[q], *reinterpret_cast<const v2d*>(sK + k_in[q]));
+            store_f64_nt(dt_ + d_idx, sK[d_idx * LK + N]);
         }
         DPILQR_LDS_FENCE();
 
@@ -407,6 +466,15 @@ __global__ __launch_bounds__(64) void k_riccati_tiled(int B, int T, const double
         DPILQR_LDS_FENCE();
     }
     if (singular && sing && lane == 0) singular[b] = 1;
+    if (stamps && lane == 0) {
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        stamps[4 * slot + 0] = t_start;
+        stamps[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[4 * slot + 2] = hw_id;
+        stamps[4 * slot + 3] = xcc_id;
+    }
 }
 
 }  // namespace dpilqr

@@ -176,6 +176,9 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
  * (0 = tile producer, 1 = Riccati sweep, 2 = line search / forward pass, 3 = initial rollout):
  * total milliseconds, number of launches, and number of sub-problems those launches processed.      */
 int32_t dpilqr_profile_enable(int32_t enable);
+/* diagnostic: register (or clear with NULL) a device buffer of 4 x uint64 per sweep workgroup that receives
+ * {start, end} wall-clock stamps (100 MHz) and the HW_ID / XCC_ID registers of the wave that ran it.   */
+int32_t dpilqr_debug_stamps(void* device_buffer);
 int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset);
 
 /* -------------------------------------------------- (6) dispatch front end ("next" row)
