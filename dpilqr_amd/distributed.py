@@ -1,0 +1,122 @@
+"""DP-iLQR driver: same entry points as the reference's dpilqr/distributed.py
+(solve_distributed :25-103, solve_rhc :106-221, define_inter_graph_threshold :224-247, solve_centralized :250-258).
+
+The per-agent sub-problem loop (and its optional multiprocessing pool) is replaced by one batched device
+dispatch (dispatch.solve_problem_list); graph construction and stitching are unchanged in meaning.
+"""
+import itertools
+import logging
+from time import perf_counter as pc
+
+import numpy as np
+
+from .control import ilqrSolver
+from .dispatch import solve_problem_list
+from .util import compute_pairwise_distance, split_graph
+
+
+def define_inter_graph_threshold(X, radius, x_dims, ids):
+    """Interaction graph {id: sorted ids within 2*radius (planar) at any sampled step, incl. itself}."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    n_rows = X.shape[0]
+    step = max(n_rows // 10, 1)                      # ~10 samples over the trajectory
+    near = compute_pairwise_distance(X, x_dims)[0:n_rows + 1:step] < 2 * radius
+    graph = {id_: [id_] for id_ in ids}
+    for col, (a, b) in enumerate(itertools.combinations(ids, 2)):
+        if near[:, col].any():
+            graph[a].append(b)
+            graph[b].append(a)
+    return {id_: sorted(members) for id_, members in graph.items()}
+
+
+def solve_distributed(problem, X, U, radius, ignore_ids=None, pool=None, verbose=True, **kwargs):
+    """One sub-problem per agent (its closed neighbourhood), all solved in one batched dispatch.
+
+    Returns X_dec (N+1, n_x), U_dec (N, n_u), J_full, solve_info {id: (seconds, neighbourhood)}.
+    `pool` is accepted for signature compatibility; the device batch takes its place.  `ignore_ids=None`
+    means "ignore nobody" (the reference raises TypeError there, quirk Q9)."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64)); U = np.asarray(U, dtype=np.float64)
+    x_dims, u_dims = problem.game_cost.x_dims, problem.game_cost.u_dims
+    N, n_s, n_c, ids = U.shape[0], x_dims[0], u_dims[0], problem.ids
+    ignore_ids = list(ignore_ids) if ignore_ids else []
+    if any(id_ not in ids for id_ in ignore_ids):
+        raise ValueError(f"Some of {ignore_ids} not in {ids}.")
+    graph = define_inter_graph_threshold(X, radius, x_dims, ids)
+    if verbose:
+        print("=" * 80 + f"\nInteraction Graph: {graph}")
+    x0_split = split_graph(X[np.newaxis, 0], x_dims, graph)
+    U_split = split_graph(U, u_dims, graph)
+    subproblems = problem.split(graph)
+    todo = [i for i, id_ in enumerate(ids) if id_ not in ignore_ids]
+    t0 = pc()
+    res = solve_problem_list([subproblems[i] for i in todo], [x0_split[i] for i in todo], [U_split[i] for i in todo],
+                             keys=[tuple(graph[ids[i]]) for i in todo], **kwargs)
+    dt_each = (pc() - t0) / max(len(todo), 1)
+    X_dec = np.zeros((N + 1, len(ids) * n_s)); U_dec = np.zeros((N, len(ids) * n_c))
+    solve_info = {}
+    for i, (Xi, Ui, _, _) in zip(todo, res):
+        Xa, Ua = subproblems[i].extract(Xi, Ui, ids[i])
+        X_dec[:, i * n_s:(i + 1) * n_s] = Xa
+        U_dec[:, i * n_c:(i + 1) * n_c] = Ua
+        solve_info[ids[i]] = (dt_each, graph[ids[i]])
+    for id_ in ignore_ids:
+        solve_info[id_] = (0.0, [id_])
+    _, J_full = ilqrSolver(problem, N)._rollout(X[0], U_dec)
+    return X_dec, U_dec, J_full, solve_info
+
+
+def solve_centralized(solver, xi, U, ids, verbose, **kwargs):
+    t0 = pc()
+    X, U, J = solver.solve(xi, U, verbose=verbose, **kwargs)
+    dt = pc() - t0
+    return X, U, J, {id_: (dt, ids) for id_ in ids}
+
+
+def solve_rhc(problem, x0, N, *args, centralized=True, n_d=2, step_size=1, J_converge=None, dist_converge=None,
+              t_diverge=None, i_trial=None, verbose=False, **kwargs):
+    """Receding-horizon loop around solve_centralized / solve_distributed (distributed.py:106-221); logs the
+    same CSV rows through `logging.info`.  The warm start is drawn from NumPy's global RNG as in the reference."""
+    if (J_converge is None) == (dist_converge is None):
+        raise ValueError("Must either specify a convergence cost or distance")
+    xf = problem.game_cost.xf
+    n_states, n_agents = problem.dynamics.x_dims[0], problem.n_agents
+    n_x, n_u = problem.dynamics.n_x, problem.dynamics.n_u
+
+    def distance_to_goal(x):
+        return np.linalg.norm((x - xf).reshape(n_agents, n_states)[:, :n_d], axis=1)
+
+    if J_converge:
+        keep_going = lambda x, J: J >= J_converge
+    else:
+        keep_going = lambda x, J: bool(np.any(distance_to_goal(x) > dist_converge))
+    model_name = type(problem.dynamics.submodels[0]).__name__
+    xi = np.asarray(x0, dtype=np.float64).reshape(1, -1)
+    X = xi.copy()
+    U = np.random.rand(N, n_u) * 0.01
+    solver = ilqrSolver(problem, N)
+    t, J, converged, dt, ids = 0, np.inf, True, problem.dynamics.dt, list(problem.ids)
+    X_full = np.zeros((0, n_x)); U_full = np.zeros((0, n_u))
+    times, subgraphs, left = [], [], distance_to_goal(xi.ravel()).tolist()
+    while keep_going(xi.ravel(), J):
+        if centralized:
+            X, U, J, info = solve_centralized(solver, xi, U, ids, False, **kwargs)
+        else:
+            X, U, J, info = solve_distributed(problem, X, U, *args, verbose=False, **kwargs)
+        xi = X[step_size]
+        X_full = np.r_[X_full, X[:step_size]]; U_full = np.r_[U_full, U[:step_size]]
+        X = np.r_[X[step_size:], np.tile(X[-1], (step_size, 1))]     # stay at the last visited state
+        U = np.r_[U[step_size:], np.zeros((step_size, n_u))]
+        times = [v[0] for v in info.values()]; subgraphs = [v[1] for v in info.values()]
+        left = distance_to_goal(xi).tolist()
+        logging.info(f'"{model_name}",{n_agents},{i_trial},{centralized},{False},{t},{J},{N},{dt},{converged},"{ids}",'
+                     f'"{times}","{subgraphs}","{left}"')
+        if t_diverge and t >= t_diverge:
+            converged = False
+            break
+        t += step_size * dt
+    if not X_full.size and not U_full.size:
+        X_full = np.asarray(x0, dtype=np.float64).copy(); U_full = np.zeros((1, n_u))
+    _, J_full = ilqrSolver(problem, U_full.shape[0])._rollout(np.asarray(x0, dtype=np.float64), U_full)
+    logging.info(f'"{model_name}",{n_agents},{i_trial},{centralized},{True},{U_full.shape[0] * dt},{J_full},{N},{dt},'
+                 f'{converged},"{ids}","{times}","{subgraphs}","{left}"')
+    return X_full, U_full, J_full

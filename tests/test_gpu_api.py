@@ -1,0 +1,179 @@
+"""GPU tests of the reference-style surface: the same objects and calls a dp-ilqr user writes
+(ilqrProblem / ilqrSolver / solve_distributed / plugin methods), checked against the golden vectors."""
+import numpy as np
+import pytest
+
+from tests.golden_util import MODEL_NAMES, relerr
+from tests.test_host_logic import MODEL_CLASSES, problem_from
+
+pytestmark = pytest.mark.gpu
+TOL_PASS, TOL_SOLVE = 1e-9, 1e-5
+
+
+@pytest.fixture(scope="module")
+def dp():
+    import dpilqr_amd
+    from dpilqr_amd import _lib
+    _lib.require_gpu()
+    return dpilqr_amd
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_plugin_models(dp, golden, name):
+    """Model(dt)(x,u), .f, .linearize and the module-level FFI functions vs bbdynamicswrap (G1)."""
+    z = golden("g1_models"); enum_val = int(z[f"{name}_enum"])
+    for i in range(4):
+        x, u, dt = z[f"{name}_x"][i], z[f"{name}_u"][i], float(z[f"{name}_dt"][i])
+        m = MODEL_CLASSES[enum_val](dt, 100)
+        assert relerr(m(x, u), z[f"{name}_xn"][i]) < 1e-12 and relerr(m.f(x, u), z[f"{name}_f"][i]) < 1e-13
+        A, B = m.linearize(x, u)
+        assert relerr(A, z[f"{name}_A"][i]) < 1e-13 and relerr(B, z[f"{name}_B"][i]) < 1e-13
+        assert relerr(dp.integrate(x, u, dt, dp.Model(enum_val)), z[f"{name}_xn"][i]) < 1e-12
+    with pytest.raises(ValueError):
+        dp.integrate(np.zeros(4), np.zeros(2), 0.1, 0)        # not a Model member (pyx:52-54)
+
+
+def test_plugin_costs(dp, golden):
+    z = golden("g2_costs")
+    rc = dp.ReferenceCost(z["ref_xf"], z["ref_Q"], z["ref_R"], z["ref_Qf"], 100)
+    for term, tag in ((False, "S"), (True, "T")):
+        for i in range(2):
+            assert abs(rc(z["ref_x"][i], z["ref_u"][i], term) - z[f"ref_cost_{tag}"][i]) < 1e-11
+            q = rc.quadraticize(z["ref_x"][i], z["ref_u"][i], term)
+            for got, nm in zip(q, ["Lx", "Lu", "Lxx", "Luu", "Lux"]):
+                assert np.allclose(got, z[f"ref_{nm}_{tag}"][i], rtol=0, atol=1e-11), (nm, tag)
+    # the reference's own (passing) ReferenceCost tests: tests/test_cost.py:52-78
+    rc2 = dp.ReferenceCost(np.zeros(3), np.eye(3), np.eye(2), np.diag([1.0, 1, 0]), 101)
+    x, u = z["reftest_x"], z["reftest_u"]
+    assert abs(rc2(x, u) - (np.sum(x ** 2) + np.sum(u ** 2))) < 1e-12 and abs(rc2(x, u, terminal=True) - np.sum(x[:-1] ** 2)) < 1e-12
+    for tag, ns in (("p2", 4), ("p3", 6), ("pm", 6)):
+        pc = dp.ProximityCost([ns] * 3, 0.5, [int(v) for v in z[f"{tag}_ndims"]])
+        for i in range(2):
+            assert abs(pc(z[f"{tag}_x"][i]) - z[f"{tag}_cost"][i]) < 1e-13
+            Lx, Lxx = pc.quadraticize(z[f"{tag}_x"][i])
+            assert np.allclose(Lx, z[f"{tag}_Lx"][i], rtol=1e-11, atol=1e-12) and np.allclose(Lxx, z[f"{tag}_Lxx"][i], rtol=1e-11, atol=1e-11)
+    for i in range(6):
+        g, H = dp.quadraticize_distance(dp.Point(*z["qd_pa"][i, :z["qd_nd"][i]]), dp.Point(*z["qd_pb"][i, :z["qd_nd"][i]]),
+                                        float(z["qd_radius"]), int(z["qd_nd"][i]))
+        nd = int(z["qd_nd"][i])
+        assert np.allclose(g, z["qd_Lx"][i, :nd], rtol=1e-12, atol=1e-13) and np.allclose(H, z["qd_Lxx"][i, :nd, :nd], rtol=1e-12, atol=1e-12)
+    assert dp.ProximityCost([4], 0.5, [2])(np.zeros(4)) == 0.0
+    k = 3
+    refs = [dp.ReferenceCost(z["gc3_xf"][i * 4:(i + 1) * 4], np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 100 + i)
+            for i in range(k)]
+    gc = dp.GameCost(refs, dp.ProximityCost([4] * k, 0.5, [2] * k))
+    assert abs(gc(z["gc3_x"][0], z["gc3_u"][0]) - z["gc3_cost_S"][0]) < 1e-10 * abs(z["gc3_cost_S"][0])
+    q = gc.quadraticize(z["gc3_x"][0], z["gc3_u"][0], terminal=True)
+    assert np.allclose(q[0], z["gc3_Lx_T"][0], rtol=1e-12, atol=1e-10) and np.allclose(q[2], z["gc3_Lxx_T"][0], rtol=1e-12, atol=1e-10)
+    assert not q[1].any() and not q[3].any()
+
+
+@pytest.mark.parametrize("case", ["cfg1_di4d_k3", "quad6d_k3", "mixed_q6h6"])
+def test_solver_passes(dp, golden, case):
+    """ilqrSolver._rollout / _backward_pass / _forward_pass as the reference's callers use them (G3)."""
+    z = golden(f"g3_passes_{case}")
+    s = dp.ilqrSolver(problem_from(z), int(z["T"]))
+    X, J = s._rollout(z["x0"].reshape(-1, 1), z["U0"])
+    assert relerr(X, z["X_roll"]) < TOL_PASS and abs(J - z["J_roll"]) < TOL_PASS * abs(z["J_roll"])
+    s.μ = float(z["mu"])
+    K, d = s._backward_pass(z["X"], z["U"])
+    assert relerr(K, z["K"]) < TOL_PASS and relerr(d, z["d"]) < TOL_PASS
+    Xn, Un, Jn = s._forward_pass(z["X"], z["U"], z["K"], z["d"], np.float32(z["alphas"][2]))
+    assert relerr(Xn, z["X_fwd"][2]) < TOL_PASS and relerr(Un, z["U_fwd"][2]) < TOL_PASS and abs(Jn - z["J_fwd"][2]) < TOL_PASS * abs(Jn)
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "quad_k3", "mixed", "di_k1"])
+def test_solver_solve(dp, golden, tag, capsys):
+    z = golden("g4_solves_misc")
+    s = dp.ilqrSolver(problem_from(z, tag + "_"), int(z[tag + "_T"]))
+    X, U, J = s.solve(z[tag + "_x0"].reshape(1, -1), z[tag + "_U0"], verbose=(tag == "cfg1"))
+    assert relerr(X, z[tag + "_X"]) < TOL_SOLVE and relerr(U, z[tag + "_U"]) < TOL_SOLVE and abs(J - z[tag + "_J"]) < TOL_SOLVE * abs(J)
+    assert s.n_bwd == len(z[tag + "_mu_trace"]) and s.on_device
+    n_acc = int((z[tag + "_acc_trace"] >= 0).sum())
+    ref = dp.ilqrSolver(s.problem, s.N)
+    for _ in range(n_acc):
+        ref._decrease_regularization()
+    assert s.μ == ref.μ and s.Δ == ref.Δ           # solver object left in the reference's final state
+    with pytest.raises(ValueError):
+        s.solve(z[tag + "_x0"], np.zeros((3, 3)))  # wrong U shape (control.py:154-155)
+
+
+def test_host_plugin_path_matches_device_path(dp, golden):
+    """A user's DynamicalModel / Cost subclasses with HOST code: the solver calls them and feeds the GPU sweep
+    with their tiles; result must equal the all-device solve of the same mathematical problem."""
+    z = golden("g4_solves_misc"); tag = "uni_k3"
+    prob = problem_from(z, tag + "_")
+
+    class HostUnicycle(dp.DynamicalModel):          # the unicycle restated as a plain NumPy plugin
+        def __init__(self, dt, id):
+            super().__init__(4, 2, dt, id)
+
+        def f(self, x, u):
+            return np.array([x[2] * np.cos(x[3]), x[2] * np.sin(x[3]), u[0], u[1]])
+
+        def __call__(self, x, u):                   # RK4 with 5 sub-steps, like the reference's C++ integrator
+            h = self.dt / 5
+            x = np.array(x, dtype=float)
+            for _ in range(5):
+                k0 = self.f(x, u); k1 = self.f(x + h / 2 * k0, u); k2 = self.f(x + h / 2 * k1, u); k3 = self.f(x + h * k2, u)
+                x = x + h * (k0 + 2 * k1 + 2 * k2 + k3) / 6.0
+            return x
+
+        def linearize(self, x, u):
+            A = np.eye(4); B = np.zeros((4, 2))
+            A[0, 2] = self.dt * np.cos(x[3]); A[0, 3] = -self.dt * x[2] * np.sin(x[3])
+            A[1, 2] = self.dt * np.sin(x[3]); A[1, 3] = self.dt * x[2] * np.cos(x[3])
+            B[2, 0] = B[3, 1] = self.dt
+            return A, B
+
+    ids = prob.ids
+    host_dyn = dp.MultiDynamicalModel([HostUnicycle(0.1, id_) for id_ in ids])
+    host_prob = dp.ilqrProblem(host_dyn, prob.game_cost)
+    hs = dp.ilqrSolver(host_prob, int(z[tag + "_T"]))
+    assert not hs.on_device
+    Xh, Uh, Jh = hs.solve(z[tag + "_x0"], z[tag + "_U0"], verbose=False)
+    assert relerr(Xh, z[tag + "_X"]) < TOL_SOLVE and relerr(Uh, z[tag + "_U"]) < TOL_SOLVE and abs(Jh - z[tag + "_J"]) < TOL_SOLVE * abs(Jh)
+
+
+@pytest.mark.parametrize("tag", ["uni5", "uni8", "quad10"])
+def test_solve_distributed(dp, golden, tag):
+    """solve_distributed(problem, X, U, radius, ignore_ids) vs the reference (G5), incl. the second,
+    trajectory-seeded call of the receding-horizon pattern."""
+    z = golden("g5_dispatch")
+    prob = problem_from(z, tag + "_")
+    Xd, Ud, Jf, info = dp.solve_distributed(prob, z[tag + "_x0"].reshape(1, -1), z[tag + "_U0"], 0.5, ignore_ids=[], verbose=False)
+    assert relerr(Xd, z[tag + "_X_dec"]) < TOL_SOLVE and relerr(Ud, z[tag + "_U_dec"]) < TOL_SOLVE
+    assert abs(Jf - z[tag + "_J_full"]) < TOL_SOLVE * abs(Jf) and set(info) == set(prob.ids)
+    if tag + "_X_dec2" in z:
+        Xd2, Ud2, Jf2, _ = dp.solve_distributed(prob, Xd, Ud, 0.5, ignore_ids=None, verbose=False)   # None tolerated (Q9)
+        assert relerr(Xd2, z[tag + "_X_dec2"]) < 1e-4 and abs(Jf2 - z[tag + "_J_full2"]) < 1e-4 * abs(Jf2)
+    ign = prob.ids[1]
+    Xi, Ui, _, info_i = dp.solve_distributed(prob, z[tag + "_x0"].reshape(1, -1), z[tag + "_U0"], 0.5, ignore_ids=[ign], verbose=False)
+    ns = prob.game_cost.x_dims[0]
+    assert not Xi[:, ns:2 * ns].any() and info_i[ign] == (0.0, [ign])           # ignored agent's columns stay zero
+    assert relerr(Xi[:, :ns], z[tag + "_X_dec"][:, :ns]) < TOL_SOLVE
+
+
+def test_device_graph_kernel(dp, golden):
+    z = golden("g5_dispatch")
+    for tag in ("uni5", "quad10", "uni8"):
+        k, ns = int(z[tag + "_k"]), int(z[tag + "_n_s"])
+        adj0 = dp.pairwise_graph(z[tag + "_x0"].reshape(1, 1, -1), 0.5, k, ns).cpu().numpy()[0]
+        adj1 = dp.pairwise_graph(z[tag + "_X_dec"][None], 0.5, k, ns).cpu().numpy()[0]
+        np.testing.assert_array_equal(adj0, z[tag + "_adj_x0"]); np.testing.assert_array_equal(adj1, z[tag + "_adj_traj"])
+
+
+def test_selfish_warmstart_and_rhc(dp, golden):
+    z = golden("g4_solves_misc"); tag = "cfg1"
+    prob = problem_from(z, tag + "_"); T = 20
+    Uw = prob.selfish_warmstart(z[tag + "_x0"], T)
+    ns, nc = 4, 2
+    for i, id_ in enumerate(prob.ids):          # each column block = that agent solving alone
+        single = prob.split({id_: [id_]})[0]
+        _, Ui, _ = dp.ilqrSolver(single, T).solve(z[tag + "_x0"][i * ns:(i + 1) * ns], verbose=False)
+        assert relerr(Uw[:, i * nc:(i + 1) * nc], Ui) < 1e-12
+    np.random.seed(0)
+    Xf, Uf, Jf = dp.solve_rhc(prob, z[tag + "_x0"], 15, centralized=True, step_size=5, dist_converge=0.5, t_diverge=3.0)
+    assert Xf.shape[1] == 12 and Uf.shape[0] == Xf.shape[0] and np.isfinite(Jf)
+    goal = z[tag + "_xf"].reshape(3, 4)[:, :2]; start = z[tag + "_x0"].reshape(3, 4)[:, :2]; end = Xf[-1].reshape(3, 4)[:, :2]
+    assert np.linalg.norm(end - goal) < np.linalg.norm(start - goal)
