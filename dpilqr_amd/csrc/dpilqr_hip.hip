@@ -138,10 +138,11 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
     if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
     const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
-    if ((m * n + threads - 1) / threads > kMaxStage)
+    if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
         return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
     // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp
-    const int ipb = (threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;
+    static const bool no_pack = getenv("DPILQR_FORWARD_NO_PACK") != nullptr;   // diagnostic switch
+    const int ipb = (!no_pack && threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;
     const size_t lds = lds_item * ipb;
     threads *= ipb;
     DISPATCH_FAMILY(D.n_s, {

@@ -78,7 +78,9 @@ struct TiledCfg {
     static constexpr int oK = oG + (NMP - N) * LG;
     static constexpr int oT3 = oK + M * LK;
     static constexpr int oTrash = oT3 + M * N;         // where masked-out stores go (never read)
-    static constexpr int total = round_up(oTrash + M * LK, 2);   // trash: a whole masked-out [K | d] column write
+    // trash must hold the widest masked-out store pattern: a [K | d] column (M rows of LK) or an S6 column (RB rows of LP)
+    static constexpr int trash_len = (M * LK > RB * LP ? M * LK : RB * LP) + 2;
+    static constexpr int total = round_up(oTrash + trash_len, 2);
     static constexpr bool supported = (N % 2 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 64 * 1024);
     // per-lane prefetch of [A|B]: 16-byte pairs, round-robin over the wave
     static constexpr int AB_PAIRS = N * NM / 2;
@@ -236,20 +238,21 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
     const int s5 = lane < S5_BLOCKS ? lane : S5_BLOCKS - 1;
     const int s5_i0 = (s5 / S5_CB) * RB, s5_j0 = (s5 % S5_CB) * 2;
     // S6 per element: P'[i][j] = wa*V[i][j] + wb*V[j][i]  with (wa,wb) = (1/2,1/2) for j < n, (1,0) for the p column
-    double* s6_dst[2];          // &sP[i0][j] (or trash for the pad column); sPt sits at a constant offset
+    double* s6_dst[2];          // &sP[i0][j]  (trash for the pad column)
+    double* s6_dstt[2];         // &sPt[i0][j] (trash for the pad column)
     const double* s6_vt[2];     // &V[j][i0]  (transposed operand; any finite address when unused)
     double s6_wa[2], s6_wb[2], s6_mu[RB][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int j = s5_j0 + c;
         s6_dst[c] = (j <= N) ? sP + s5_i0 * LP + j : sTrash;
+        s6_dstt[c] = (j <= N) ? sPt + s5_i0 * LP + j : sTrash;
         s6_vt[c] = (j < N) ? sQ + j * LQ + s5_i0 : sQ;
         s6_wa[c] = (j < N) ? 0.5 : 1.0;
         s6_wb[c] = (j < N) ? 0.5 : 0.0;
 #pragma unroll
         for (int r = 0; r < RB; ++r) s6_mu[r][c] = (s5_i0 + r == j) ? mu : 0.0;
     }
-    constexpr int PT_OFF = C::oPt - C::oP;
     // S3 epilogue: where this lane's column of -X goes in [K | d], and the coalesced copy-out pattern
     double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sTrash;
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
                     s6_dst[c][r * LP] = pn[r][c];
-                    s6_dst[c][r * LP + PT_OFF] = pn[r][c] + s6_mu[r][c];
+                    s6_dstt[c][r * LP] = pn[r][c] + s6_mu[r][c];
                 }
         }
         DPILQR_LDS_FENCE();

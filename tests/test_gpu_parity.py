@@ -204,3 +204,24 @@ def test_window_invariance(dp):
             assert (full[key] == part[key]).all().item(), (w, key)
     g = pb.solve(x0, U0, gains=True, window=50)      # gains requested: K, d indexed by item
     assert (g["X"] == full["X"]).all().item()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 8])
+def test_sweep_multi_item_all_sizes(dp, k):
+    """Every instantiated sweep size (and the generic kernel beyond them) on a 9-item batch with per-item mu:
+    each wavefront of a packed workgroup must produce its own item's gains (regression: a masked store pattern
+    once spilled past a wave's LDS slice into its neighbour's)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(k)
+    B, T = 9, 12
+    xf = rng.normal(size=(B, 4 * k)); x0 = rng.normal(size=(B, 4 * k)); U = rng.normal(size=(B, T, 2 * k)) * 0.1
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    pb = dp.ProblemBatch([3] * k, [2] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, _ = pb.rollout(x0, U)
+    mu = rng.uniform(0, 1, size=B)
+    from dpilqr_amd.device import to_dev
+    K, d = pb.backward_pass(X, U, to_dev(mu))
+    for i in range(B):
+        p = orc.Problem([3] * k, [2] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
