@@ -148,8 +148,8 @@ def main():
         achieved = ric_bytes / (ric["ms"] * 1e-3) / 1e9 if ric["ms"] > 0 else 0.0
         traffic = None
         tf = ROOT / "profiles" / "riccati_traffic.json"   # PMC pass (rocprofv3 --pmc), see profiles/README.md
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        if tf.exists() and ric["launches"]:   # measured HBM bytes per sub-problem pass x the items of an average launch
+            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_subproblem_pass") * ric["items"] / ric["launches"]
         nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy(); st = r["status"].cpu().numpy()
         out = {
             "metric": "ilqr_subproblems_per_sec", "value": value, "unit": "subproblems/s", "n_gpus": world,
@@ -165,6 +165,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_riccati_tiled<20,10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
+                         "algorithmic_bytes_per_launch": ric_bytes / max(ric["launches"], 1),
                          "launches": ric["launches"], "subproblem_passes": ric["items"],
                          "avg_launch_ms": ric["ms"] / max(ric["launches"], 1)},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
