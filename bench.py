@@ -7,9 +7,9 @@ scripts/analysis.py:45-69,140-143 (seed s: np.random.seed(s); random_setup(5,4,r
 energy=10); Q=diag(1,1,0,0), R=I, Qf=1000 I, radius 0.5, dt 0.1, U0=0, tol 1e-3, n_lqr_iter 50).
 One "step" = one complete ilqrSolver.solve of every sub-problem of one such batch (device resident:
 x0/xf/U0 of all K steps are in HBM before the clock starts).  The K batches (K x 1024 different seeds per
-GPU) are handed to the solver together, the way a Monte-Carlo driver would, and it keeps a WINDOW of 1024
+GPU) are handed to the solver together, the way a Monte-Carlo driver would, and it keeps a WINDOW of 2048
 sub-problems in flight: sub-problems need 1..25 iLQR iterations, so finished ones are retired on the device
-and replaced by not-yet-started ones, and every launch of the hot kernels works on ~1024 sub-problems.  All
+and replaced by not-yet-started ones, and every launch of the hot kernels works on ~2048 sub-problems (two sweep wavefronts per SIMD).  All
 K x 1024 solves complete inside the timed region.  For N>1 the region also contains the path's one
 collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) of all ranks.
 
@@ -76,8 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
+    ap.add_argument("--window", type=int, default=2048, help="sub-problems in flight per GPU (2048 = two sweep waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
 
     import torch
@@ -112,7 +113,7 @@ def main():
 
     def run(j):
         pb, x0, U0 = j[0], j[1], j[2]
-        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3, window=B)
+        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3, window=args.window)
         if world > 1:
             r = gather_results(r)                            # the one collective of the path
         return r
@@ -157,8 +158,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cfg2: batches of {B} independent 5-agent DoubleIntDynamics4D iLQR sub-problems per GPU "
                                    "per step, T=50, scripts/analysis.py scenario distribution, tol=1e-3, n_lqr_iter=50; "
-                                   f"{args.steps} steps = {args.steps * B} distinct seeds per GPU, window of {B} in flight",
-                       "batch_per_gpu": B, "window": B, "n_x": N_X, "n_u": N_U, "horizon": T,
+                                   f"{args.steps} steps = {args.steps * B} distinct seeds per GPU, window of {args.window} in flight",
+                       "batch_per_gpu": B, "window": args.window, "n_x": N_X, "n_u": N_U, "horizon": T,
                        "mean_backward_passes": float(nb.mean()), "mean_forward_passes": float(nf.mean()),
                        "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather" if world > 1 else "single GPU"},
@@ -171,7 +172,7 @@ def main():
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], _ = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, B))
+            out["cpu_baseline"], _ = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, x0_h.shape[0]))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

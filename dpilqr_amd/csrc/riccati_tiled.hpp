@@ -68,45 +68,52 @@ struct TiledCfg {
     static constexpr int LQ = NP;
     static constexpr int LK = NP;
     static constexpr int LG = round_up(M + N + 2, 4); // [Q_uu | Q_ux | Q_u | pad]
-    // LDS carve (doubles)
+    // LDS carve (doubles).  Lifetimes within a step: sAB S0-S2, sT S1-S2, sQ S1-S6, sG S1-S5, sK S3-S6,
+    // sT3 S4-S5, sP S6-S1(next).  sK and sT3 are therefore carved out of sT's space (dead after S2), which brings a
+    // wave's slice to ~20 KB so that EIGHT waves (two per SIMD) fit in the CU's 160 KiB.
     static constexpr int oAB = 0;
-    static constexpr int oP = oAB + N * LAB;
-    static constexpr int oPt = oP + N * LP;
-    static constexpr int oT = oPt + N * LP;            // T^T: LP rows (rows >= N are write-only dummies)
-    static constexpr int oQ = oT + LP * LAB;
-    static constexpr int oG = oQ + N * LQ;             // NMP-N rows (rows >= M are write-only dummies)
-    static constexpr int oK = oG + (NMP - N) * LG;
-    static constexpr int oT3 = oK + M * LK;
-    static constexpr int oTrash = oT3 + M * N;         // where masked-out stores go (never read)
-    // trash must hold the widest masked-out store pattern: a [K | d] column (M rows of LK) or an S6 column (RB rows of LP)
-    static constexpr int trash_len = (M * LK > RB * LP ? M * LK : RB * LP) + 2;
-    static constexpr int total = round_up(oTrash + trash_len, 2);
+    static constexpr int oT = oAB + N * LAB;             // T^T: N rows (columns of the pad block go to sTrash)
+    static constexpr int oK = oT;                        // [K | d | pad]  M x LK   (inside sT, after S2)
+    static constexpr int oT3 = oK + M * LK;              // T3^T           M x N    (inside sT, after S2)
+    static_assert(M * LK + M * N <= N * LAB, "sK + sT3 must fit inside sT");
+    static constexpr int oP = oT + N * LAB;
+    static constexpr int oQ = oP + N * LP;
+    static constexpr int oG = oQ + N * LQ;               // M rows
+    static constexpr int oTrash = oG + M * LG;           // 2 doubles: where masked-out 16-byte stores go
+    static constexpr int total = round_up(oTrash + 2, 2);
     static constexpr bool supported = (N % 2 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 64 * 1024);
+    // masked-out column writes borrow dead buffers: S3's [K|d] columns -> sT3, S6's pad column -> the sT space
+    static_assert((M - 1) * LK < M * N && (RB - 1) * LP < N * LAB, "borrowed trash regions too small");
     // per-lane prefetch of [A|B]: 16-byte pairs, round-robin over the wave
     static constexpr int AB_PAIRS = N * NM / 2;
     static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
 };
 
 // acc[r][c] += sum_l X[l*LDX + r] * Y[l*LDY + c]   (X, Y already offset to the block's first row/col)
-// Software-pipelined by hand: the operands of reduction step l+1 are requested before the FMAs of
-// step l issue, and a scheduling barrier per step keeps the compiler from hoisting every ds_read of
-// the (fully unrolled) loop to the top, which would blow the 256-VGPR budget into AGPR copies.
-template <int RBK, int CBK, int L, int LDX, int LDY>
+// Software-pipelined by hand, DEPTH reduction steps deep: the operands of step l+DEPTH-1 are requested before
+// the FMAs of step l issue (a ds_read_b128 takes ~130-200 cycles to return with four waves on the CU, one
+// step's 16 FMAs only 64), and a scheduling barrier per step keeps the compiler from hoisting every ds_read of
+// the fully unrolled loop to the top, which would blow the 256-VGPR budget into AGPR copies.
+template <int RBK, int CBK, int L, int LDX, int LDY, int DEPTH = 2>
 __device__ __forceinline__ void block_product(const double* __restrict__ X, const double* __restrict__ Y,
                                               double (&acc)[RBK][CBK]) {
-    v2d xa[2][RBK / 2], yb[2][CBK / 2];
+    constexpr int D = DEPTH < L ? DEPTH : L;
+    v2d xa[D][RBK / 2], yb[D][CBK / 2];
 #pragma unroll
-    for (int r = 0; r < RBK / 2; ++r) xa[0][r] = *reinterpret_cast<const v2d*>(X + 2 * r);
+    for (int p = 0; p < D - 1; ++p) {
 #pragma unroll
-    for (int c = 0; c < CBK / 2; ++c) yb[0][c] = *reinterpret_cast<const v2d*>(Y + 2 * c);
+        for (int r = 0; r < RBK / 2; ++r) xa[p][r] = *reinterpret_cast<const v2d*>(X + p * LDX + 2 * r);
+#pragma unroll
+        for (int c = 0; c < CBK / 2; ++c) yb[p][c] = *reinterpret_cast<const v2d*>(Y + p * LDY + 2 * c);
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        const int cur = l & 1, nxt = cur ^ 1;
-        if (l + 1 < L) {
+        const int cur = l % D, nxt = (l + D - 1) % D;
+        if (l + D - 1 < L) {
 #pragma unroll
-            for (int r = 0; r < RBK / 2; ++r) xa[nxt][r] = *reinterpret_cast<const v2d*>(X + (l + 1) * LDX + 2 * r);
+            for (int r = 0; r < RBK / 2; ++r) xa[nxt][r] = *reinterpret_cast<const v2d*>(X + (l + D - 1) * LDX + 2 * r);
 #pragma unroll
-            for (int c = 0; c < CBK / 2; ++c) yb[nxt][c] = *reinterpret_cast<const v2d*>(Y + (l + 1) * LDY + 2 * c);
+            for (int c = 0; c < CBK / 2; ++c) yb[nxt][c] = *reinterpret_cast<const v2d*>(Y + (l + D - 1) * LDY + 2 * c);
         }
 #pragma unroll
         for (int r = 0; r < RBK; ++r)
@@ -150,7 +157,6 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
     double* lds = lds_all + wave * C::total;
     double* sAB = lds + C::oAB;
     double* sP = lds + C::oP;
-    double* sPt = lds + C::oPt;
     double* sT = lds + C::oT;
     double* sQ = lds + C::oQ;
     double* sG = lds + C::oG;
@@ -172,15 +178,9 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
         const double* rec = base + (int64_t)T * L.stride;
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N;
-            const double v = rec[L.oLxx + e];
-            sP[i * LP + j] = v;
-            sPt[i * LP + j] = (i == j) ? v + mu : v;
+            sP[i * LP + j] = rec[L.oLxx + e];
         }
-        for (int i = lane; i < N; i += 64) {
-            const double v = rec[L.oLx + i];
-            sP[i * LP + N] = v;
-            sPt[i * LP + N] = v;
-        }
+        for (int i = lane; i < N; i += 64) sP[i * LP + N] = rec[L.oLx + i];
     }
 
     // ---- per-lane block coordinates and addresses, constant over the horizon.  The time loop below is
@@ -192,8 +192,23 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
     const int s1 = lane < S1_BLOCKS ? lane : S1_BLOCKS - 1;
     const int s1_i0 = (s1 / S1_CB) * RB, s1_j0 = (s1 % S1_CB) * CB;
     const double* s1_x = sAB + s1_i0;
-    const double* s1_y = ((s1_i0 < N) ? sP : sPt) + s1_j0;          // B rows see P + mu I (quirk Q6)
-    double* s1_t = sT + s1_j0 * LAB + s1_i0;                         // T^T[j0 + c][i0 + r]
+    const double* s1_y = sP + s1_j0;
+    // T^T[j0 + c][i0 + r].  The pad block (j0 == n: the p column and padding) has no rows in sT: its lanes
+    // collapse every store of this group onto the 16-byte trash slot (offsets multiplied by s1_keep = 0).
+    const int s1_keep = (s1_j0 < N) ? 1 : 0;
+    double* s1_t = s1_keep ? sT + s1_j0 * LAB + s1_i0 : sTrash;
+    // mu enters only B's products (quirk Q6): B^T (P + mu I) = B^T P + mu B^T, added as a correction to the
+    // B rows of the stacked product: T2[a][j] += mu * B[j][a].  s1_mu[c] is mu for (B row block, real column j),
+    // else 0; s1_b[c] points at B[j][a0..] (any finite row when unused).
+    double s1_mu[CB];
+    const double* s1_b[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int j = s1_j0 + c;
+        const bool reg = (s1_i0 >= N) && (j < N);
+        s1_mu[c] = reg ? mu : 0.0;
+        s1_b[c] = sAB + (reg ? j : 0) * LAB + (reg ? s1_i0 : 0);
+    }
     double* s1_q[RB];                                                // Q_x / Q_u slots of the p column
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -238,23 +253,19 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
     const int s5 = lane < S5_BLOCKS ? lane : S5_BLOCKS - 1;
     const int s5_i0 = (s5 / S5_CB) * RB, s5_j0 = (s5 % S5_CB) * 2;
     // S6 per element: P'[i][j] = wa*V[i][j] + wb*V[j][i]  with (wa,wb) = (1/2,1/2) for j < n, (1,0) for the p column
-    double* s6_dst[2];          // &sP[i0][j]  (trash for the pad column)
-    double* s6_dstt[2];         // &sPt[i0][j] (trash for the pad column)
+    double* s6_dst[2];          // &sP[i0][j]; the pad column's writes land in the sT space, which is dead by S6
     const double* s6_vt[2];     // &V[j][i0]  (transposed operand; any finite address when unused)
-    double s6_wa[2], s6_wb[2], s6_mu[RB][2];
+    double s6_wa[2], s6_wb[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int j = s5_j0 + c;
-        s6_dst[c] = (j <= N) ? sP + s5_i0 * LP + j : sTrash;
-        s6_dstt[c] = (j <= N) ? sPt + s5_i0 * LP + j : sTrash;
+        s6_dst[c] = (j <= N) ? sP + s5_i0 * LP + j : sT;
         s6_vt[c] = (j < N) ? sQ + j * LQ + s5_i0 : sQ;
         s6_wa[c] = (j < N) ? 0.5 : 1.0;
         s6_wb[c] = (j < N) ? 0.5 : 0.0;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) s6_mu[r][c] = (s5_i0 + r == j) ? mu : 0.0;
     }
     // S3 epilogue: where this lane's column of -X goes in [K | d], and the coalesced copy-out pattern
-    double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sTrash;
+    double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sT3;   // sT3 is not live during S3
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
     int k_in[K_ROUNDS], k_out[K_ROUNDS];
 #pragma unroll
@@ -309,6 +320,12 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
     // is vmcnt(0) on every iteration; with nothing pending on entry the in-loop waits stay counted.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
+#ifdef DPILQR_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define PHASE_MARK(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define PHASE_MARK(i)
+#endif
     for (int t = T - 1; t >= 0; --t) {
         const int tn = t > 0 ? t - 1 : 0;   // record to prefetch (the last step re-reads record 0: harmless)
         // ---- S0: park [A|B] of record t in LDS
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
         for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
         DPILQR_LDS_FENCE();
         prefetch_ab(tn);
+        PHASE_MARK(0)
 
         // ---- S1: [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]
         {
@@ -326,10 +344,19 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
                 for (int c = 0; c < CB; ++c) acc[r][c] = 0.0;
             block_product<RB, CB, N, LAB, LP>(s1_x, s1_y, acc);
 #pragma unroll
-            for (int c = 0; c < CB; ++c)   // T^T[j][i']: the operand orientation S2 wants (rows >= n are dummies)
+            for (int c = 0; c < CB; ++c) {   // + mu B^T on the B rows, then T^T[j][i']: the orientation S2 wants
+#pragma unroll
+                for (int r = 0; r < RB; r += 2) {
+                    const v2d bt = *reinterpret_cast<const v2d*>(s1_b[c] + r);
+                    acc[r][c] = fma(s1_mu[c], bt.x, acc[r][c]);
+                    acc[r + 1][c] = fma(s1_mu[c], bt.y, acc[r + 1][c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int r = 0; r < RB; r += 2)
-                    *reinterpret_cast<v2d*>(s1_t + c * LAB + r) = v2d{acc[r][c], acc[r + 1][c]};
+                    *reinterpret_cast<v2d*>(s1_t + s1_keep * (c * LAB + r)) = v2d{acc[r][c], acc[r + 1][c]};
 #pragma unroll
             for (int r = 0; r < RB; ++r) {  // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
                 const double lv = (r & 1) ? nLxu[r / 2].y : nLxu[r / 2].x;
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
         }
         DPILQR_LDS_FENCE();
         prefetch_lxu(tn);
+        PHASE_MARK(1)
 
         // ---- S2: [T1;T2][A|B] -> Q_xx, Q_ux, Q_uu
         {
@@ -355,6 +383,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
         }
         DPILQR_LDS_FENCE();
         prefetch_l(tn);
+        PHASE_MARK(2)
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers
         {
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
             }
             // K = -X (lanes M..M+N-1 hold its columns), d = -x (lane M+N): into LDS as [K | d]
 #pragma unroll
-            for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];   // lanes outside the range write to sTrash
+            for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];   // lanes outside the range scribble on the dead sT3
         }
         DPILQR_LDS_FENCE();
         // stream K[t] (M x N, contiguous) and d[t] out with unconditional, coalesced stores: every lane
@@ -418,6 +447,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
             store_f64_nt(dt_ + d_idx, sK[d_idx * LK + N]);
         }
         DPILQR_LDS_FENCE();
+        PHASE_MARK(3)
 
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
         {
@@ -427,6 +457,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
             *reinterpret_cast<v2d*>(sT3 + (s4_c0 + 1) * N + s4_i0) = v2d{acc[1][0], acc[1][1]};
         }
         DPILQR_LDS_FENCE();
+        PHASE_MARK(4)
 
         // ---- S5: V = ((Q_xx + T3 K) + K^T Q_ux) + Q_ux^T K, with [K|d] and [Q_ux|Q_u] carrying the p update
         double vb[RB][2];
@@ -449,8 +480,9 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
                 *reinterpret_cast<v2d*>(sQ + (s5_i0 + r) * LQ + s5_j0) = v2d{vb[r][0], vb[r][1]};
         }
         DPILQR_LDS_FENCE();
+        PHASE_MARK(5)
 
-        // ---- S6: P <- (V + V^T)/2 (and its regularised copy) ; p <- V[:, n]
+        // ---- S6: P <- (V + V^T)/2 ; p <- V[:, n]
         {
             double pn[RB][2];
 #pragma unroll
@@ -461,12 +493,10 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    s6_dst[c][r * LP] = pn[r][c];
-                    s6_dstt[c][r * LP] = pn[r][c] + s6_mu[r][c];
-                }
+                for (int r = 0; r < RB; ++r) s6_dst[c][r * LP] = pn[r][c];
         }
         DPILQR_LDS_FENCE();
+        PHASE_MARK(6)
     }
     if (singular && sing && lane == 0) singular[b] = 1;
     if (stamps && lane == 0) {
@@ -477,6 +507,9 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
         stamps[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[4 * slot + 2] = hw_id;
         stamps[4 * slot + 3] = xcc_id;
+#ifdef DPILQR_PHASE_STAMPS
+        for (int i = 0; i < 7; ++i) stamps[4 * B + 8 * slot + i] = ph[i];
+#endif
     }
 }
 
