@@ -73,8 +73,8 @@ def cpu_baseline(x0, xf, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
     ap.add_argument("--window", type=int, default=2048, help="sub-problems in flight per GPU (2048 = two sweep waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

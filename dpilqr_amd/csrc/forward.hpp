@@ -257,7 +257,7 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
 // (n_alpha * k <= 64, e.g. cfg2's 50) four of them share a 256-thread workgroup, one wave each with its own
 // LDS slice and no workgroup barrier -- the same SIMD-placement argument as for the sweep (riccati_tiled.hpp).
 template <int NS, int NC>
-__global__ __launch_bounds__(256) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X,
+__global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X,
                                                   double* U, const double* __restrict__ K, const double* __restrict__ d,
                                                   const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc,
                                                   double* Jc, SolveState S, const int32_t* __restrict__ items,
