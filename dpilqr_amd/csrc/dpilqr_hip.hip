@@ -16,6 +16,7 @@
 #include "forward.hpp"
 #include "models.hpp"
 #include "riccati.hpp"
+#include "riccati_mfma.hpp"
 #include "riccati_tiled.hpp"
 #include "tiles.hpp"
 
@@ -109,8 +110,33 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
                        int gains_by_item, hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
-    static const bool force_generic = getenv("DPILQR_FORCE_GENERIC_RICCATI") != nullptr;
-    if (!force_generic) {
+    // sweep selection: matrix-pipe kernel where instantiated, else the vector-pipe tiled kernel, else the generic one
+    // (DPILQR_RICCATI=mfma|tiled|generic pins one for A/B measurements)
+    static const char* pick_env = getenv("DPILQR_RICCATI");
+    static const int pick = getenv("DPILQR_FORCE_GENERIC_RICCATI") ? 2
+                            : (!pick_env ? 0 : (!strcmp(pick_env, "tiled") ? 1 : (!strcmp(pick_env, "generic") ? 2 : 0)));
+    if (pick == 0) {
+#define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
+    if (n == NN && m == MM) {                                                                                      \
+        static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
+        static const int stagger = getenv("DPILQR_STAGGER") ? atoi(getenv("DPILQR_STAGGER")) : 100;                \
+        static const bool no8 = getenv("DPILQR_MFMA_WAVES4") != nullptr;                                           \
+        const bool w8 = !no8 && grid_items > 1024;   /* enough items for two waves per SIMD */                     \
+        const int wv = w8 ? 8 : 4;                                                                                 \
+        const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
+        int32_t rc_t = w8 ? allow_lds(k_riccati_mfma<NN, MM, 8>, lds_t) : allow_lds(k_riccati_mfma<NN, MM, 4>, lds_t); \
+        if (rc_t) return rc_t;                                                                                     \
+        if (w8) hipLaunchKernelGGL((k_riccati_mfma<NN, MM, 8>), dim3((grid_items + 7) / 8), dim3(512), lds_t, st, B, T, \
+                                   tiles, mu, K, d, singular, items, n_items, gains_by_item, stagger);             \
+        else hipLaunchKernelGGL((k_riccati_mfma<NN, MM, 4>), dim3((grid_items + 3) / 4), dim3(256), lds_t, st, B, T,    \
+                                tiles, mu, K, d, singular, items, n_items, gains_by_item, stagger);                \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+        DPILQR_TILED_SIZES(DPILQR_TRY_MFMA)
+#undef DPILQR_TRY_MFMA
+    }
+    if (pick <= 1) {
 #define DPILQR_TRY_TILED(NN, MM)                                                                                   \
     if (n == NN && m == MM) {                                                                                      \
         static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
@@ -372,7 +398,7 @@ int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t
     const TileLayout L(n_x, n_u);
     offsets[0] = L.oA; offsets[1] = L.oB; offsets[2] = L.oLxx; offsets[3] = L.oLux; offsets[4] = L.oLuu;
     offsets[5] = L.oLx; offsets[6] = L.oLu;
-    row_strides[0] = L.ldAB; row_strides[1] = L.ldAB; row_strides[2] = n_x; row_strides[3] = n_x; row_strides[4] = n_u;
+    row_strides[0] = L.ldAB; row_strides[1] = L.ldAB; row_strides[2] = n_x; row_strides[3] = L.ldUG; row_strides[4] = L.ldUG;
     row_strides[5] = 1; row_strides[6] = 1;
     *stride = L.stride;
     return DPILQR_OK;

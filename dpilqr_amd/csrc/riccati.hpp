@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
             const int a = e / n, j = e - a * n;
             double s = 0.0;
             for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sA[l * ld + j], s);
-            const double q = rec[L.oLux + e] + s;
+            const double q = rec[L.oLux + a * L.ldUG + j] + s;
             sQux[e] = q;
             sK[a * n1 + j] = q;
         }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, in
             const int a = e / m, c = e - a * m;
             double s = 0.0;
             for (int l = 0; l < n; ++l) s = fma(sT2[a * n + l], sB[l * ld + c], s);
-            const double q = rec[L.oLuu + e] + s;
+            const double q = rec[L.oLuu + a * L.ldUG + c] + s;
             sQuu[e] = q;
             sLU[e] = q;
         }

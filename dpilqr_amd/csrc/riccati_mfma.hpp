@@ -1,0 +1,457 @@
+// riccati_mfma.hpp -- K2 on the matrix pipe: the Riccati backward sweep with one wavefront per sub-problem
+// and every dense product issued as v_mfma_f64_16x16x4_f64 (ilqrSolver._backward_pass, control.py:116-148).
+//
+// Why MFMA for 20-wide matrices: measured on MI355X (scripts/ubench/mfma_f64.hip) the fp64 MFMA delivers the
+// SAME peak FMA rate as the vector ALU (64 cycles per 16x16x4 instruction per SIMD = 16 FMA/clk), so padding
+// 20 -> 32 costs arithmetic efficiency -- but the VALU sweep (riccati_tiled.hpp) is bound by instruction
+// ISSUE, not by arithmetic: 1226 FMA + 294 LDS-read instructions per step.  One MFMA replaces 16 vector FMAs
+// and their operand reads with a single issue slot and two 8-byte LDS reads, and the matrix pipe runs beside
+// the vector pipe, which is left with the pivoted LU solve.  Per step at cfg2: 70 MFMAs + 73 operand reads.
+//
+// Data flow, LDS residency, prefetching, the in-register pivoted LU and the four-waves-per-workgroup packing
+// are those of riccati_tiled.hpp; only the products differ.  Every product has the form
+//     C[i][j] = sum_l X[l][i] * Y[l][j]
+// with X, Y row-major in LDS (rows = reduction index), which is the MFMA operand order:
+//     lane (g = lane/16, c = lane%16) supplies A = X[l0+g][i0+c], B = Y[l0+g][j0+c]  (4 reduction rows per MFMA)
+//     and owns D[i0 + g + 4v][j0 + c], v = 0..3   (layout verified by the micro-benchmark).
+// So every LDS / HBM address of a D element is  (lane term) + (compile-time tile/v term): no address tables;
+// what a lane may store is decided by a few lane predicates (column in range) and compile-time row ranges.
+// Reduction lengths that are not multiples of 4 (n_u = 10 -> 12) read zero rows kept at the end of [K|d].
+// Reads past a row's logical width wrap into finite neighbouring data and only feed outputs that are dropped.
+//
+//   S1  [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (+ mu B^T on the B rows)          2x2 tiles x 5 k-steps
+//   S2  [T1;T2] [A|B] -> Q_xx, Q_ux, Q_uu                                          2x2 x 5
+//   S3  LU solve in registers (vector pipe)
+//   S4  T3^T = Q_uu-contracted K                                                   1x2 x 3
+//   S5  a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] (its transpose supplies Q_ux^T K and Q_ux^T d)   2 x (2x2 x 3)
+//   S6  P <- (V + V^T)/2
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "riccati_tiled.hpp"
+
+namespace dpilqr {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int N, int M>
+struct MfmaCfg {
+    static constexpr int NM = N + M;
+    static constexpr int NP = N + 1;                   // columns of [P|p], [K|d], [Q_ux|Q_u]
+    static constexpr int MK = round_up(M, 4);          // reduction length over controls, zero padded
+    static constexpr int LAB = round_up(NM, 2);        // [A|B] rows
+    static constexpr int LT = LAB;                     // T^T rows (index i' < NM)
+    static constexpr int LP = round_up(NP, 2);
+    static constexpr int LQ = LP;                      // [Q_xx | Q_x]
+    static constexpr int LG = round_up(M + NP, 2);     // [Q_uu | Q_ux | Q_u]
+    static constexpr int LK = LP;                      // [K | d]
+    static constexpr int LM = LP;                      // a2 = [K|d]^T [Q_ux|Q_u]  (NP x NP)
+    static constexpr int KROWS = MK + 2;               // [K|d] rows incl. zero rows (a 16-wide tile read may wrap a row)
+    static constexpr int T_NM = (NM + 15) / 16, T_NP = (NP + 15) / 16, T_N = (N + 15) / 16, T_M = (M + 15) / 16;
+    // LDS carve (doubles).  sK, sT3 live inside sT's space (dead after S2); a2 lives inside sAB's (dead after S2).
+    static constexpr int szAB = round_up(N * LAB > NP * LM ? N * LAB : NP * LM, 2);
+    static constexpr int szT = round_up(N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N, 2);
+    static constexpr int oAB = 0;
+    static constexpr int oT = oAB + szAB;
+    static constexpr int oK = oT;
+    static constexpr int oT3 = oK + KROWS * LK;
+    static constexpr int oP = oT + szT;
+    static constexpr int oQ = oP + N * LP;
+    static constexpr int oG = oQ + N * LQ;
+    static constexpr int oEnd = oG + MK * LG;          // sG has MK rows: rows >= M are never written (zero)
+    static constexpr int total = round_up(oEnd + 32, 2);   // slack for wrapped 16-wide reads of the last rows
+    static constexpr bool supported = (N % 4 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 40 * 1024);
+    static constexpr int AB_PAIRS = N * NM / 2;
+    static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
+};
+
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// acc[it][jt] += sum_{l < KLEN} X[l][16 it + c] * Y[l][16 jt + c']  for TI x TJ output tiles.
+// px / py point at X[g][c] / Y[g][c] of this lane (g = lane / 16, c = lane % 16).
+template <int TI, int TJ, int KLEN, int LDX, int LDY>
+__device__ __forceinline__ void mfma_product(const double* __restrict__ px, const double* __restrict__ py,
+                                             v4d (&acc)[TI][TJ]) {
+    static_assert(KLEN % 4 == 0, "reduction length must be padded to a multiple of 4");
+#pragma unroll
+    for (int ks = 0; ks < KLEN / 4; ++ks) {
+        double a[TI], b[TJ];
+#pragma unroll
+        for (int it = 0; it < TI; ++it) a[it] = px[ks * 4 * LDX + 16 * it];
+#pragma unroll
+        for (int jt = 0; jt < TJ; ++jt) b[jt] = py[ks * 4 * LDY + 16 * jt];
+#pragma unroll
+        for (int it = 0; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = mfma_f64(a[it], b[jt], acc[it][jt]);
+    }
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void zero_tiles(v4d (&acc)[TI][TJ]) {
+#pragma unroll
+    for (int it = 0; it < TI; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = v4d{0.0, 0.0, 0.0, 0.0};
+}
+
+// Visit the D elements of one tile (first row `row0`, a compile-time constant after unrolling) whose row
+// i = row0 + g + 4v lies in [lo, hi).  f(v, i - g - lo) gets the sub-row index and the lane-independent part of
+// (i - lo), so the caller's address is  lane_pointer[(i - g - lo) * LD]  with lane_pointer = buf + g*LD + column.
+// A 4-row group entirely inside / outside the range costs no lane test; only a straddling group compares g.
+template <typename F>
+__device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool col_ok, F&& f) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = row0 + 4 * v;           // rows r .. r+3 over g = 0..3
+        if (r + 3 < lo || r >= hi) continue;
+        const bool inside = (r >= lo) && (r + 3 < hi);
+        if (col_ok && (inside || (r + g >= lo && r + g < hi))) f(v, r - lo);
+    }
+}
+
+// WAVES = 4: one wave per SIMD (launches that cannot fill two).  WAVES = 8: a 512-thread workgroup owns the
+// whole CU, waves w and w+4 share a SIMD, and waves 4..7 start `stagger` x 64 cycles late: a sweep step
+// alternates a matrix-pipe half (S1, S2, S4, S5) with a vector-pipe half (the LU solve), so two waves that
+// run in lockstep contend for one pipe at a time, while two waves half a step apart keep both pipes busy.
+template <int N, int M, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
+    int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
+    double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ n_items, int gains_by_item, int stagger) {
+    using C = MfmaCfg<N, M>;
+    constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
+    constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
+    const int wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * WAVES + wave;
+    if (slot >= (n_items ? *n_items : B)) return;
+    const int b = items ? items[slot] : slot;
+    if (b >= B) return;
+    if (WAVES == 8 && wave >= 4) {   // wave-uniform
+        for (int s = 0; s < stagger; ++s) __builtin_amdgcn_s_sleep(1);
+    }
+    const int64_t gslot = gains_by_item ? b : slot;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c16 = lane & 15;
+    const TileLayout L(N, M);
+
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds = lds_all + wave * C::total;
+    double* sAB = lds + C::oAB;
+    double* sMt = sAB;                 // a2 (NP x NP), after S2
+    double* sT = lds + C::oT;
+    double* sK = lds + C::oK;          // [K | d], KROWS rows (rows >= M zero), after S2
+    double* sT3 = lds + C::oT3;        // T3^T, MK rows, after S2
+    double* sP = lds + C::oP;
+    double* sQ = lds + C::oQ;
+    double* sG = lds + C::oG;
+
+    const double mu = mu_arr[b];
+    const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
+    int sing = 0;
+    unsigned long long* const stamps = g_stamp_buf;
+    unsigned long long t_start = 0;
+    if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
+
+    for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
+    DPILQR_LDS_FENCE();
+    {
+        const double* rec = base + (int64_t)T * L.stride;
+        for (int e = lane; e < N * N; e += 64) {
+            const int i = e / N, j = e - i * N;
+            sP[i * LP + j] = rec[L.oLxx + e];
+        }
+        for (int i = lane; i < N; i += 64) sP[i * LP + N] = rec[L.oLx + i];
+    }
+
+    // ---- lane terms.  For column tile jt this lane's column is j = 16 jt + c16.
+    bool colN[T_NM], colP[T_NM], colNM[T_NM], colLE[T_NM];   // j < n ; j == n ; j < n+m ; j <= n
+    int colG[T_NM];                                          // column of [Q_uu | Q_ux | Q_u] (and of UG in the record) holding global column j
+#pragma unroll
+    for (int jt = 0; jt < T_NM; ++jt) {
+        const int j = 16 * jt + c16;
+        colN[jt] = j < N; colP[jt] = j == N; colNM[jt] = j < NM; colLE[jt] = j <= N;
+        colG[jt] = (j < N) ? M + j : j - N;
+    }
+    // operand pointers X[g][c16]
+    const double* pAB = sAB + g * LAB + c16;
+    const double* pP = sP + g * LP + c16;
+    const double* pT = sT + g * LT + c16;
+    const double* pGuu = sG + g * LG + c16;          // Q_uu columns
+    const double* pGux = sG + g * LG + M + c16;      // [Q_ux | Q_u] columns
+    const double* pK = sK + g * LK + c16;
+    const double* pT3 = sT3 + g * N + c16;
+    // D-element pointers: row-major "[i][j]" = buf + g*LD + c16 ; transposed "[j][i]" = buf + c16*LD + g
+    double* dTt = sT + c16 * LT + g;                 // T^T[j][i']
+    const double* dBt = sAB + c16 * LAB + g;         // B[j][a] sits at [A|B][j][i'] with i' = n + a
+    double* dQ = sQ + g * LQ + c16;                  // Q_xx / V [i][j]
+    const double* dQt = sQ + c16 * LQ + g;           // V[j][i]
+    double* dG = sG + g * LG;                        // + colG[jt]
+    double* dT3 = sT3 + g * N + c16;
+    double* dMt = sMt + g * LM + c16;                // a2[i][j]
+    const double* dMtT = sMt + c16 * LM + g;         // a2[j][i]
+    double* dP = sP + g * LP + c16;
+    // record offsets of this lane's l-values (row part g*ld + column part), see TileLayout
+    const int gLxx = L.oLxx + g * N + c16;           // + 16 jt + (row const) * N
+    const int gUG = L.oLuu + g * L.ldUG;             // + colG[jt] + (row const) * ldUG
+    const int gLxu = L.oLx + g;                      // [l_x ; l_u][i']
+    // [A|B] prefetch -> LDS, S3 epilogue patterns (as in riccati_tiled.hpp)
+    double* sTrash = lds + C::oEnd;
+    double* ab_dst[C::AB_ROUNDS];
+    int ab_src[C::AB_ROUNDS];
+#pragma unroll
+    for (int q = 0; q < C::AB_ROUNDS; ++q) {
+        const int e = 2 * (lane + 64 * q);
+        const int row = e / NM, col = e - row * NM;
+        ab_dst[q] = (e < N * NM) ? sAB + row * LAB + col : sTrash;
+        ab_src[q] = (e < N * NM) ? L.oA + e : 0;
+    }
+    double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sT3;   // sT3 is not live during S3
+    static_assert((M - 1) * LK < MK * N, "S3's masked columns must fit the dead T3 buffer");
+    constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
+    int k_in[K_ROUNDS], k_out[K_ROUNDS];
+#pragma unroll
+    for (int q = 0; q < K_ROUNDS; ++q) {
+        const int e2 = min(lane + 64 * q, K_PAIRS - 1), e = 2 * e2;
+        k_out[q] = e;
+        k_in[q] = (e / N) * LK + (e % N);
+    }
+    const int d_idx = min(lane, M - 1);
+
+    // ---- prefetch registers (one record ahead), re-filled right after they are consumed.  They mirror the D
+    // layout: nL[it][jt][v] is the l-value added to element (it, jt, v) of the S2 product.
+    v2d nAB[C::AB_ROUNDS];
+    double nL[T_NM][T_NM][4];
+    double nLxu[T_NM][4];
+    auto prefetch_ab = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
+#pragma unroll
+        for (int q = 0; q < C::AB_ROUNDS; ++q) nAB[q] = *reinterpret_cast<const v2d*>(rec + ab_src[q]);
+    };
+    auto prefetch_lxu = [&](int t) {   // only the lanes of the p column need it
+        const double* rec = base + (int64_t)t * L.stride + gLxu;
+#pragma unroll
+        for (int it = 0; it < T_NM; ++it) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nLxu[it][v] = 0.0;
+            for_rows(16 * it, 0, NM, g, colP[N / 16], [&](int v, int r) { nLxu[it][v] = rec[r]; });
+        }
+    };
+    auto prefetch_l = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
+#pragma unroll
+        for (int it = 0; it < T_NM; ++it)
+#pragma unroll
+            for (int jt = 0; jt < T_NM; ++jt) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) nL[it][jt][v] = 0.0;
+                for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { nL[it][jt][v] = rec[gLxx + 16 * jt + r * N]; });
+                for_rows(16 * it, N, NM, g, colNM[jt], [&](int v, int r) { nL[it][jt][v] = rec[gUG + colG[jt] + r * L.ldUG]; });
+            }
+    };
+    prefetch_ab(T - 1);
+    prefetch_lxu(T - 1);
+    prefetch_l(T - 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see riccati_tiled.hpp
+
+#ifdef DPILQR_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define MPHASE(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define MPHASE(i)
+#endif
+    for (int t = T - 1; t >= 0; --t) {
+        const int tn = t > 0 ? t - 1 : 0;
+        // ---- S0
+#pragma unroll
+        for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
+        DPILQR_LDS_FENCE();
+        prefetch_ab(tn);
+        MPHASE(0)
+
+        // ---- S1: [A|B]^T [P|p]
+        {
+            v4d acc[T_NM][T_NP];
+            zero_tiles(acc);
+            mfma_product<T_NM, T_NP, N, LAB, LP>(pAB, pP, acc);
+#pragma unroll
+            for (int it = 0; it < T_NM; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt) {
+                    // T1 rows: T^T[j][i'] = acc
+                    for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { dTt[16 * jt * LT + r] = acc[it][jt][v]; });
+                    // T2 rows: + mu B[j][a]   (quirk Q6: B^T (P + mu I) = B^T P + mu B^T)
+                    for_rows(16 * it, N, NM, g, colN[jt], [&](int v, int r) {
+                        dTt[16 * jt * LT + N + r] = fma(mu, dBt[16 * jt * LAB + N + r], acc[it][jt][v]);
+                    });
+                    // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+                    if (16 * jt <= N && N < 16 * jt + 16) {
+                        for_rows(16 * it, 0, N, g, colP[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = nLxu[it][v] + acc[it][jt][v]; });
+                        for_rows(16 * it, N, NM, g, colP[jt], [&](int v, int r) { dG[M + N + r * LG] = nLxu[it][v] + acc[it][jt][v]; });
+                    }
+                }
+        }
+        DPILQR_LDS_FENCE();
+        prefetch_lxu(tn);
+        MPHASE(1)
+
+        // ---- S2: [T1;T2][A|B] -> Q_xx (rows < n, cols < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped
+        {
+            v4d acc[T_NM][T_NM];
+            zero_tiles(acc);
+            mfma_product<T_NM, T_NM, N, LT, LAB>(pT, pAB, acc);
+#pragma unroll
+            for (int it = 0; it < T_NM; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NM; ++jt) {
+                    for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = nL[it][jt][v] + acc[it][jt][v]; });
+                    for_rows(16 * it, N, NM, g, colNM[jt], [&](int v, int r) { dG[colG[jt] + r * LG] = nL[it][jt][v] + acc[it][jt][v]; });
+                }
+        }
+        DPILQR_LDS_FENCE();
+        prefetch_l(tn);
+        // sT is dead from here on and becomes [K | d] + T3^T: the reduction-padding rows of [K | d] must read as zero
+        for (int e = lane; e < (C::KROWS - M) * LK; e += 64) sK[M * LK + e] = 0.0;
+        MPHASE(2)
+
+        // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers (vector pipe)
+        {
+            const int col = lane < M + N + 1 ? lane : M + N;
+            double v[M], invd[M];
+#pragma unroll
+            for (int r = 0; r < M; ++r) v[r] = sG[r * LG + col];
+#pragma unroll
+            for (int kk = 0; kk < M; ++kk) {
+                int piv = kk;
+                double best = fabs(v[kk]);
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r) {
+                    const double av = fabs(v[r]);
+                    piv = (av > best) ? r : piv;
+                    best = fmax(best, av);
+                }
+                piv = __builtin_amdgcn_readlane(piv, kk);
+                if (piv != kk) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = kk + 1; r < M; ++r)
+                        if (r == piv) {
+                            asm volatile("" ::: "memory");
+                            const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
+                        }
+                }
+                const double pv = readlane_f64(v[kk], kk);
+                if (pv == 0.0) sing = 1;
+                double inv = __builtin_amdgcn_rcp(pv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                invd[kk] = inv;
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r) {
+                    const double l = readlane_f64(v[r], kk) * inv;
+                    v[r] = fma(-l, v[kk], v[r]);
+                }
+            }
+#pragma unroll
+            for (int r = M - 1; r >= 0; --r) {
+                double s = v[r];
+#pragma unroll
+                for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
+                v[r] = s * invd[r];
+            }
+#pragma unroll
+            for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];
+        }
+        DPILQR_LDS_FENCE();
+        {
+            double* Kt = Kout + (gslot * T + t) * M * N;
+            double* dt_ = dout + (gslot * T + t) * M;
+#pragma unroll
+            for (int q = 0; q < K_ROUNDS; ++q) store_v2d_nt(Kt + k_out[q], *reinterpret_cast<const v2d*>(sK + k_in[q]));
+            store_f64_nt(dt_ + d_idx, sK[d_idx * LK + N]);
+        }
+        DPILQR_LDS_FENCE();
+        MPHASE(3)
+
+        // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
+        {
+            v4d acc[T_M][T_N];
+            zero_tiles(acc);
+            mfma_product<T_M, T_N, MK, LG, LK>(pGuu, pK, acc);
+#pragma unroll
+            for (int it = 0; it < T_M; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_N; ++jt)
+                    for_rows(16 * it, 0, M, g, colN[jt], [&](int v, int r) { dT3[16 * jt + r * N] = acc[it][jt][v]; });
+        }
+        DPILQR_LDS_FENCE();
+        MPHASE(4)
+
+        // ---- S5: a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] ; V = ((Q + a1) + a2) + a2^T   (rows < n, cols <= n)
+        {
+            v4d a1[T_NP][T_NP], a2[T_NP][T_NP];
+            zero_tiles(a1);
+            zero_tiles(a2);
+            mfma_product<T_NP, T_NP, MK, N, LK>(pT3, pK, a1);
+            mfma_product<T_NP, T_NP, MK, LK, LG>(pK, pGux, a2);
+#pragma unroll
+            for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt)
+                    for_rows(16 * it, 0, NP, g, colLE[jt], [&](int v, int r) { dMt[16 * jt + r * LM] = a2[it][jt][v]; });
+            DPILQR_LDS_FENCE();
+            double vb[T_NP][T_NP][4];
+#pragma unroll
+            for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) vb[it][jt][v] = 0.0;
+                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) {
+                        vb[it][jt][v] = ((dQ[16 * jt + r * LQ] + a1[it][jt][v]) + a2[it][jt][v]) + dMtT[16 * jt * LM + r];
+                    });
+                }
+            DPILQR_LDS_FENCE();
+#pragma unroll
+            for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt)
+                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = vb[it][jt][v]; });
+            DPILQR_LDS_FENCE();
+            // ---- S6: P <- (V + V^T)/2 ; p <- V[:, n]
+#pragma unroll
+            for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt) {
+                    for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) {
+                        vb[it][jt][v] = 0.5 * (vb[it][jt][v] + dQt[16 * jt * LQ + r]);
+                    });
+                }
+            DPILQR_LDS_FENCE();
+#pragma unroll
+            for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                for (int jt = 0; jt < T_NP; ++jt)
+                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) { dP[16 * jt + r * LP] = vb[it][jt][v]; });
+        }
+        DPILQR_LDS_FENCE();
+        MPHASE(5)
+    }
+    if (singular && sing && lane == 0) singular[b] = 1;
+    if (stamps && lane == 0) {
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        stamps[4 * slot + 0] = t_start;
+        stamps[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[4 * slot + 2] = hw_id;
+        stamps[4 * slot + 3] = xcc_id;
+#ifdef DPILQR_PHASE_STAMPS
+        for (int i = 0; i < 7; ++i) stamps[4 * B + 8 * slot + i] = ph[i];
+#endif
+    }
+}
+
+}  // namespace dpilqr

@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64 * kTiledWaves) void k_riccati_tiled(int B, int T
             double* d;
             int o;
             if (s2_reg == 0) { d = sQ + i * LQ + j; o = L.oLxx + i * N + j; }
-            else if (s2_reg == 1) { d = sG + (i - N) * LG + M + j; o = L.oLux + (i - N) * N + j; }
-            else { d = sG + (i - N) * LG + (j - N); o = L.oLuu + (i - N) * M + (j - N); }
+            else if (s2_reg == 1) { d = sG + (i - N) * LG + M + j; o = L.oLux + (i - N) * L.ldUG + j; }
+            else { d = sG + (i - N) * LG + (j - N); o = L.oLuu + (i - N) * L.ldUG + (j - N); }
             s2_dst[r][c] = ok ? d : sTrash;
             s2_src[r][c] = ok ? o : 0;
         }

@@ -21,12 +21,15 @@
 namespace dpilqr {
 
 struct TileLayout {
-    // One record = [ AB n x (n+m) | L_xx n x n | L_ux m x n | L_uu m x m | L_x n | L_u m ], every component
-    // starting on a 16-byte boundary.  A and B are stored INTERLEAVED, row l = [A[l][0..n) | B[l][0..m)],
-    // so that the sweep's stacked products ([A|B]^T P and [T1;T2][A|B]) stream contiguous rows.
+    // One record = [ AB n x (n+m) | L_xx n x n | UG m x (m+n) | L_x n | L_u m ], every component starting on a
+    // 16-byte boundary.  Two components are row-interleaved because the sweep consumes them as stacked matrices:
+    //   AB row l = [ A[l][0..n) | B[l][0..m) ]          (operands of [A|B]^T P and [T1;T2][A|B])
+    //   UG row a = [ L_uu[a][0..m) | L_ux[a][0..n) ]    (added onto the rows of [Q_uu | Q_ux])
     int n, m;              // n_x, n_u
     int oA, oB, ldAB;      // A[l][i] at oA + l*ldAB + i ; B[l][a] at oB + l*ldAB + a (oB = oA + n)
-    int oLxx, oLux, oLuu, oLx, oLu;
+    int oLxx;
+    int oLuu, oLux, ldUG;  // L_uu[a][c] at oLuu + a*ldUG + c ; L_ux[a][j] at oLux + a*ldUG + j (oLux = oLuu + m)
+    int oLx, oLu;
     int stride;            // doubles per record (even -> 16-byte aligned records)
     __host__ __device__ static int even(int x) { return (x + 1) & ~1; }
     __host__ __device__ TileLayout(int n_x, int n_u) : n(n_x), m(n_u) {
@@ -34,15 +37,15 @@ struct TileLayout {
         oA = 0;
         oB = n;
         oLxx = even(n * ldAB);
-        oLux = even(oLxx + n * n);
-        oLuu = even(oLux + m * n);
-        oLx = even(oLuu + m * m);
+        ldUG = m + n;
+        oLuu = even(oLxx + n * n);
+        oLux = oLuu + m;
+        oLx = even(oLuu + m * ldUG);
         oLu = oLx + n;     // [L_x | L_u] contiguous: the sweep reads them as one (n+m)-vector
         stride = even(oLu + m);
     }
 };
 
-// LDS carve for one (b,t): per-agent blocks + per-pair derivatives
 // LDS doubles of one time step's phase-1 results: per-agent A, B blocks, x - xf, u, per-pair gradient + Hessian
 __host__ __device__ inline int make_tiles_lds_doubles(int k, int ns, int nc) {
     return k * ns * ns + k * ns * nc + k * ns + k * nc + (k * (k - 1) / 2) * 12;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
             for (int e = lane; e < k * NC * NC; e += 64) {
                 const int a = e / (NC * NC), r = e - a * NC * NC, li = r / NC, lj = r - li * NC;
                 const double* R = P.R + a * NC * NC;
-                rec[L.oLuu + (a * NC + li) * m + a * NC + lj] = wr * (R[li * NC + lj] + R[lj * NC + li]);
+                rec[L.oLuu + (a * NC + li) * L.ldUG + a * NC + lj] = wr * (R[li * NC + lj] + R[lj * NC + li]);
             }
             for (int j = lane; j < m; j += 64) {
                 const int a = j / NC, lj = j - a * NC;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
             const int ai = i / NS, aj = j / NC;
             rec[L.oB + i * L.ldAB + j] = (ai == aj) ? sB[ai * NS * NC + (i - ai * NS) * NC + (j - aj * NC)] : 0.0;
         }
-        for (int e = lane; e < m * n; e += 64) rec[L.oLux + e] = 0.0;  // L_ux = 0 (cost.py:93,231)
+        for (int e = lane; e < m * n; e += 64) rec[L.oLux + (e / n) * L.ldUG + (e % n)] = 0.0;  // L_ux = 0 (cost.py:93,231)
         for (int e = lane; e < m * m; e += 64) {
             const int i = e / m, j = e - i * m;
             const int ai = i / NC, aj = j / NC;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
                 const int li = i - ai * NC, lj = j - aj * NC;
                 v = wr * (R[li * NC + lj] + R[lj * NC + li]);  // R + R^T (cost.py:63,92)
             }
-            rec[L.oLuu + e] = v;
+            rec[L.oLuu + i * L.ldUG + j] = v;
         }
         for (int j = lane; j < m; j += 64) {
             const int a = j / NC, lj = j - a * NC;

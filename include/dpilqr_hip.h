@@ -112,8 +112,9 @@ int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const dou
 /* -------------------------------------------------- (3) tiles: the plugin contract of the sweep
  * One "tile record" per (item, time step) holds what DynamicalModel.linearize (dynamics.py:173-186)
  * and Cost.quadraticize (cost.py:208-239) return at (X[t],U[t]), packed as
- *     [ AB n_x*(n_x+n_u) | L_xx n_x*n_x | L_ux n_u*n_x | L_uu n_u*n_u | L_x n_x | L_u n_u ]
- * where AB stores A and B interleaved by row: row l = [ A[l][0..n_x) | B[l][0..n_u) ].
+ *     [ AB n_x*(n_x+n_u) | L_xx n_x*n_x | UG n_u*(n_u+n_x) | L_x n_x | L_u n_u ]
+ * where AB stores A and B interleaved by row, row l = [ A[l][0..n_x) | B[l][0..n_u) ], and UG stores L_uu and
+ * L_ux the same way, row a = [ L_uu[a][0..n_u) | L_ux[a][0..n_x) ] (the sweep consumes both as stacked matrices).
  * Record t = T holds the terminal quadraticisation (only L_xx, L_x are read).
  * dpilqr_tile_layout returns, for the 7 components in the order A,B,Lxx,Lux,Luu,Lx,Lu, the offset of
  * element [0][0] and the row stride (both in doubles), plus the record stride; a tile buffer is

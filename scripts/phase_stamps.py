@@ -27,7 +27,7 @@ for rep in range(3):
 torch.cuda.synchronize()
 s = buf.cpu().numpy()
 ph = s[4 * B:].reshape(B, 8)[:, :7] / T
-names = ["S0 park AB", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5 three sums", "S6 symmetrise"]
+names = ["S0 park AB", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6 sums, symmetrise", "-"]
 tot = ph.sum(1).mean()
 for n, v in zip(names, ph.mean(0)):
     print(f"{n:22s} {v:8.0f} cycles/step  {100 * v / tot:5.1f} %")
