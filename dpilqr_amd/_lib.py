@@ -47,6 +47,7 @@ SIGNATURES = {
     "dpilqr_make_tiles": (i32, [_DP, vp, vp, vp, vp, vp, vp]),
     "dpilqr_rollout": (i32, [_DP, vp, vp, vp, vp, vp]),
     "dpilqr_backward_pass_tiles": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_backward_pass_tiles_blocks": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_tiles_bytes": (i64, [i32, i32, i32, i32]),
     "dpilqr_backward_pass": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_forward_pass": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),

@@ -119,7 +119,7 @@ class ProblemBatch:
     def backward_pass(self, X, U, mu, tiles=None):
         """control.py:116-148: K (B,T,n_u,n_x), d (B,T,n_u)."""
         tiles = self.make_tiles(X, U, tiles)
-        return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu)
+        return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu, blocks=(self.n_s, self.n_c))
 
     def forward_pass(self, X, U, K, d, alphas):
         """control.py:95-114 for all alphas: Xn (B,A,T+1,n_x), Un (B,A,T,n_u), Jn (B,A)."""
@@ -179,13 +179,17 @@ class ProblemBatch:
         return out
 
 
-def backward_pass_tiles(tiles, B, T, n_x, n_u, mu, singular=None):
-    """The Riccati sweep on explicit tile records -- the plugin contract (any linearize/quadraticize)."""
+def backward_pass_tiles(tiles, B, T, n_x, n_u, mu, singular=None, blocks=None):
+    """The Riccati sweep on explicit tile records -- the plugin contract (any linearize/quadraticize).
+
+    blocks=(n_s, n_c): the caller's promise that A, B of every record are block diagonal with per-agent
+    blocks of that size (MultiDynamicalModel.linearize, dynamics.py:173-186); same gains, fewer products."""
     lib = _lib.load()
     mu_t = to_dev(np.broadcast_to(np.asarray(mu, dtype=np.float64), (B,))) if not isinstance(mu, torch.Tensor) else mu
     K = empty((B, T, n_u, n_x)); d = empty((B, T, n_u))
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, n_x, n_u, ptr(tiles), ptr(mu_t), ptr(K), ptr(d), ptr(singular),
-                                              None, None, stream_handle()))
+    ns, nc = blocks if blocks else (0, 0)
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, n_x, n_u, ns, nc, ptr(tiles), ptr(mu_t), ptr(K), ptr(d),
+                                                     ptr(singular), None, None, stream_handle()))
     return K, d
 
 

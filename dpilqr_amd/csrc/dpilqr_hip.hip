@@ -108,8 +108,12 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
 
 int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
-                       int gains_by_item, hipStream_t st) {
+                       int gains_by_item, int block_ns, int block_nc, hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
+    // block_ns > 0: the caller guarantees that [A|B] is block diagonal with block_ns x (block_ns + block_nc) blocks
+    // (tiles made by k_make_tiles from a MultiDynamicalModel); 0: arbitrary dense tiles (the plugin boundary).
+    static const bool no_bd = getenv("DPILQR_RICCATI_DENSE") != nullptr;   // A/B switch
+    const bool bd = !no_bd && block_ns == 4 && block_nc == 2 && n == 4 * (m / 2) && m % 2 == 0;
     // sweep selection: matrix-pipe kernel where instantiated, else the vector-pipe tiled kernel, else the generic one
     // (DPILQR_RICCATI=mfma|tiled|generic pins one for A/B measurements)
     static const char* pick_env = getenv("DPILQR_RICCATI");
@@ -124,12 +128,12 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         const bool w8 = !no8 && grid_items > 1024;   /* enough items for two waves per SIMD */                     \
         const int wv = w8 ? 8 : 4;                                                                                 \
         const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
-        int32_t rc_t = w8 ? allow_lds(k_riccati_mfma<NN, MM, 8>, lds_t) : allow_lds(k_riccati_mfma<NN, MM, 4>, lds_t); \
+        auto kern = w8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)                  \
+                       : (bd ? k_riccati_mfma<NN, MM, 4, 4, 2> : k_riccati_mfma<NN, MM, 4, 0, 0>);                 \
+        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
         if (rc_t) return rc_t;                                                                                     \
-        if (w8) hipLaunchKernelGGL((k_riccati_mfma<NN, MM, 8>), dim3((grid_items + 7) / 8), dim3(512), lds_t, st, B, T, \
-                                   tiles, mu, K, d, singular, items, n_items, gains_by_item, stagger);             \
-        else hipLaunchKernelGGL((k_riccati_mfma<NN, MM, 4>), dim3((grid_items + 3) / 4), dim3(256), lds_t, st, B, T,    \
-                                tiles, mu, K, d, singular, items, n_items, gains_by_item, stagger);                \
+        hipLaunchKernelGGL(kern, dim3((grid_items + wv - 1) / wv), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d, \
+                           singular, items, n_items, gains_by_item, stagger);                                      \
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
@@ -432,7 +436,21 @@ int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_
                                    const int32_t* n_items, void* stream) {
     if (B < 0 || T < 1 || n_x < 1 || n_u < 1) return fail(DPILQR_EINVAL, "backward_pass_tiles: bad sizes");
     if (!tiles || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_tiles: NULL pointer");
-    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, 0, as_stream(stream));
+    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, 0, 0, 0, as_stream(stream));
+}
+
+int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int32_t n_u, int32_t block_ns,
+                                          int32_t block_nc, const double* tiles, const double* mu, double* K,
+                                          double* d, int32_t* singular, const int32_t* items,
+                                          const int32_t* n_items, void* stream) {
+    if (B < 0 || T < 1 || n_x < 1 || n_u < 1) return fail(DPILQR_EINVAL, "backward_pass_tiles_blocks: bad sizes");
+    if (!tiles || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_tiles_blocks: NULL pointer");
+    if (block_ns < 0 || block_nc < 0 || (block_ns > 0 && (block_nc < 1 || n_x % block_ns || n_u % block_nc ||
+                                                          n_x / block_ns != n_u / block_nc)))
+        return fail(DPILQR_EINVAL, "backward_pass_tiles_blocks: n_x=%d, n_u=%d are not k blocks of %d, %d", n_x, n_u,
+                    block_ns, block_nc);
+    return launch_riccati(B, T, n_x, n_u, tiles, mu, K, d, singular, items, n_items, B, 0, block_ns, block_nc,
+                          as_stream(stream));
 }
 
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
@@ -443,7 +461,7 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
     rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, false, as_stream(stream));
     if (rc) return rc;
     return launch_riccati(desc->B, desc->T, desc->k * desc->n_s, desc->k * desc->n_c, tiles_workspace, mu, K, d, nullptr,
-                          nullptr, nullptr, desc->B, 0, as_stream(stream));
+                          nullptr, nullptr, desc->B, 0, desc->n_s, desc->n_c, as_stream(stream));
 }
 
 int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,
@@ -551,7 +569,8 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
             if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, st))) return rc;
             g_prof.end(st);
             g_prof.begin(1, it, st);
-            if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, st)))
+            if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, D.n_s, D.n_c,
+                                     st)))
                 return rc;
             g_prof.end(st);
             g_prof.begin(2, it, st);

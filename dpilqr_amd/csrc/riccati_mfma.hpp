@@ -50,7 +50,9 @@ struct MfmaCfg {
     static constexpr int T_NM = (NM + 15) / 16, T_NP = (NP + 15) / 16, T_N = (N + 15) / 16, T_M = (M + 15) / 16;
     // LDS carve (doubles).  sK, sT3 live inside sT's space (dead after S2); a2 lives inside sAB's (dead after S2).
     static constexpr int szAB = round_up(N * LAB > NP * LM ? N * LAB : NP * LM, 2);
-    static constexpr int szT = round_up(N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N, 2);
+    static constexpr int LTB = LP;                     // block-diagonal variant: T row-major, [i'][j], j <= n
+    static constexpr int szT0 = N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N;
+    static constexpr int szT = round_up(szT0 > NM * LTB ? szT0 : NM * LTB, 2);
     static constexpr int oAB = 0;
     static constexpr int oT = oAB + szAB;
     static constexpr int oK = oT;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool c
 // whole CU, waves w and w+4 share a SIMD, and waves 4..7 start `stagger` x 64 cycles late: a sweep step
 // alternates a matrix-pipe half (S1, S2, S4, S5) with a vector-pipe half (the LU solve), so two waves that
 // run in lockstep contend for one pipe at a time, while two waves half a step apart keep both pipes busy.
-template <int N, int M, int WAVES>
+template <int N, int M, int WAVES, int NS, int NC>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
@@ -220,6 +222,69 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     }
     const int d_idx = min(lane, M - 1);
 
+    // ---- block-diagonal variant (NS > 0): [A|B] of a MultiDynamicalModel is block diagonal (dynamics.py:173-186:
+    // uniform_block_diag of the agents' (A_i, B_i)), so column i' of [A|B] has its non-zeros in the NS rows of ONE
+    // agent and S1 / S2 need NS terms per output instead of n.  The skipped terms are exact zeros (x + 0*y == x),
+    // so the results are those of the dense sum, term for term.  The record is still read in full -- it is the
+    // dense plugin format -- only the multiplications by structural zeros are dropped; these two phases run on
+    // the vector pipe (NS = 4 rows per block is one MFMA reduction step: a 16-row tile would use 4 of its rows).
+    // Lane (ag, sub): agent ag = lane / LPA.  S1: rows i' of agent ag (NS columns of A, NC of B) x CPL columns
+    // of [P|p];  S2: RPL rows of T x the NS + NC columns of agent ag.  Idle lanes duplicate a working lane
+    // (same addresses, same values), so nothing is predicated.
+    constexpr bool BD = NS > 0;
+    constexpr int KA = BD ? N / (BD ? NS : 1) : 1, LPA = 64 / KA, NSC = NS + NC;
+    constexpr int CPL = 2 * ((NP + 2 * LPA - 1) / (2 * LPA));
+    constexpr int RPL = (NM + LPA - 1) / LPA;
+    constexpr int LTB = C::LTB;
+    static_assert(!BD || (NS % 2 == 0 && NC % 2 == 0 && N % 2 == 0 && M % 2 == 0 && CPL == 2),
+                  "block-diagonal variant: 16-byte vector accesses need even block sizes");
+    const int ag = min(lane / LPA, KA - 1);
+    const int sub1 = min(lane - (lane / LPA) * LPA, (NP - 1) / CPL), j0 = CPL * sub1;   // S1 columns j0, j0+1
+    const int sub2 = min(lane - (lane / LPA) * LPA, (NM - 1) / RPL);
+    const double* bP = sP + NS * ag * LP + j0;                 // P[NS ag + l][j0 ..]
+    const double* bABa = sAB + NS * ag * LAB + NS * ag;        // A block row l
+    const double* bABb = sAB + NS * ag * LAB + N + NC * ag;    // B block row l
+    const double* bBmu[CPL];                                   // B[j][NC ag ..] for the mu B^T term (j < n)
+    bool bMuOn[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { bMuOn[c] = j0 + c < N; bBmu[c] = sAB + min(j0 + c, N - 1) * LAB + N + NC * ag; }
+    double* bTa = sT + NS * ag * LTB + j0;                     // T[NS ag + r][j0 ..]   (A^T P rows)
+    double* bTb = sT + (N + NC * ag) * LTB + j0;               // T[n + NC ag + r][j0 ..] (B^T P rows)
+    const bool bPcol = (j0 == N);                              // this lane holds A^T p, B^T p
+    const double* bT2[RPL];                                    // S2: T[i'_r][NS ag ..]
+    double* bDa[RPL];                                          // S2 outputs over A's columns: Q_xx row or Q_ux row
+    double* bDb[RPL];                                          //            over B's columns: Q_uu row (or dropped)
+    int bSa[RPL], bSb[RPL];                                    // record offsets of the matching l-values
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int ip = min(RPL * sub2 + r, NM - 1);
+        bT2[r] = sT + ip * LTB + NS * ag;
+        if (ip < N) {
+            bDa[r] = sQ + ip * LQ + NS * ag; bSa[r] = L.oLxx + ip * N + NS * ag;
+            bDb[r] = lds + C::oEnd;          bSb[r] = bSa[r];
+        } else {
+            bDa[r] = sG + (ip - N) * LG + M + NS * ag; bSa[r] = L.oLux + (ip - N) * L.ldUG + NS * ag;
+            bDb[r] = sG + (ip - N) * LG + NC * ag;     bSb[r] = L.oLuu + (ip - N) * L.ldUG + NC * ag;
+        }
+    }
+    const int bSx = L.oLx + NS * ag, bSu = L.oLu + NC * ag;
+    v2d nbL[RPL][NSC / 2 > 0 ? NSC / 2 : 1];
+    v2d nbX[NSC / 2 > 0 ? NSC / 2 : 1];
+    auto prefetch_bd = [&](int t) {
+        const double* rec = base + (int64_t)t * L.stride;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+#pragma unroll
+            for (int q = 0; q < NS / 2; ++q) nbL[r][q] = *reinterpret_cast<const v2d*>(rec + bSa[r] + 2 * q);
+#pragma unroll
+            for (int q = 0; q < NC / 2; ++q) nbL[r][NS / 2 + q] = *reinterpret_cast<const v2d*>(rec + bSb[r] + 2 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < NS / 2; ++q) nbX[q] = *reinterpret_cast<const v2d*>(rec + bSx + 2 * q);
+#pragma unroll
+        for (int q = 0; q < NC / 2; ++q) nbX[NS / 2 + q] = *reinterpret_cast<const v2d*>(rec + bSu + 2 * q);
+    };
+
     // ---- prefetch registers (one record ahead), re-filled right after they are consumed.  They mirror the D
     // layout: nL[it][jt][v] is the l-value added to element (it, jt, v) of the S2 product.
     v2d nAB[C::AB_ROUNDS];
@@ -252,8 +317,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             }
     };
     prefetch_ab(T - 1);
-    prefetch_lxu(T - 1);
-    prefetch_l(T - 1);
+    if constexpr (BD) {
+        prefetch_bd(T - 1);
+    } else {
+        prefetch_lxu(T - 1);
+        prefetch_l(T - 1);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see riccati_tiled.hpp
 
 #ifdef DPILQR_PHASE_STAMPS
@@ -272,7 +341,52 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         MPHASE(0)
 
         // ---- S1: [A|B]^T [P|p]
-        {
+        if constexpr (BD) {
+            double acc[NSC][CPL];
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                double ab[NSC], pr[CPL];
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bABa + l * LAB + 2 * q);
+                    ab[2 * q] = v.x; ab[2 * q + 1] = v.y;
+                }
+#pragma unroll
+                for (int q = 0; q < NC / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bABb + l * LAB + 2 * q);
+                    ab[NS + 2 * q] = v.x; ab[NS + 2 * q + 1] = v.y;
+                }
+                {
+                    const v2d v = *reinterpret_cast<const v2d*>(bP + l * LP);
+                    pr[0] = v.x; pr[1] = v.y;
+                }
+#pragma unroll
+                for (int r = 0; r < NSC; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) acc[r][c] = (l == 0) ? ab[r] * pr[c] : fma(ab[r], pr[c], acc[r][c]);
+            }
+            // T2 rows: + mu B[j][c]   (quirk Q6: B^T (P + mu I) = B^T P + mu B^T)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                for (int q = 0; q < NC / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bBmu[c] + 2 * q);
+                    acc[NS + 2 * q][c] = fma(mu, bMuOn[c] ? v.x : 0.0, acc[NS + 2 * q][c]);
+                    acc[NS + 2 * q + 1][c] = fma(mu, bMuOn[c] ? v.y : 0.0, acc[NS + 2 * q + 1][c]);
+                }
+#pragma unroll
+            for (int r = 0; r < NS; ++r) *reinterpret_cast<v2d*>(bTa + r * LTB) = v2d{acc[r][0], acc[r][1]};
+#pragma unroll
+            for (int r = 0; r < NC; ++r) *reinterpret_cast<v2d*>(bTb + r * LTB) = v2d{acc[NS + r][0], acc[NS + r][1]};
+            // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+            if (bPcol) {
+#pragma unroll
+                for (int r = 0; r < NS; ++r) sQ[(NS * ag + r) * LQ + N] = ((r & 1) ? nbX[r / 2].y : nbX[r / 2].x) + acc[r][0];
+#pragma unroll
+                for (int r = 0; r < NC; ++r)
+                    sG[(NC * ag + r) * LG + M + N] = ((r & 1) ? nbX[NS / 2 + r / 2].y : nbX[NS / 2 + r / 2].x) + acc[NS + r][0];
+            }
+        } else {
             v4d acc[T_NM][T_NP];
             zero_tiles(acc);
             mfma_product<T_NM, T_NP, N, LAB, LP>(pAB, pP, acc);
@@ -294,11 +408,49 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 }
         }
         DPILQR_LDS_FENCE();
-        prefetch_lxu(tn);
+        if constexpr (!BD) prefetch_lxu(tn);
         MPHASE(1)
 
         // ---- S2: [T1;T2][A|B] -> Q_xx (rows < n, cols < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped
-        {
+        if constexpr (BD) {
+            double acc[RPL][NSC];
+            double tv[RPL][NS];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bT2[r] + 2 * q);
+                    tv[r][2 * q] = v.x; tv[r][2 * q + 1] = v.y;
+                }
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                double ab[NSC];
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bABa + l * LAB + 2 * q);
+                    ab[2 * q] = v.x; ab[2 * q + 1] = v.y;
+                }
+#pragma unroll
+                for (int q = 0; q < NC / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bABb + l * LAB + 2 * q);
+                    ab[NS + 2 * q] = v.x; ab[NS + 2 * q + 1] = v.y;
+                }
+#pragma unroll
+                for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                    for (int c = 0; c < NSC; ++c) acc[r][c] = (l == 0) ? tv[r][l] * ab[c] : fma(tv[r][l], ab[c], acc[r][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q)
+                    *reinterpret_cast<v2d*>(bDa[r] + 2 * q) = v2d{nbL[r][q].x + acc[r][2 * q], nbL[r][q].y + acc[r][2 * q + 1]};
+#pragma unroll
+                for (int q = 0; q < NC / 2; ++q)
+                    *reinterpret_cast<v2d*>(bDb[r] + 2 * q) =
+                        v2d{nbL[r][NS / 2 + q].x + acc[r][NS + 2 * q], nbL[r][NS / 2 + q].y + acc[r][NS + 2 * q + 1]};
+            }
+        } else {
             v4d acc[T_NM][T_NM];
             zero_tiles(acc);
             mfma_product<T_NM, T_NM, N, LT, LAB>(pT, pAB, acc);
@@ -311,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 }
         }
         DPILQR_LDS_FENCE();
-        prefetch_l(tn);
+        if constexpr (BD) prefetch_bd(tn); else prefetch_l(tn);
         // sT is dead from here on and becomes [K | d] + T3^T: the reduction-padding rows of [K | d] must read as zero
         for (int e = lane; e < (C::KROWS - M) * LK; e += 64) sK[M * LK + e] = 0.0;
         MPHASE(2)

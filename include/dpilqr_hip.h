@@ -137,6 +137,15 @@ int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const do
 int32_t dpilqr_backward_pass_tiles(int32_t B, int32_t T, int32_t n_x, int32_t n_u, const double* tiles,
                                    const double* mu, double* K, double* d, int32_t* singular,
                                    const int32_t* items, const int32_t* n_items, void* stream);
+/* The same sweep for records whose A and B are block diagonal with n_x/block_ns agents' blocks of
+ * block_ns x block_ns and block_ns x block_nc -- what MultiDynamicalModel.linearize (dynamics.py:173-186,
+ * uniform_block_diag) always returns.  The records are the same dense records and are read in full; the
+ * caller's promise lets the sweep skip the products with the structural zeros (which are exact, so the
+ * gains are those of the dense sweep).  block_ns == 0 is dpilqr_backward_pass_tiles.                   */
+int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int32_t n_u, int32_t block_ns,
+                                          int32_t block_nc, const double* tiles, const double* mu, double* K,
+                                          double* d, int32_t* singular, const int32_t* items,
+                                          const int32_t* n_items, void* stream);
 /* convenience: make_tiles + backward_pass_tiles for recognised plugins; workspace = tile buffer      */
 int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u);
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,

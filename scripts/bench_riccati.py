@@ -25,15 +25,16 @@ else:
 tiles = pb.make_tiles(X, U)
 K = empty((Bmax, T, N_U, N_X)); d = empty((Bmax, T, N_U))
 lib = _lib.load()
+BLK = (0, 0) if os.environ.get('DENSE') else (4, 2)
 for B in sizes:
     for rep in range(3):
-        _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tiles), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tiles), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     e0.record()
     for rep in range(n):
-        _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tiles), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tiles), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     gbs = B * (BWD_READ_BYTES + BWD_WRITE_BYTES) / (us * 1e-6) / 1e9
@@ -49,7 +50,7 @@ for rep in range(n + 3):
     pb2.make_tiles(Xb, Ub, tl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record(); torch.cuda.synchronize()
     if rep >= 3:
         tot += e0.elapsed_time(e1)
@@ -61,7 +62,7 @@ for rep in range(n + 3):
     import time; time.sleep(0.002)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record(); torch.cuda.synchronize()
     if rep >= 3:
         tot += e0.elapsed_time(e1)
@@ -73,7 +74,7 @@ for rep in range(n + 3):
     pb2.make_tiles(Xb, Ub, tl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record()
     evs.append((e0, e1))
 torch.cuda.synchronize()
@@ -87,7 +88,7 @@ for rep in range(n + 3):
     for k2 in range(2):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
         e1.record()
         pair.append((e0, e1))
     evs.append(pair)
@@ -104,7 +105,7 @@ for rep in range(n + 3):
     junk2.copy_(junk)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record()
     evs.append((e0, e1))
 torch.cuda.synchronize()
@@ -116,7 +117,7 @@ for rep in range(n + 3):
     junk2.copy_(junk)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record()
     evs.append((e0, e1))
 torch.cuda.synchronize()
@@ -130,7 +131,7 @@ for rep in range(n + 3):
     pb2.make_tiles(Xb, Ub, tl2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, BLK[0], BLK[1], ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     e1.record()
     evs.append((e0, e1))
 torch.cuda.synchronize()

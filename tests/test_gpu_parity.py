@@ -225,3 +225,27 @@ def test_sweep_multi_item_all_sizes(dp, k):
         p = orc.Problem([3] * k, [2] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
         Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+
+
+@pytest.mark.parametrize("k,model", [(1, 0), (2, 3), (3, 0), (4, 3), (5, 0), (5, 3)])
+def test_sweep_blocks_variant_equals_dense(dp, k, model):
+    """dpilqr_backward_pass_tiles_blocks skips the products with the structural zeros of a block-diagonal
+    [A|B] (MultiDynamicalModel.linearize, dynamics.py:173-186); those terms are exact zeros, so its gains
+    must be the dense sweep's -- and both the oracle's -- on the same records."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    rng = np.random.default_rng(100 + k)
+    B, T = 13, 20
+    xf = rng.normal(size=(B, 4 * k)); x0 = rng.normal(size=(B, 4 * k)); U = rng.normal(size=(B, T, 2 * k)) * 0.2
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    pb = dp.ProblemBatch([model] * k, [2] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, _ = pb.rollout(x0, U)
+    mu = to_dev(rng.uniform(0, 1, size=B))
+    tiles = pb.make_tiles(X, U)
+    Kd, dd = dp.backward_pass_tiles(tiles, B, T, pb.n_x, pb.n_u, mu)
+    Kb, db = dp.backward_pass_tiles(tiles, B, T, pb.n_x, pb.n_u, mu, blocks=(4, 2))
+    assert relerr(Kb.cpu().numpy(), Kd.cpu().numpy()) < 1e-11 and relerr(db.cpu().numpy(), dd.cpu().numpy()) < 1e-11
+    for i in (0, B - 1):
+        p = orc.Problem([model] * k, [2] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], float(mu[i]))
+        assert relerr(Kb[i].cpu().numpy(), Ko) < TOL_PASS and relerr(db[i].cpu().numpy(), do) < TOL_PASS, i
