@@ -86,6 +86,8 @@ int forward_threads(int k, int ngrp) {
 int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
                           const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
+    static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
+    if (force_dense) sparse = false;
     const int ts = make_tiles_steps(D.k, D.n_s, D.n_c);
     const size_t lds = make_tiles_lds_bytes(D.k, D.n_s, D.n_c, ts);
     dim3 grid((D.T + 1 + ts - 1) / ts, grid_items);

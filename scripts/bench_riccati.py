@@ -41,7 +41,7 @@ for B in sizes:
     print(f"B={B:5d}  {us:8.1f} us/launch  {gbs:8.1f} GB/s algorithmic  ({gbs/80:.1f} % of 8 TB/s)")
 
 # K2 timed inside the K1 -> K2 sequence of the solver (tiles freshly written by the producer)
-B = 1024
+B = int(os.environ.get("B2", "1024"))
 Xb, Ub = X[:B].contiguous(), U[:B].contiguous()
 pb2 = dp.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf[:B], np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
 tl = pb2.tiles_buffer()

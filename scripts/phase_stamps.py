@@ -23,7 +23,7 @@ lib = _lib.load()
 buf = torch.zeros((B * 12,), dtype=torch.int64, device="cuda")
 _lib.check(lib.dpilqr_debug_stamps(ptr(buf)))
 for rep in range(3):
-    _lib.check(lib.dpilqr_backward_pass_tiles(B, T, N_X, N_U, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, 4, 2, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
 torch.cuda.synchronize()
 s = buf.cpu().numpy()
 ph = s[4 * B:].reshape(B, 8)[:, :7] / T
