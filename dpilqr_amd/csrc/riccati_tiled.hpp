@@ -43,11 +43,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 // operations in issue order (MI355X guide, s_waitcnt notes), so hiding these fire-and-forget stores from
 // the pass keeps its counted vmcnt(N) waits: they merely become conservative by the number of stores
 // in flight.  Nothing ever reads the stored data back inside the kernel.
+// The trailing s_nop covers the "VMEM store data > 64 bit, then a VALU write of the data VGPRs" hazard: the
+// compiler's hazard recogniser does not look inside inline assembly, and the data registers are read a few
+// cycles after issue.
 __device__ __forceinline__ void store_v2d_nt(double* p, v2d v) {
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_f64_nt(double* p, double v) {
-    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 
 // Diagnostic stamps (dpilqr_debug_stamps): when a buffer is registered, lane 0 of every sweep workgroup

@@ -73,7 +73,8 @@ typedef struct dpilqr_batch_desc {
     int32_t n_s; /* per-agent state dim   (3, 4, 6 or 12)                        */
     int32_t n_c; /* per-agent control dim (2, 3 or 4)                            */
     int32_t T;   /* horizon N (control.py:56)                                    */
-    int32_t reserved;
+    int32_t uniform_model; /* hint: 1 + Model enum when EVERY agent of EVERY item uses that model (lets the
+                              solver pick kernels compiled for it); 0 = unknown / mixed, always valid  */
     double dt;     /* DynamicalModel.dt                                          */
     double w_ref;  /* GameCost.REF_WEIGHT  = 1   (cost.py:185)                   */
     double w_prox; /* GameCost.PROX_WEIGHT = 200 (cost.py:186)                   */
