@@ -85,10 +85,12 @@ int forward_threads(int k, int ngrp) {
 }
 
 int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
-                          const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, hipStream_t st) {
+                          const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, bool dyn_only,
+                          hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
     static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
     if (force_dense) sparse = false;
+    if (!sparse) dyn_only = false;
     const int ts = make_tiles_steps(D.k, D.n_s, D.n_c);
     const size_t lds = make_tiles_lds_bytes(D.k, D.n_s, D.n_c, ts);
     dim3 grid((D.T + 1 + ts - 1) / ts, grid_items);
@@ -97,9 +99,10 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
         if (rc) return rc;
         if (sparse) {
             if ((rc = allow_lds(k_make_tiles<NS, NC, true>, lds))) return rc;
-            hipLaunchKernelGGL((k_make_tiles<NS, NC, true>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts);
+            hipLaunchKernelGGL((k_make_tiles<NS, NC, true>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts,
+                               dyn_only ? 1 : 0);
         } else {
-            hipLaunchKernelGGL((k_make_tiles<NS, NC, false>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts);
+            hipLaunchKernelGGL((k_make_tiles<NS, NC, false>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts, 0);
         }
     })
     HIP_TRY(hipGetLastError());
@@ -444,7 +447,7 @@ int32_t dpilqr_make_tiles(const dpilqr_batch_desc* desc, const double* X, const 
     int32_t rc = check_desc(desc);
     if (rc) return rc;
     if (!X || !U || !tiles) return fail(DPILQR_EINVAL, "make_tiles: NULL pointer");
-    return launch_make_tiles(*desc, X, U, tiles, items, n_items, desc->B, false, as_stream(stream));
+    return launch_make_tiles(*desc, X, U, tiles, items, n_items, desc->B, false, false, as_stream(stream));
 }
 
 int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const double* U, double* X, double* J,
@@ -484,7 +487,7 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
     int32_t rc = check_desc(desc);
     if (rc) return rc;
     if (!X || !U || !mu || !K || !d || !tiles_workspace) return fail(DPILQR_EINVAL, "backward_pass: NULL pointer");
-    rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, false, as_stream(stream));
+    rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, false, false, as_stream(stream));
     if (rc) return rc;
     return launch_riccati(desc->B, desc->T, desc->k * desc->n_s, desc->k * desc->n_c, tiles_workspace, mu, K, d, nullptr,
                           nullptr, nullptr, desc->B, 0, desc->n_s, desc->n_c, as_stream(stream));
@@ -583,6 +586,14 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     if (n_lqr_iter > 0) {
         // the tile producer of the loop writes only structurally non-zero entries: put the zeros in place once
         HIP_TRY(hipMemsetAsync(tiles, 0, W.K - W.tiles, st));
+        // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every
+        // item, so they are written once into all Wn slots here (with items 0..Wn-1 as stand-ins; their (X, U)
+        // dependent entries are overwritten by each iteration's producer launch) and skipped afterwards.
+        static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
+        const int um = D.uniform_model - 1;
+        const bool static_part_placed = !no_static && D.R_bstride == 0 &&
+                                        (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
+        if (static_part_placed && (rc = launch_make_tiles(D, X, U, tiles, nullptr, nullptr, Wn, true, false, st))) return rc;
         int upper = Wn;
         for (int it = 0; it < kMaxGlobalIter; ++it) {
             int32_t* cur = lists + (size_t)(it & 1) * Wn;
@@ -592,7 +603,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
             S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
             S.next_count = nxt_n;
             g_prof.begin(0, it, st);
-            if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, st))) return rc;
+            if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, static_part_placed, st))) return rc;
             g_prof.end(st);
             g_prof.begin(1, it, st);
             if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, D.n_s, D.n_c,

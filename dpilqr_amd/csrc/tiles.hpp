@@ -56,11 +56,14 @@ __host__ __device__ inline int make_tiles_lds_doubles(int k, int ns, int nc) {
 // doubles of a cfg2 record.  It requires a buffer whose structural zeros are already in place -- the solve
 // loop zeroes its tile workspace once per call and then reuses the slots for items of the same shape -- and
 // leaves in HBM exactly the dense records the sweep reads.  SPARSE = false (the API's default) writes all of it.
+// dyn_only (SPARSE only): additionally skip what does not depend on (X, U) -- A, B of a model with linear dynamics
+// and L_uu = w_ref (R + R^T) -- when the caller has put those in place once and every item that will use the
+// slot shares them (one linear model, one R for the batch).
 template <int NS, int NC, bool SPARSE>
 __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const double* __restrict__ X,
                                                     const double* __restrict__ U, double* __restrict__ tiles,
                                                     const int32_t* __restrict__ items,
-                                                    const int32_t* __restrict__ n_items, int ts) {
+                                                    const int32_t* __restrict__ n_items, int ts, int dyn_only) {
     // one wavefront handles `ts` consecutive time steps of one item: phase 1 spreads (step, agent) and
     // (step, pair) over the lanes, phase 2 writes the records one after the other
     const int slot = blockIdx.y;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
         for (int i = 0; i < NS; ++i) x[i] = xt[a * NS + i];
 #pragma unroll
         for (int i = 0; i < NC; ++i) u[i] = terminal ? 0.0 : ut[a * NC + i];
-        if (!terminal) {
+        if (!terminal && !(SPARSE && dyn_only)) {
             linearize_rt<NS>(P.model[a], x, u, D.dt, A, Bm);
 #pragma unroll
             for (int i = 0; i < NS * NS; ++i) sA[a * NS * NS + i] = A[i];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
     if (SPARSE) {
         // ---- phase 2 (sparse): only the structurally non-zero entries; same values as the dense path below
         constexpr int PD = NS < 3 ? NS : 3;    // position sub-block edge of the coupling blocks
-        if (!terminal) {
+        if (!terminal && !dyn_only) {
             for (int e = lane; e < k * NS * NS; e += 64) {
                 const int a = e / (NS * NS), r = e - a * NS * NS, li = r / NS, lj = r - li * NS;
                 rec[L.oA + (a * NS + li) * L.ldAB + a * NS + lj] = sA[e];
@@ -164,6 +167,8 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
                 const double* R = P.R + a * NC * NC;
                 rec[L.oLuu + (a * NC + li) * L.ldUG + a * NC + lj] = wr * (R[li * NC + lj] + R[lj * NC + li]);
             }
+        }
+        if (!terminal) {
             for (int j = lane; j < m; j += 64) {
                 const int a = j / NC, lj = j - a * NC;
                 const double* R = P.R + a * NC * NC;
