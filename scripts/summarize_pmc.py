@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) of bench.py into
+profiles/<tag>_bench_hbm_counters.csv and profiles/riccati_traffic.json (read by bench.py for roofline.traffic).
+
+    python scripts/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [window]
+
+gfx950: FETCH_SIZE tallies 64 B per 128-B request on wide coalesced reads (MI355X_MICROARCH.md, "HBM"), so read
+bytes = 2 x FETCH_SIZE KB; WRITE_SIZE is exact for 16-B-per-lane stores.  "Full" launches are those whose grid
+covers the whole window of sub-problems."""
+import csv, json, statistics, sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+window = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+ALGO = 619360  # bytes per sub-problem backward pass, bench.py
+
+def short(name):
+    if "k_riccati" in name: return "riccati"
+    if "k_make_tiles" in name: return "tiles"
+    if "k_linesearch_wave" in name or "k_forward" in name: return "forward"
+    return None
+
+def load(path, counter):
+    by = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == counter:
+            by[k].append((int(r["Grid_Size"]), float(r["Counter_Value"]), r["Kernel_Name"]))
+    return by
+
+F, Wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+rows = []
+out = {}
+for k in ("riccati", "tiles", "forward"):
+    gmax = max(g for g, _, _ in F[k])
+    full_f = [v for g, v, _ in F[k] if g == gmax]
+    full_w = [v for g, v, _ in Wr[k] if g == gmax]
+    # the first full producer launch of a solve also places the static part: use the median
+    f, w = statistics.median(full_f), statistics.median(full_w)
+    rows.append([k, len(F[k]), len(full_f), f, w, int(2 * f * 1024), int(w * 1024)])
+    out[k] = (f, w, [n for g, _, n in F[k] if g == gmax][0])
+with open(ROOT / "profiles" / f"{tag}_bench_hbm_counters.csv", "w", newline="") as fh:
+    wr = csv.writer(fh)
+    wr.writerow(["kernel", "launches_in_pass", "full_window_launches", "FETCH_SIZE_KB_median_full", "WRITE_SIZE_KB_median_full",
+                 "corrected_read_bytes", "write_bytes"])
+    wr.writerows(rows)
+f, w, name = out["riccati"]
+total = 2 * f * 1024 + w * 1024
+js = {"kernel": name.split("(")[0].replace("void dpilqr::", ""), "window_items": window,
+      "FETCH_SIZE_KB_full_window_launch": f, "WRITE_SIZE_KB_full_window_launch": w,
+      "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); "
+                    "WRITE_SIZE exact for 16-B-per-lane stores",
+      "hbm_bytes_per_full_window_launch": total, "hbm_bytes_per_subproblem_pass": total / window,
+      "algorithmic_bytes_per_subproblem_pass": ALGO,
+      "source": f"profiles/{tag}_bench_hbm_counters.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
+                "bench.py --steps 8 --warmup 1 --no-cpu-baseline)"}
+(ROOT / "profiles" / "riccati_traffic.json").write_text(json.dumps(js, indent=1))
+for r in rows: print(r)
+print(json.dumps(js, indent=1))
