@@ -476,16 +476,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + col];
 #pragma unroll
             for (int kk = 0; kk < M; ++kk) {
-                int piv = kk;
-                double best = fabs(v[kk]);
+                // partial pivoting (dgetf2's idamax): a row swap is needed iff some |v[r]|, r > kk, is strictly
+                // larger than |v[kk]| in column kk.  One max per row decides that; the index search and the swap
+                // run only then (never on the bench's data: Q_uu is strongly diagonal).
+                double mx = 0.0;
 #pragma unroll
-                for (int r = kk + 1; r < M; ++r) {
-                    const double av = fabs(v[r]);
-                    piv = (av > best) ? r : piv;
-                    best = fmax(best, av);
-                }
-                piv = __builtin_amdgcn_readlane(piv, kk);
-                if (piv != kk) {
+                for (int r = kk + 1; r < M; ++r) mx = fmax(mx, fabs(v[r]));
+                const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > fabs(v[kk]));
+                if ((need >> kk) & 1ull) {
+                    int piv = kk;
+                    double best = fabs(v[kk]);
+#pragma unroll
+                    for (int r = kk + 1; r < M; ++r) {
+                        const double av = fabs(v[r]);
+                        piv = (av > best) ? r : piv;
+                        best = fmax(best, av);
+                    }
+                    piv = __builtin_amdgcn_readlane(piv, kk);
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int r = kk + 1; r < M; ++r)

@@ -249,3 +249,39 @@ def test_sweep_blocks_variant_equals_dense(dp, k, model):
         p = orc.Problem([model] * k, [2] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
         Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], float(mu[i]))
         assert relerr(Kb[i].cpu().numpy(), Ko) < TOL_PASS and relerr(db[i].cpu().numpy(), do) < TOL_PASS, i
+
+
+@pytest.mark.parametrize("k,blocks", [(5, None), (5, (4, 2)), (2, None), (3, (4, 2)), (7, None)])
+def test_sweep_row_pivoting_on_plugin_tiles(dp, k, blocks):
+    """Tiles a user plugin might hand over: Q_uu far from diagonally dominant, so dgesv's partial pivoting swaps
+    rows at most steps (the built-in costs never make it swap).  The sweep must follow the same pivots: gains
+    against the oracle's LU, and the swap count of a NumPy replay must be large (so the test tests what it says)."""
+    import scipy.linalg as sl
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7 * k + (1 if blocks else 0))
+    n, m, T, B = 4 * k, 2 * k, 6, 5
+    A = np.zeros((B, T, n, n)); Bm = np.zeros((B, T, n, m))
+    if blocks:
+        for a in range(k):
+            A[:, :, 4 * a:4 * a + 4, 4 * a:4 * a + 4] = np.eye(4) + 0.1 * rng.normal(size=(B, T, 4, 4))
+            Bm[:, :, 4 * a:4 * a + 4, 2 * a:2 * a + 2] = 0.3 * rng.normal(size=(B, T, 4, 2))
+    else:
+        A[:] = np.eye(n) + 0.1 * rng.normal(size=(B, T, n, n)) / np.sqrt(n)
+        Bm[:] = 0.3 * rng.normal(size=(B, T, n, m))
+    S = rng.normal(size=(B, T + 1, n, n)); Lxx = S @ S.transpose(0, 1, 3, 2) / n + np.eye(n)
+    Luu = rng.normal(size=(B, T + 1, m, m)) * 3.0          # not symmetric, not dominant: pivots move
+    Lux = 0.2 * rng.normal(size=(B, T + 1, m, n))
+    Lx = rng.normal(size=(B, T + 1, n)); Lu = rng.normal(size=(B, T + 1, m))
+    mu = 0.25
+    tiles = dp.pack_tiles(A, Bm, Lx, Lu, Lxx, Luu, Lux)
+    K, d = dp.backward_pass_tiles(tiles, B, T, n, m, mu, blocks=blocks)
+    K, d = K.cpu().numpy(), d.cpu().numpy()
+    swaps = 0
+    for b in range(B):
+        Ko, do = orc.backward_pass_tiles(A[b], Bm[b], Lx[b], Lu[b], Lxx[b], Luu[b], Lux[b], mu)
+        assert relerr(K[b], Ko) < 1e-8 and relerr(d[b], do) < 1e-8, b
+        P = Lxx[b, T]                                       # NumPy replay of the last step, to count the row swaps
+        Quu = Luu[b, T - 1] + Bm[b, T - 1].T @ (P + mu * np.eye(n)) @ Bm[b, T - 1]
+        _, piv = sl.lu_factor(Quu)
+        swaps += int((piv != np.arange(m)).sum())
+    assert swaps >= B                                       # rows really are exchanged
