@@ -67,6 +67,36 @@ struct MfmaCfg {
     static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
 };
 
+// fp64 vector operations whose FIRST operand is taken from lane L of the executing lane's 16-lane row (DPP
+// row_newbcast, the one DPP control the 64-bit ALU has; v_fmac_f64 and v_mov_b64 are the fp64 opcodes that take it
+// on gfx950): the LU solve's multipliers and U
+// entries reach every lane of the row inside the arithmetic instruction instead of through two v_readlane each.
+// The leading s_nop covers "VALU write of a VGPR, then a DPP read of it" (2 wait states), which the compiler's
+// hazard recogniser cannot see inside inline assembly.
+template <int L>
+__device__ __forceinline__ double dpp_fmac_row(double acc, double a, double b) {   // acc + a[lane L of the row] * b, fused
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(L));
+    return acc;
+}
+template <int L>
+__device__ __forceinline__ double dpp_mov_row(double a) {   // a[lane L of the row]
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a), "n"(L));
+    return r;
+}
+#define DPILQR_ROW_SWITCH(FN, ...)                                                                                  \
+    switch (l) {                                                                                                    \
+    case 0: return FN<0>(__VA_ARGS__); case 1: return FN<1>(__VA_ARGS__); case 2: return FN<2>(__VA_ARGS__);        \
+    case 3: return FN<3>(__VA_ARGS__); case 4: return FN<4>(__VA_ARGS__); case 5: return FN<5>(__VA_ARGS__);        \
+    case 6: return FN<6>(__VA_ARGS__); case 7: return FN<7>(__VA_ARGS__); case 8: return FN<8>(__VA_ARGS__);        \
+    case 9: return FN<9>(__VA_ARGS__); case 10: return FN<10>(__VA_ARGS__); case 11: return FN<11>(__VA_ARGS__);    \
+    case 12: return FN<12>(__VA_ARGS__); case 13: return FN<13>(__VA_ARGS__); case 14: return FN<14>(__VA_ARGS__);  \
+    default: return FN<15>(__VA_ARGS__);                                                                            \
+    }
+// `l` is a compile-time constant after unrolling at every call site: the switch folds to one instruction
+__device__ __forceinline__ double fmac_row(double acc, double a, double b, int l) { DPILQR_ROW_SWITCH(dpp_fmac_row, acc, a, b) }
+__device__ __forceinline__ double mov_row(double a, int l) { DPILQR_ROW_SWITCH(dpp_mov_row, a) }
+
 __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -210,7 +240,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         ab_dst[q] = (e < N * NM) ? sAB + row * LAB + col : sTrash;
         ab_src[q] = (e < N * NM) ? L.oA + e : 0;
     }
-    double* s3_k = (lane >= M && lane <= M + N) ? sK + (lane - M) : sT3;   // sT3 is not live during S3
+    // S3 lane layout.  ROWLU (every size instantiated today): each 16-lane row holds its own copy of the M columns of
+    // Q_uu (lanes 0..M-1 of the row) and 16-M of the n+1 right-hand sides, so that a multiplier or a U entry is
+    // always in the consuming lane's own row (DPP row broadcast) and all 64 lanes work.  Otherwise: lane = column.
+    constexpr bool ROWLU = (M < 16) && (4 * (16 - M) >= NP);
+    const int s3_q = ROWLU ? (16 - M) * g + (c16 - M) : lane - M;                 // right-hand side index
+    const bool s3_rhs = ROWLU ? (c16 >= M && s3_q < NP) : (lane >= M && lane <= M + N);
+    const int s3_col = ROWLU ? (c16 < M ? c16 : min(M + s3_q, M + N)) : (lane < M + N + 1 ? lane : M + N);
+    double* s3_k = s3_rhs ? sK + s3_q : sT3;   // sT3 is not live during S3
     static_assert((M - 1) * LK < MK * N, "S3's masked columns must fit the dead T3 buffer");
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
     int k_in[K_ROUNDS], k_out[K_ROUNDS];
@@ -470,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers (vector pipe)
         {
-            const int col = lane < M + N + 1 ? lane : M + N;
+            const int col = s3_col;
             double v[M], invd[M];
 #pragma unroll
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + col];
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                             const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
                         }
                 }
-                const double pv = readlane_f64(v[kk], kk);
+                const double pv = ROWLU ? mov_row(v[kk], kk) : readlane_f64(v[kk], kk);
                 if (pv == 0.0) sing = 1;
                 double inv = __builtin_amdgcn_rcp(pv);
                 inv = fma(fma(-pv, inv, 1.0), inv, inv);
@@ -509,16 +546,29 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 invd[kk] = inv;
 #pragma unroll
                 for (int r = kk + 1; r < M; ++r) {
-                    const double l = readlane_f64(v[r], kk) * inv;
+                    const double l = (ROWLU ? mov_row(v[r], kk) : readlane_f64(v[r], kk)) * inv;
                     v[r] = fma(-l, v[kk], v[r]);
                 }
             }
+            if constexpr (ROWLU) {
+                double nv[M];   // minus the solved rows: fma(-U, x, s) == fma(U, -x, s)
 #pragma unroll
-            for (int r = M - 1; r >= 0; --r) {
-                double s = v[r];
+                for (int r = M - 1; r >= 0; --r) {
+                    double s = v[r];
 #pragma unroll
-                for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
-                v[r] = s * invd[r];
+                    for (int c = r + 1; c < M; ++c) s = fmac_row(s, v[r], nv[c], c);
+                    nv[r] = -(s * invd[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < M; ++r) v[r] = -nv[r];
+            } else {
+#pragma unroll
+                for (int r = M - 1; r >= 0; --r) {
+                    double s = v[r];
+#pragma unroll
+                    for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
+                    v[r] = s * invd[r];
+                }
             }
 #pragma unroll
             for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];
