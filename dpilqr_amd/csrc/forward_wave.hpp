@@ -218,7 +218,17 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
     for (int i = 0; i < NC; ++i) ut[i] = 0.0;
 
+#ifdef DPILQR_PHASE_STAMPS
+    unsigned long long w_wait = 0, w_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T; ++t) {
+#ifdef DPILQR_PHASE_STAMPS
+        {
+            const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            w_wait += __builtin_amdgcn_s_memtime() - a0;
+        }
+#endif
         // K[t], d[t], dx, x' -> LDS
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
@@ -293,6 +303,12 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = xn[i];
     }
+#ifdef DPILQR_PHASE_STAMPS
+    if (g_stamp_buf && tid == 0) {
+        g_stamp_buf[2 * slot] = w_wait;
+        g_stamp_buf[2 * slot + 1] = __builtin_amdgcn_s_memtime() - w_t0;
+    }
+#endif
     if (active) {
         store_vec(Xw + (int64_t)T * n, x, NS);
         if (T > 0) store_vec(Uw + (int64_t)(T - 1) * m, ut, NC);

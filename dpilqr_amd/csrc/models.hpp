@@ -208,7 +208,13 @@ __device__ __forceinline__ double div6(double x) {
     double q = x * c;
     const double r = fma(-6.0, q, x);
     q = fma(r, c, q);
-    if (fabs(x) < 0x1p-1000 && x != 0.0) q = x / 6.0;
+    // wave-uniform test: a per-lane `if` is if-converted, i.e. the division would be evaluated every time
+    if (__builtin_amdgcn_ballot_w64(fabs(x) < 0x1p-1000 && x != 0.0) != 0ull) {
+        double xs = x;
+        asm volatile("" : "+v"(xs));   // or the compiler hoists the division above the branch it is meant to hide behind
+        const double qs = xs / 6.0;
+        if (fabs(x) < 0x1p-1000 && x != 0.0) q = qs;
+    }
     return q;
 }
 
