@@ -11,7 +11,7 @@ from time import perf_counter as pc
 import numpy as np
 
 from .control import ilqrSolver
-from .dispatch import solve_problem_list
+from .dispatch import solve_problem_list, solve_scenarios_distributed  # noqa: F401
 from .util import compute_pairwise_distance, split_graph
 
 

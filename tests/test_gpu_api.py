@@ -188,3 +188,27 @@ def test_selfish_warmstart_and_rhc(dp, golden):
     assert Xf.shape[1] == 12 and Uf.shape[0] == Xf.shape[0] and np.isfinite(Jf)
     goal = z[tag + "_xf"].reshape(3, 4)[:, :2]; start = z[tag + "_x0"].reshape(3, 4)[:, :2]; end = Xf[-1].reshape(3, 4)[:, :2]
     assert np.linalg.norm(end - goal) < np.linalg.norm(start - goal)
+
+
+@pytest.mark.parametrize("tag", ["uni5", "quad10"])
+def test_solve_scenarios_distributed_equals_per_scenario_calls(dp, golden, tag):
+    """The Monte-Carlo front end (many scenarios of one problem, array code + one device solve per cluster size)
+    must give, scenario by scenario, exactly what solve_distributed gives -- including the golden scenario, which
+    is the reference's own answer (G5)."""
+    from dpilqr_amd.dispatch import solve_scenarios_distributed
+    z = golden("g5_dispatch")
+    prob = problem_from(z, tag + "_")
+    k = len(prob.ids); ns = prob.game_cost.x_dims[0]
+    T = z[tag + "_U0"].shape[0]
+    rng = np.random.default_rng(5)
+    S = 6
+    x0 = np.tile(z[tag + "_x0"].reshape(1, -1), (S, 1))
+    jitter = rng.normal(scale=0.15, size=(S, k, ns)); jitter[:, :, 2:] = 0.0; jitter[0] = 0.0     # scenario 0 = golden
+    x0 = x0 + jitter.reshape(S, -1)
+    U0 = np.tile(z[tag + "_U0"][None], (S, 1, 1))
+    Xd, Ud, Jf, info = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5)
+    assert relerr(Xd[0], z[tag + "_X_dec"]) < TOL_SOLVE and abs(Jf[0] - z[tag + "_J_full"]) < TOL_SOLVE * abs(Jf[0])
+    assert info["n_subproblems"] == S * k and info["n_unique"] <= S * k
+    for s in range(S):
+        Xs, Us, Js, _ = dp.solve_distributed(prob, x0[s].reshape(1, -1), U0[s], 0.5, ignore_ids=[], verbose=False)
+        assert (Xd[s] == Xs).all() and (Ud[s] == Us).all() and Jf[s] == Js, s
