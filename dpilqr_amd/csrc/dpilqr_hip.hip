@@ -18,6 +18,7 @@
 #include "riccati.hpp"
 #include "riccati_mfma.hpp"
 #include "forward_wave.hpp"
+#include "riccati_wg.hpp"
 #include "riccati_tiled.hpp"
 #include "tiles.hpp"
 
@@ -145,6 +146,29 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     }
         DPILQR_TILED_SIZES(DPILQR_TRY_MFMA)
 #undef DPILQR_TRY_MFMA
+    }
+    // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
+    static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
+    if (pick == 0 && !no_wg && block_ns > 0) {
+#define DPILQR_TRY_WG(KK, NS_, NC_)                                                                                 \
+    if (block_ns == NS_ && block_nc == NC_ && n == KK * NS_ && m == KK * NC_) {                                     \
+        using WC = WgCfg<KK * NS_, KK * NC_, NS_, NC_>;                                                             \
+        static_assert(WC::supported, "workgroup sweep not available for this size");                                \
+        const size_t lds_w = sizeof(double) * WC::total;                                                            \
+        int32_t rc_w = allow_lds(k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>, lds_w);                                \
+        if (rc_w) return rc_w;                                                                                      \
+        hipLaunchKernelGGL((k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>), dim3(grid_items), dim3(kWgThreads), lds_w, \
+                           st, B, T, tiles, mu, K, d, singular, items, n_items, gains_by_item);                     \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+        // four-state models (DoubleInt4D, Unicycle4D), 6..15 agents; six-state models (DoubleInt6D, Quadcopter6D,
+        // Human6D, HumanLin6D), 2..10 agents
+        DPILQR_TRY_WG(6, 4, 2) DPILQR_TRY_WG(7, 4, 2) DPILQR_TRY_WG(8, 4, 2) DPILQR_TRY_WG(9, 4, 2) DPILQR_TRY_WG(10, 4, 2)
+        DPILQR_TRY_WG(11, 4, 2) DPILQR_TRY_WG(12, 4, 2) DPILQR_TRY_WG(13, 4, 2) DPILQR_TRY_WG(14, 4, 2) DPILQR_TRY_WG(15, 4, 2)
+        DPILQR_TRY_WG(2, 6, 3) DPILQR_TRY_WG(3, 6, 3) DPILQR_TRY_WG(4, 6, 3) DPILQR_TRY_WG(5, 6, 3) DPILQR_TRY_WG(6, 6, 3)
+        DPILQR_TRY_WG(7, 6, 3) DPILQR_TRY_WG(8, 6, 3) DPILQR_TRY_WG(9, 6, 3) DPILQR_TRY_WG(10, 6, 3)
+#undef DPILQR_TRY_WG
     }
     if (pick <= 1) {
 #define DPILQR_TRY_TILED(NN, MM)                                                                                   \

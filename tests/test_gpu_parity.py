@@ -206,7 +206,7 @@ def test_window_invariance(dp):
     assert (g["X"] == full["X"]).all().item()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 8, 12, 15])
 def test_sweep_multi_item_all_sizes(dp, k):
     """Every instantiated sweep size (and the generic kernel beyond them) on a 9-item batch with per-item mu:
     each wavefront of a packed workgroup must produce its own item's gains (regression: a masked store pattern
@@ -285,3 +285,24 @@ def test_sweep_row_pivoting_on_plugin_tiles(dp, k, blocks):
         _, piv = sl.lu_factor(Quu)
         swaps += int((piv != np.arange(m)).sum())
     assert swaps >= B                                       # rows really are exchanged
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 7, 10])
+def test_sweep_six_state_family(dp, k):
+    """The 6-state / 3-control family (Quadcopter6D; odd block sizes: no 16-byte alignment to lean on) through the
+    workgroup-per-item sweep and, for k = 1, the size-generic one: gains against the oracle, per-item mu."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    rng = np.random.default_rng(40 + k)
+    B, T = 5, 10
+    xf = rng.normal(size=(B, 6 * k)); x0 = rng.normal(size=(B, 6 * k)); U = rng.normal(size=(B, T, 3 * k)) * 0.05
+    U[:, :, 0::3] += 9.80665
+    Q, R, Qf = 50.0 * np.eye(6), np.eye(3), 1000.0 * np.eye(6)
+    pb = dp.ProblemBatch([4] * k, [3] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, _ = pb.rollout(x0, U)
+    mu = rng.uniform(0, 1, size=B)
+    K, d = pb.backward_pass(X, U, to_dev(mu))
+    for i in range(B):
+        p = orc.Problem([4] * k, [3] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
