@@ -8,7 +8,7 @@ import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libdpilqr_hip.so"
+LIB_PATH = Path(os.environ["DPILQR_LIB"]) if os.environ.get("DPILQR_LIB") else HERE / "libdpilqr_hip.so"   # override: diagnostics only
 
 i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 

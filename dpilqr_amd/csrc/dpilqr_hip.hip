@@ -19,6 +19,7 @@
 #include "riccati_mfma.hpp"
 #include "forward_wave.hpp"
 #include "riccati_wg.hpp"
+#include "tiles_wave.hpp"
 #include "riccati_tiled.hpp"
 #include "tiles.hpp"
 
@@ -92,6 +93,36 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
     static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
     if (force_dense) sparse = false;
     if (!sparse) dyn_only = false;
+    // the solve loop's producer for a batch of one model: kernels compiled per (model, agents), tiles_wave.hpp
+    static const bool no_wave = getenv("DPILQR_TILES_GENERIC") != nullptr;   // A/B switch
+    if (sparse && !no_wave && D.uniform_model > 0) {
+        const int model = D.uniform_model - 1;
+#define DPILQR_TRY_TW(MODEL, KA)                                                                                    \
+    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
+        constexpr int rpg = TilesWaveCfg<MODEL, KA, true>::RPG;                                                     \
+        const int n_groups = (D.T + 1 + rpg - 1) / rpg;                                                             \
+        const int gpw = n_groups >= 12 ? (n_groups + 3) / 4 : (n_groups + 2) / 3;   /* 3-4 wavefronts per item */   \
+        const dim3 grid_w((n_groups + gpw - 1) / gpw, grid_items);                                                  \
+        if (dyn_only) {                                                                                             \
+            const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                             \
+            hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles,   \
+                               items, n_items, gpw);                                                                \
+        } else {                                                                                                    \
+            const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, false>::total;                            \
+            hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, false>), grid_w, dim3(64), lds_w, st, D, X, U, tiles,  \
+                               items, n_items, gpw);                                                                \
+        }                                                                                                           \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+#define DPILQR_TW_AGENTS(MODEL) DPILQR_TRY_TW(MODEL, 1) DPILQR_TRY_TW(MODEL, 2) DPILQR_TRY_TW(MODEL, 3)            \
+        DPILQR_TRY_TW(MODEL, 4) DPILQR_TRY_TW(MODEL, 5) DPILQR_TRY_TW(MODEL, 6)
+        DPILQR_TW_AGENTS(kDoubleInt4D)
+        DPILQR_TW_AGENTS(kUnicycle4D)
+        DPILQR_TW_AGENTS(kQuadcopter6D)
+#undef DPILQR_TW_AGENTS
+#undef DPILQR_TRY_TW
+    }
     const int ts = make_tiles_steps(D.k, D.n_s, D.n_c);
     const size_t lds = make_tiles_lds_bytes(D.k, D.n_s, D.n_c, ts);
     dim3 grid((D.T + 1 + ts - 1) / ts, grid_items);
