@@ -226,6 +226,8 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     return DPILQR_OK;
 }
 
+static bool no_wave_ro() { static const bool v = getenv("DPILQR_FORWARD_GENERIC") != nullptr; return v; }
+
 int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
                        const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
                        const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
@@ -237,6 +239,25 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
     if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
         return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
+    if (!no_wave_ro() && mode == kModeRollout && D.uniform_model > 0 && !items) {
+        const int model = D.uniform_model - 1;
+#define DPILQR_TRY_RO(MODEL, KA)                                                                                    \
+    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
+        using WR = WaveRolloutLds<MODEL, KA>;                                                                       \
+        const int per_wg = 4 * WR::IPW;                                                                             \
+        hipLaunchKernelGGL((k_rollout_wave<MODEL, KA>), dim3((grid_items + per_wg - 1) / per_wg), dim3(256),        \
+                           sizeof(double) * WR::total * 4, st, D, x0, U, X, Jc);                                    \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+#define DPILQR_RO_AGENTS(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)            \
+        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6)
+        DPILQR_RO_AGENTS(kDoubleInt4D)
+        DPILQR_RO_AGENTS(kUnicycle4D)
+        DPILQR_RO_AGENTS(kQuadcopter6D)
+#undef DPILQR_RO_AGENTS
+#undef DPILQR_TRY_RO
+    }
     // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
     // compiled for (model, agents), see forward_wave.hpp
     static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch

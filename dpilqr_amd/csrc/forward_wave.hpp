@@ -356,4 +356,135 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
     for (int e = tid; e < T * m; e += 64) Ub[e] = Ua[e];
 }
 
+// ---- rollouts (ilqrSolver._rollout, control.py:80-93) for a batch of one model: 64 / KA sub-problems share a
+// wavefront, lane (w, a) = (sub-problem w of the wavefront, agent a).  The generic kernel gives every sub-problem a
+// wavefront of which KA lanes work; the solve starts with one rollout per item of the whole job.
+template <int MODEL, int KA>
+struct WaveRolloutLds {
+    static constexpr int NS = ModelDef<MODEL>::NS, n = KA * NS, NP = KA * (KA - 1) / 2, NP1 = NP > 0 ? NP : 1;
+    static constexpr int IPW = 64 / KA;                       // sub-problems per wavefront
+    static constexpr int oxs = 0, ocr = oxs + IPW * n, ocp = ocr + IPW * KA, total = (ocp + IPW * NP1 + 1) & ~1;
+};
+
+template <int MODEL, int KA>
+__global__ __launch_bounds__(256) void k_rollout_wave(dpilqr_batch_desc D, const double* __restrict__ x0,
+                                                      const double* __restrict__ U, double* __restrict__ X,
+                                                      double* __restrict__ Jout) {
+    using W = WaveRolloutLds<MODEL, KA>;
+    constexpr int NS = W::NS, NC = ModelDef<MODEL>::NC, n = W::n, m = KA * NC, NPAIRS = W::NP, NP1 = W::NP1, IPW = W::IPW;
+    constexpr PairTable<KA> PT{};
+    constexpr int PPL = (NPAIRS + KA - 1) / KA;
+    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = threadIdx.x & 63;
+    const bool lane_on = tid < IPW * KA;
+    const int w = lane_on ? tid / KA : 0, a = lane_on ? tid - (tid / KA) * KA : 0;
+    const int64_t b_raw = ((int64_t)blockIdx.x * 4 + sub) * IPW + w;
+    const bool active = lane_on && b_raw < D.B;
+    const int b = (int)(b_raw < D.B ? b_raw : D.B - 1);       // idle lanes shadow the last item, store nothing
+    const int T = D.T;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds = lds_all + sub * W::total;
+    double* sxs = lds + W::oxs + w * n;
+    double* scr = lds + W::ocr + w * KA;
+    double* scp = lds + W::ocp + w * NP1;
+    const ItemParams P = item_params(D, b);
+    double xf[NS], Q[NS * NS], R[NC * NC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xf[i] = P.xf[a * NS + i];
+#pragma unroll
+    for (int i = 0; i < NS * NS; ++i) Q[i] = P.Q[a * NS * NS + i];
+#pragma unroll
+    for (int i = 0; i < NC * NC; ++i) R[i] = P.R[a * NC * NC + i];
+    const double radius = P.radius;
+    bool homog = true;
+#pragma unroll
+    for (int i = 1; i < KA; ++i) homog = homog && (P.n_dims[i] == P.n_dims[0]);
+    int pi[PPL > 0 ? PPL : 1], pj[PPL > 0 ? PPL : 1], pnd[PPL > 0 ? PPL : 1];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int p = min(a + q * KA, NP1 - 1);
+        int ii = 0, jj = 0;
+#pragma unroll
+        for (int e = 0; e < NPAIRS; ++e)
+            if (e == p) { ii = PT.i[e]; jj = PT.j[e]; }
+        pi[q] = ii; pj[q] = jj;
+        pnd[q] = homog ? 2 : min(P.n_dims[ii], P.n_dims[jj]);
+    }
+    const double* Ub = U + (int64_t)b * T * m + a * NC;
+    double* Xw = X + (int64_t)b * (T + 1) * n + a * NS;
+    auto store_vec = [&](double* p, const double* v, int len) {
+        if ((len & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < len; i += 2) store_v2d_nt(p + i, v2d{v[i], v[i + 1]});
+        } else {
+#pragma unroll
+            for (int i = 0; i < len; ++i) store_f64_nt(p + i, v[i]);
+        }
+    };
+    auto stage_cost = [&](double& J) {   // pairs (combinations order), agents, then time: the reference's order
+        double prox = 0.0, ref = 0.0;
+#pragma unroll
+        for (int p = 0; p < NPAIRS; ++p) prox += scp[p];
+#pragma unroll
+        for (int i = 0; i < KA; ++i) ref += scr[i];
+        J += D.w_prox * prox + D.w_ref * ref;
+    };
+    double x[NS], u[NC], un[NC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = x0[(int64_t)b * n + a * NS + i];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) un[i] = (T > 0) ? Ub[i] : 0.0;
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        if (active) store_vec(Xw + (int64_t)t * n, x, NS);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) u[i] = un[i];
+        if (t + 1 < T) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) un[i] = Ub[(int64_t)(t + 1) * m + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
+        DPILQR_LDS_FENCE();
+        if (a == 0 && t > 0) stage_cost(J);
+        const double cr = ref_cost<NS, NC>(x, u, xf, Q, R, false);
+        double cp[PPL > 0 ? PPL : 1];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        DPILQR_LDS_FENCE();
+        scr[a] = cr;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+            if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
+        double xn[NS];
+        integrate<MODEL>(x, u, D.dt, xn);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = xn[i];
+    }
+    if (active) store_vec(Xw + (int64_t)T * n, x, NS);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
+    DPILQR_LDS_FENCE();
+    if (a == 0 && T > 0) stage_cost(J);
+    {
+        double Qf[NS * NS], uz[NC];
+#pragma unroll
+        for (int i = 0; i < NS * NS; ++i) Qf[i] = P.Qf[a * NS * NS + i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) uz[c] = 0.0;
+        const double cr = ref_cost<NS, NC>(x, uz, xf, Qf, R, true);
+        double cp[PPL > 0 ? PPL : 1];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        DPILQR_LDS_FENCE();
+        scr[a] = cr;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+            if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
+        DPILQR_LDS_FENCE();
+        if (a == 0) stage_cost(J);
+    }
+    if (active && a == 0) Jout[b] = J;
+}
+
 }  // namespace dpilqr
