@@ -324,12 +324,16 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
 // Admission, decided on the device where the exact number of survivors is known: behind the survivors
 // that the previous iteration's line search pushed, append as many not-yet-started items as fit in the
 // window, and clear the counter the NEXT iteration will push into.  ctl = {count, admitted} mailbox copy.
-__global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window) {
+__global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window,
+                        int32_t* mail) {
     const int base = *count, first = *admitted;
     const int n_new = min(B - first, window - base);
     __syncthreads();
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
-    if (threadIdx.x == 0) { *count = base + n_new; *admitted = first + n_new; *next_count = 0; }
+    if (threadIdx.x == 0) {
+        *count = base + n_new; *admitted = first + n_new; *next_count = 0;
+        mail[0] = base + n_new; mail[1] = first + n_new;   // pinned host memory: the host reads it after the event
+    }
 }
 
 __global__ void k_copy_f64(int n, const double* src, double* dst) {
@@ -377,6 +381,7 @@ int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || w
 
 struct Mailbox {  // pinned host words the device-side active counters are copied into
     int32_t* host = nullptr;
+    int32_t* dev = nullptr;   // the same words as the device sees them
     std::vector<int32_t> hist;  // exact active-list length of every global iteration of the last solve
     hipEvent_t ev[2] = {nullptr, nullptr};
     ~Mailbox() {
@@ -631,6 +636,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
 
     if (!g_mail.host) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_mail.dev), g_mail.host, 0));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[1], hipEventDisableTiming));
     }
@@ -675,7 +681,9 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
             int32_t* cur = lists + (size_t)(it & 1) * Wn;
             int32_t* cur_n = counts + (it % kCountRing);
             int32_t* nxt_n = counts + ((it + 1) % kCountRing);
-            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn);
+            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn,
+                               g_mail.dev + 2 * (it & 1));
+            HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
             S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
             S.next_count = nxt_n;
             g_prof.begin(0, it, st);
@@ -701,9 +709,6 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                 // once everything is admitted the list can only shrink: tighten the grid
                 upper = (adm >= D.B) ? std::min(Wn, std::max(act, 1)) : Wn;
             }
-            HIP_TRY(hipMemcpyAsync(g_mail.host + 2 * (it & 1), cur_n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(g_mail.host + 2 * (it & 1) + 1, admitted_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
             if (done) break;
             if (it + 1 == kMaxGlobalIter) return fail(DPILQR_EUNSUPPORTED, "solve_batch: more than %d global iterations", kMaxGlobalIter);
         }
