@@ -104,8 +104,13 @@ def tile_layout(n_x, n_u):
     return {p: (off[i], ld[i]) for i, p in enumerate(TILE_PARTS)}, stride.value
 
 
-def profile_enable(on=True):
-    return load().dpilqr_profile_enable(int(bool(on)))
+PROFILE_CLASSES = {"tiles": 1, "riccati": 2, "forward": 4, "rollout": 8}
+
+
+def profile_enable(on=True, classes=None):
+    """classes: iterable of PROFILE_CLASSES names to bracket with events (None = all)."""
+    mask = 0 if not classes else sum(PROFILE_CLASSES[c] for c in classes)
+    return load().dpilqr_profile_enable(int(bool(on)) | (mask << 1))
 
 
 def profile_read(reset=True):

@@ -395,6 +395,9 @@ thread_local Mailbox g_mail;
 // opt-in per-kernel timing (dpilqr_profile_*): event pairs recorded on the solve's own stream
 struct Profiler {
     bool on = false;
+    int mask = 0xF;   // classes that get events (0 tiles, 1 riccati, 2 forward, 3 rollout); every event pair costs a
+                      // dispatch gap, so a caller that needs one kernel's duration asks for that one only
+    bool skip = false;
     double ms[4] = {0, 0, 0, 0};
     int64_t launches[4] = {0, 0, 0, 0}, items[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> pool;
@@ -410,13 +413,14 @@ struct Profiler {
         return pool[used++];
     }
     void begin(int cls, int iter, hipStream_t st) {
-        if (!on) return;
+        skip = !on || !((mask >> cls) & 1);
+        if (skip) return;
         recs.push_back({cls, iter, used});
         hipEvent_t e = next();
         if (e) (void)hipEventRecord(e, st);
     }
     void end(hipStream_t st) {
-        if (!on) return;
+        if (skip) return;
         hipEvent_t e = next();
         if (e) (void)hipEventRecord(e, st);
     }
@@ -734,7 +738,8 @@ int32_t dpilqr_debug_stamps(void* buf) {
 
 int32_t dpilqr_profile_enable(int32_t enable) {
     const int32_t prev = g_prof.on ? 1 : 0;
-    g_prof.on = enable != 0;
+    g_prof.on = (enable & 1) != 0;
+    g_prof.mask = (enable >> 1) & 0xF ? (enable >> 1) & 0xF : 0xF;
     return prev;
 }
 

@@ -185,7 +185,9 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
  * When enabled, dpilqr_solve_batch brackets every kernel launch of its iteration loop with HIP events
  * recorded on `stream` and accumulates, per calling thread, for each kernel class c
  * (0 = tile producer, 1 = Riccati sweep, 2 = line search / forward pass, 3 = initial rollout):
- * total milliseconds, number of launches, and number of sub-problems those launches processed.      */
+ * total milliseconds, number of launches, and number of sub-problems those launches processed.
+ * enable: bit 0 = on; bits 1..4 = optional mask of the classes to bracket (0 = all).  Every bracketed launch
+ * costs a dispatch gap, so a measurement of one kernel asks for that class only.                       */
 int32_t dpilqr_profile_enable(int32_t enable);
 /* diagnostic: register (or clear with NULL) a device buffer of 4 x uint64 per sweep workgroup that receives
  * {start, end} wall-clock stamps (100 MHz) and the HW_ID / XCC_ID registers of the wave that ran it.   */
