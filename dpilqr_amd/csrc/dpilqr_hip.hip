@@ -93,34 +93,29 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
     static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
     if (force_dense) sparse = false;
     if (!sparse) dyn_only = false;
-    // the solve loop's producer for a batch of one model: kernels compiled per (model, agents), tiles_wave.hpp
+    // the solve loop's producer for a batch of one linear model whose (X, U)-independent entries are already in place:
+    // kernels compiled per (model, agents), tiles_wave.hpp.  (Measured: for the other cases -- A, B to be written too,
+    // or more than 6 agents -- the generic producer's sparse stores are the faster ones.)
     static const bool no_wave = getenv("DPILQR_TILES_GENERIC") != nullptr;   // A/B switch
-    if (sparse && !no_wave && D.uniform_model > 0) {
+    if (sparse && dyn_only && !no_wave && D.uniform_model > 0) {
         const int model = D.uniform_model - 1;
-#define DPILQR_TRY_TW(MODEL, KA)                                                                                    \
+#define DPILQR_TRY_TW(MODEL, KA, LINEAR)                                                                            \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
-        constexpr int rpg = TilesWaveCfg<MODEL, KA, true>::RPG;                                                     \
+        constexpr int rpg = TilesWaveCfg<MODEL, KA, false>::RPG;                                                    \
         const int n_groups = (D.T + 1 + rpg - 1) / rpg;                                                             \
         const int gpw = n_groups >= 12 ? (n_groups + 3) / 4 : (n_groups + 2) / 3;   /* 3-4 wavefronts per item */   \
         const dim3 grid_w((n_groups + gpw - 1) / gpw, grid_items);                                                  \
-        if (dyn_only) {                                                                                             \
-            const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                             \
-            hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles,   \
-                               items, n_items, gpw);                                                                \
-        } else {                                                                                                    \
-            const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, false>::total;                            \
-            hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, false>), grid_w, dim3(64), lds_w, st, D, X, U, tiles,  \
-                               items, n_items, gpw);                                                                \
-        }                                                                                                           \
+        const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                                 \
+        hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles, items, \
+                           n_items, gpw);                                                                           \
         HIP_TRY(hipGetLastError());                                                                                 \
         return DPILQR_OK;                                                                                           \
     }
-#define DPILQR_TW_AGENTS(MODEL) DPILQR_TRY_TW(MODEL, 1) DPILQR_TRY_TW(MODEL, 2) DPILQR_TRY_TW(MODEL, 3)            \
-        DPILQR_TRY_TW(MODEL, 4) DPILQR_TRY_TW(MODEL, 5) DPILQR_TRY_TW(MODEL, 6)
-        DPILQR_TW_AGENTS(kDoubleInt4D)
-        DPILQR_TW_AGENTS(kUnicycle4D)
-        DPILQR_TW_AGENTS(kQuadcopter6D)
-#undef DPILQR_TW_AGENTS
+#define DPILQR_TW_6(MODEL, LINEAR) DPILQR_TRY_TW(MODEL, 1, LINEAR) DPILQR_TRY_TW(MODEL, 2, LINEAR)                  \
+        DPILQR_TRY_TW(MODEL, 3, LINEAR) DPILQR_TRY_TW(MODEL, 4, LINEAR) DPILQR_TRY_TW(MODEL, 5, LINEAR)             \
+        DPILQR_TRY_TW(MODEL, 6, LINEAR)
+        DPILQR_TW_6(kDoubleInt4D, true)
+#undef DPILQR_TW_6
 #undef DPILQR_TRY_TW
     }
     const int ts = make_tiles_steps(D.k, D.n_s, D.n_c);
@@ -250,12 +245,16 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
         HIP_TRY(hipGetLastError());                                                                                 \
         return DPILQR_OK;                                                                                           \
     }
-#define DPILQR_RO_AGENTS(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)            \
-        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6)
-        DPILQR_RO_AGENTS(kDoubleInt4D)
-        DPILQR_RO_AGENTS(kUnicycle4D)
-        DPILQR_RO_AGENTS(kQuadcopter6D)
-#undef DPILQR_RO_AGENTS
+#define DPILQR_RO_10(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)                \
+        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6) DPILQR_TRY_RO(MODEL, 7)             \
+        DPILQR_TRY_RO(MODEL, 8) DPILQR_TRY_RO(MODEL, 9) DPILQR_TRY_RO(MODEL, 10)
+#define DPILQR_RO_15(MODEL) DPILQR_RO_10(MODEL) DPILQR_TRY_RO(MODEL, 11) DPILQR_TRY_RO(MODEL, 12)                   \
+        DPILQR_TRY_RO(MODEL, 13) DPILQR_TRY_RO(MODEL, 14) DPILQR_TRY_RO(MODEL, 15)
+        DPILQR_RO_15(kDoubleInt4D)
+        DPILQR_RO_15(kUnicycle4D)
+        DPILQR_RO_10(kQuadcopter6D)
+#undef DPILQR_RO_15
+#undef DPILQR_RO_10
 #undef DPILQR_TRY_RO
     }
     // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
