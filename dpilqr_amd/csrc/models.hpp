@@ -60,7 +60,9 @@ template <> struct ModelDef<kDoubleInt6D> {  // x=[p(3),v(3)] u=[a(3)]
 template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
     static constexpr int NS = 3, NC = 2;
     __device__ static void f(const double* x, const double* u, double* o) {
-        o[0] = u[0] * cos(x[2]); o[1] = u[0] * sin(x[2]); o[2] = u[1];
+        double sn, cs;
+        sincos(x[2], &sn, &cs);
+        o[0] = u[0] * cs; o[1] = u[0] * sn; o[2] = u[1];
     }
     __device__ static void jac(const double* x, const double* u, double* A, double* B) {
         const double s = sin(x[2]), c = cos(x[2]);
@@ -72,7 +74,9 @@ template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
 template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
     static constexpr int NS = 4, NC = 2;
     __device__ static void f(const double* x, const double* u, double* o) {
-        o[0] = x[2] * cos(x[3]); o[1] = x[2] * sin(x[3]); o[2] = u[0]; o[3] = u[1];
+        double sn, cs;
+        sincos(x[3], &sn, &cs);   // one argument reduction for both (same values as sin(), cos())
+        o[0] = x[2] * cs; o[1] = x[2] * sn; o[2] = u[0]; o[3] = u[1];
     }
     __device__ static void jac(const double* x, const double*, double* A, double* B) {
         const double s = sin(x[3]), c = cos(x[3]);
