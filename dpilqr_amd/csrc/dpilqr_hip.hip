@@ -264,20 +264,25 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
         const int model = D.uniform_model - 1;
 #define DPILQR_TRY_WAVE(MODEL, KA)                                                                                  \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
-        const size_t lds_w = sizeof(double) * WaveFwdLds<MODEL, KA>::total * kWaveFwdItems;                         \
+        using WF = WaveFwdLds<MODEL, KA>;                                                                           \
+        const size_t lds_w = sizeof(double) * WF::total * WF::IPB;                                                  \
         int32_t rc_w = allow_lds(k_linesearch_wave<MODEL, KA>, lds_w);                                              \
         if (rc_w) return rc_w;                                                                                      \
-        hipLaunchKernelGGL((k_linesearch_wave<MODEL, KA>), dim3((grid_items + kWaveFwdItems - 1) / kWaveFwdItems),  \
-                           dim3(64 * kWaveFwdItems), lds_w, st, D, X, U, K, d, alphas, Xc, Uc, S, items, n_items);  \
+        hipLaunchKernelGGL((k_linesearch_wave<MODEL, KA>), dim3((grid_items + WF::IPB - 1) / WF::IPB),              \
+                           dim3(64 * WF::NW * WF::IPB), lds_w, st, D, X, U, K, d, alphas, Xc, Uc, S, items, n_items); \
         HIP_TRY(hipGetLastError());                                                                                 \
         return DPILQR_OK;                                                                                           \
     }
-#define DPILQR_WAVE_AGENTS(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)    \
-        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6)
-        DPILQR_WAVE_AGENTS(kDoubleInt4D)
-        DPILQR_WAVE_AGENTS(kUnicycle4D)
-        DPILQR_WAVE_AGENTS(kQuadcopter6D)
-#undef DPILQR_WAVE_AGENTS
+#define DPILQR_WAVE_10(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)        \
+        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6) DPILQR_TRY_WAVE(MODEL, 7)     \
+        DPILQR_TRY_WAVE(MODEL, 8) DPILQR_TRY_WAVE(MODEL, 9) DPILQR_TRY_WAVE(MODEL, 10)
+#define DPILQR_WAVE_15(MODEL) DPILQR_WAVE_10(MODEL) DPILQR_TRY_WAVE(MODEL, 11) DPILQR_TRY_WAVE(MODEL, 12)           \
+        DPILQR_TRY_WAVE(MODEL, 13) DPILQR_TRY_WAVE(MODEL, 14) DPILQR_TRY_WAVE(MODEL, 15)
+        DPILQR_WAVE_15(kDoubleInt4D)
+        DPILQR_WAVE_15(kUnicycle4D)
+        DPILQR_WAVE_10(kQuadcopter6D)
+#undef DPILQR_WAVE_15
+#undef DPILQR_WAVE_10
 #undef DPILQR_TRY_WAVE
     }
     // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp

@@ -99,31 +99,40 @@ struct WaveFwdLds {
     static constexpr int od = oK + m * n;                          // d[t]  m
     static constexpr int odx = (od + m + 1) & ~1;                  // dx    [g][n]
     static constexpr int oxs = odx + DPILQR_N_ALPHA * n;           // x'    [g][n]
-    static constexpr int ocr = oxs + DPILQR_N_ALPHA * n;           // ref cost  [g][KA]
-    static constexpr int ocp = ocr + DPILQR_N_ALPHA * KA;          // pair cost [g][NP1]
-    static constexpr int oJ = ocp + DPILQR_N_ALPHA * NP1;          // J [g]
+    static constexpr int ocr = oxs + DPILQR_N_ALPHA * n;           // ref cost  [parity][g][KA]
+    static constexpr int ocp = ocr + 2 * DPILQR_N_ALPHA * KA;      // pair cost [parity][g][NP1]
+    static constexpr int oJ = ocp + 2 * DPILQR_N_ALPHA * NP1;      // J [g]
+    static constexpr int NW = (KA * DPILQR_N_ALPHA + 63) / 64;     // wavefronts per sub-problem
+    static constexpr int IPB = NW == 1 ? 4 : 1;                    // sub-problems per workgroup
     static constexpr int octl = oJ + DPILQR_N_ALPHA;
     static constexpr int total = (octl + 2 + 1) & ~1;
 };
 
-constexpr int kWaveFwdItems = 4;   // wavefronts (= sub-problems) per workgroup, one per SIMD
+// NW = 1 (k * 10 <= 64 lanes): four sub-problems per workgroup, one wavefront each, no barriers.  NW = 2, 3 (7..15
+// agents): one sub-problem per workgroup; its wavefronts meet at two s_barriers per step (staged data written /
+// everybody done reading it) and the per-step cost slots alternate by parity, because a candidate's lanes can
+// straddle two wavefronts.
+template <int NW>
+__device__ __forceinline__ void wave_sync() {
+    if constexpr (NW == 1) asm volatile("" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int MODEL, int KA>
-__global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
+__global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL, KA>::IPB), 2) void k_linesearch_wave(
     dpilqr_batch_desc D, double* X, double* U, const double* __restrict__ K, const double* __restrict__ d,
     const double* __restrict__ alphas, double* Xc, double* Uc, SolveState S, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items) {
     using W = WaveFwdLds<MODEL, KA>;
     constexpr int NS = W::NS, NC = W::NC, n = W::n, m = W::m, mn = m * n, NPAIRS = W::NP, NP1 = W::NP1;
     constexpr int NG = DPILQR_N_ALPHA;
-    static_assert(KA * NG <= 64, "one wavefront per sub-problem");
-    constexpr PairTable<KA> PT{};
+    constexpr int NW = W::NW, NTH = 64 * NW;
     constexpr int PPL = (NPAIRS + KA - 1) / KA;          // pair costs per agent lane (round-robin deal)
-    constexpr int KV = (mn / 2 + 63) / 64;               // v2d of K[t] a lane stages (mn is even: NC*NS*KA*KA)
+    constexpr int KV = (mn / 2 + NTH - 1) / NTH;         // v2d of K[t] a lane stages (mn is even: NC*NS*KA*KA)
 
-    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tid = threadIdx.x & 63;
-    const int slot = blockIdx.x * kWaveFwdItems + sub;
+    const int sub = NW == 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int slot = blockIdx.x * W::IPB + sub;
     if (slot >= *n_items) return;
     const int b = items[slot];
     const int T = D.T;
@@ -161,10 +170,9 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         const int p = min(a + q * KA, NP1 - 1);
-        int ii = 0, jj = 0;
-#pragma unroll
-        for (int e = 0; e < NPAIRS; ++e)
-            if (e == p) { ii = PT.i[e]; jj = PT.j[e]; }
+        int ii = 0, rem = p;                              // p-th pair of itertools.combinations(range(KA), 2)
+        while (rem >= KA - 1 - ii) { rem -= KA - 1 - ii; ++ii; }
+        const int jj = ii + 1 + rem;
         pi[q] = ii; pj[q] = jj;
         pnd[q] = homog ? 2 : min(P.n_dims[ii], P.n_dims[jj]);
     }
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
     double* sd = lds + W::od;
     double* sdx = lds + W::odx + g * n;
     double* sxs = lds + W::oxs + g * n;
-    double* scr = lds + W::ocr + g * KA;
-    double* scp = lds + W::ocp + g * NP1;
+    double* scr0 = lds + W::ocr + g * KA;            // + parity * NG * KA
+    double* scp0 = lds + W::ocp + g * NP1;           // + parity * NG * NP1
 
     // ---- step data: registers <- HBM one step ahead
     v2d stK[KV];
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
         const double* Kt = Kb + (int64_t)t * mn;
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
-            const int e = min(tid + 64 * q, mn / 2 - 1);
+            const int e = min(tid + NTH * q, mn / 2 - 1);
             stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
         }
         std_ = db[(int64_t)t * m + min(tid, m - 1)];
@@ -201,13 +209,23 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
             for (int i = 0; i < len; ++i) store_f64_nt(p + i, v[i]);
         }
     };
-    auto stage_cost = [&](double& J) {   // summed in the reference's order: pairs (combinations order), agents, time
+    auto stage_cost = [&](double& J, int par) {   // summed in the reference's order: pairs (combinations order), agents, time
+        const double* scp = scp0 + par * NG * NP1;
+        const double* scr = scr0 + par * NG * KA;
         double prox = 0.0, ref = 0.0;
 #pragma unroll
         for (int p = 0; p < NPAIRS; ++p) prox += scp[p];
 #pragma unroll
         for (int i = 0; i < KA; ++i) ref += scr[i];
         J += D.w_prox * prox + D.w_ref * ref;
+    };
+    auto post_costs = [&](double cr, const double* cp, int par) {
+        if (active) {
+            scr0[par * NG * KA + a] = cr;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q)
+                if (a + q * KA < NPAIRS) scp0[par * NG * NP1 + a + q * KA] = cp[q];
+        }
     };
 
 #pragma unroll
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
         // K[t], d[t], dx, x' -> LDS
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
-            const int e = min(tid + 64 * q, mn / 2 - 1);
+            const int e = min(tid + NTH * q, mn / 2 - 1);
             *reinterpret_cast<v2d*>(sK + 2 * e) = stK[q];
         }
         if (tid < m) sd[tid] = std_;
@@ -252,9 +270,9 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
                 sxs[a * NS + i] = x[i];
             }
         }
-        DPILQR_LDS_FENCE();
+        wave_sync<NW>();
         if (t + 1 < T) fetch(t + 1);
-        if (a == 0 && t > 0) stage_cost(J);          // stage cost of step t-1
+        if (a == 0 && t > 0) stage_cost(J, (t & 1) ^ 1);   // stage cost of step t-1
         DPILQR_LDS_FENCE();
         // du = K[t] dx + alpha d[t] (control.py:106): this agent's NC rows, j ascending
         {
@@ -292,16 +310,12 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
         DPILQR_LDS_FENCE();
-        if (active) {
-            scr[a] = cr;
-#pragma unroll
-            for (int q = 0; q < PPL; ++q)
-                if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
-        }
+        post_costs(cr, cp, t & 1);
         double xn[NS];
         integrate<MODEL>(x, ut, D.dt, xn);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = xn[i];
+        wave_sync<NW>();   // everybody is done with this step's staged K, d, dx, x'
     }
 #ifdef DPILQR_PHASE_STAMPS
     if (g_stamp_buf && tid == 0) {
@@ -319,8 +333,8 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
             for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
         }
-        DPILQR_LDS_FENCE();
-        if (a == 0 && T > 0) stage_cost(J);
+        wave_sync<NW>();
+        if (a == 0 && T > 0) stage_cost(J, (T & 1) ^ 1);
         double Qf[NS * NS], uz[NC];
 #pragma unroll
         for (int i = 0; i < NS * NS; ++i) Qf[i] = P.Qf[a * NS * NS + i];
@@ -331,29 +345,26 @@ __global__ __launch_bounds__(64 * kWaveFwdItems, 2) void k_linesearch_wave(
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
         DPILQR_LDS_FENCE();
-        if (active) {
-            scr[a] = cr;
-#pragma unroll
-            for (int q = 0; q < PPL; ++q)
-                if (a + q * KA < NPAIRS) scp[a + q * KA] = cp[q];
-        }
-        DPILQR_LDS_FENCE();
-        if (a == 0) stage_cost(J);
+        post_costs(cr, cp, T & 1);
+        wave_sync<NW>();
+        if (a == 0) stage_cost(J, T & 1);
     }
     if (active && a == 0) lds[W::oJ + g] = J;
     // the candidates' trajectory stores (issued behind the compiler's back) must have landed before the copy below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    wave_sync<NW>();
     int* ctl = reinterpret_cast<int*>(lds + W::octl);
     if (tid == 0) ctl[0] = linesearch_decide(S, b, NG, lds + W::oJ);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    wave_sync<NW>();
     const int acc = ctl[0];
     if (acc < 0) return;
     // accepted: X, U <- the accepted candidate's trajectory (a coalesced copy out of the scratch)
     const double* Xa = Xc + ((int64_t)slot * NG + acc) * (int64_t)(T + 1) * n;
     const double* Ua = Uc + ((int64_t)slot * NG + acc) * (int64_t)T * m;
-    for (int e = tid; e < (T + 1) * n; e += 64) Xb[e] = Xa[e];
-    for (int e = tid; e < T * m; e += 64) Ub[e] = Ua[e];
+    for (int e = tid; e < (T + 1) * n; e += NTH) Xb[e] = Xa[e];
+    for (int e = tid; e < T * m; e += NTH) Ub[e] = Ua[e];
 }
 
 // ---- rollouts (ilqrSolver._rollout, control.py:80-93) for a batch of one model: 64 / KA sub-problems share a
