@@ -72,7 +72,7 @@ def pairwise_graph(X, radius, k, n_s):
     return adj
 
 
-def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, **kwargs):
+def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, concurrent=True, **kwargs):
     """solve_distributed (distributed.py:25-103) for S scenarios of ONE k-agent problem at once -- the Monte-Carlo
     front end (scripts/analysis.py:126-174 runs it seed by seed).  Everything between the interaction graph and
     the stitched trajectories is array code: no per-sub-problem Python objects, one windowed device solve per
@@ -104,22 +104,37 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, **k
     X_dec = np.zeros((S, T + 1, k * n_s)); U_dec = np.zeros((S, T, k * n_c))
     X0 = X[:, 0].reshape(S, k, n_s); Uk = U.reshape(S, T, k, n_c); xfk = xf.reshape(S, k, n_s)
     agent_of = np.arange(k)
-    n_bwd_total = 0
-    for kc in np.unique(u_size):
+
+    def solve_bucket(kc):
+        """All distinct sub-problems with kc agents: one windowed device solve, on this thread's own stream."""
         sel = np.nonzero(u_size == kc)[0]                                                 # sub-problems of this size
         members = np.nonzero(u_mask[sel])[1].reshape(len(sel), kc)                        # sorted agent ids, (Bk, kc)
-        s_of = u_s[sel]
-        rows = s_of[:, None]
-        pb = ProblemBatch(d["model"][members], d["n_dims"][members], xfk[rows, members].reshape(len(sel), kc * n_s),
-                          d["Q"][members], d["R"][members], d["Qf"][members], d["radius"], d["dt"], T,
-                          w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(sel))
-        x0 = X0[rows, members].reshape(len(sel), kc * n_s)
-        U0 = Uk[rows, :, members]                                                         # (Bk, kc, T, n_c)
-        U0 = np.ascontiguousarray(np.transpose(U0, (0, 2, 1, 3))).reshape(len(sel), T, kc * n_c)
-        r = pb.solve(x0, U0, window=window, **solve_kw)
-        Xs = r["X"].cpu().numpy().reshape(len(sel), T + 1, kc, n_s)
-        Us = r["U"].cpu().numpy().reshape(len(sel), T, kc, n_c)
-        n_bwd_total += int(r["n_bwd"].sum().item())
+        rows = u_s[sel][:, None]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pb = ProblemBatch(d["model"][members], d["n_dims"][members], xfk[rows, members].reshape(len(sel), kc * n_s),
+                              d["Q"][members], d["R"][members], d["Qf"][members], d["radius"], d["dt"], T,
+                              w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(sel))
+            x0 = X0[rows, members].reshape(len(sel), kc * n_s)
+            U0 = Uk[rows, :, members]                                                     # (Bk, kc, T, n_c)
+            U0 = np.ascontiguousarray(np.transpose(U0, (0, 2, 1, 3))).reshape(len(sel), T, kc * n_c)
+            r = pb.solve(x0, U0, window=window, **solve_kw)
+            Xs = r["X"].cpu().numpy().reshape(len(sel), T + 1, kc, n_s)
+            Us = r["U"].cpu().numpy().reshape(len(sel), T, kc, n_c)
+            return sel, Xs, Us, int(r["n_bwd"].sum().item())
+
+    # buckets are independent and, for a handful of scenarios, small: their solves run concurrently, each on its own
+    # HIP stream from its own host thread (the library keeps its per-solve state per thread)
+    sizes = [int(v) for v in np.unique(u_size)]
+    torch.cuda.synchronize()
+    if concurrent and len(sizes) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(sizes))) as pool:
+            results = list(pool.map(solve_bucket, sizes))
+    else:
+        results = [solve_bucket(kc) for kc in sizes]
+    n_bwd_total = 0
+    for sel, Xs, Us, nb in results:
+        n_bwd_total += nb
         # 3. stitch: agent i of scenario s takes ITS columns of the sub-problem solved for its neighbourhood
         local = np.full(len(uniq), -1, dtype=np.int64); local[sel] = np.arange(len(sel))
         owner_s, owner_i = np.nonzero(local[inverse] >= 0)
