@@ -16,9 +16,13 @@ fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 window = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 ALGO = 619360  # bytes per sub-problem backward pass, bench.py
 
+seen_wave_producer = 'k_make_tiles_wave' in open(fetch_csv).read()
+
+
 def short(name):
     if "k_riccati" in name: return "riccati"
-    if "k_make_tiles" in name: return "tiles"
+    if "k_make_tiles_wave" in name: return "tiles"
+    if "k_make_tiles" in name: return "tiles_static" if seen_wave_producer else "tiles"
     if "k_linesearch_wave" in name or "k_forward" in name: return "forward"
     return None
 
@@ -33,7 +37,7 @@ def load(path, counter):
 F, Wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
 rows = []
 out = {}
-for k in ("riccati", "tiles", "forward"):
+for k in [c for c in ("riccati", "tiles", "tiles_static", "forward") if c in F]:
     gmax = max(g for g, _, _ in F[k])
     full_f = [v for g, v, _ in F[k] if g == gmax]
     full_w = [v for g, v, _ in Wr[k] if g == gmax]
