@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events in the timed run "
                     "(per-kernel breakdown; costs ~4 %% of throughput in dispatch gaps) instead of the Riccati sweep only")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
 
     import torch

@@ -54,7 +54,7 @@ int32_t check_desc(const dpilqr_batch_desc* d) {
     if (d->k > kMaxAgents) return fail(DPILQR_EUNSUPPORTED, "k=%d agents per sub-problem exceeds %d", d->k, kMaxAgents);
     if (family_nc(d->n_s) != d->n_c)
         return fail(DPILQR_EINVAL, "(n_s,n_c)=(%d,%d) is not a model family; expected (3,2),(4,2),(6,3),(12,4)", d->n_s, d->n_c);
-    if (!d->model || !d->n_dims || !d->xf || !d->Q || !d->R || !d->Qf || !d->radius)
+    if (d->B > 0 && (!d->model || !d->n_dims || !d->xf || !d->Q || !d->R || !d->Qf || !d->radius))   // an empty batch owns nothing
         return fail(DPILQR_EINVAL, "desc holds a NULL device pointer");
     return DPILQR_OK;
 }
@@ -543,6 +543,7 @@ int32_t dpilqr_rollout(const dpilqr_batch_desc* desc, const double* x0, const do
                        void* stream) {
     int32_t rc = check_desc(desc);
     if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
     if (!x0 || !U || !X || !J) return fail(DPILQR_EINVAL, "rollout: NULL pointer");
     SolveState S{};
     return launch_forward(*desc, kModeRollout, x0, X, const_cast<double*>(U), nullptr, nullptr, nullptr, 1, nullptr,
@@ -611,6 +612,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                            void* stream) {
     int32_t rc = check_desc(desc);
     if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;   // an empty batch: nothing to read or write
     if (!x0 || !U || !X || !J || !status || !n_bwd || !n_fwd || !workspace)
         return fail(DPILQR_EINVAL, "solve_batch: NULL pointer");
     if ((K_out == nullptr) != (d_out == nullptr)) return fail(DPILQR_EINVAL, "solve_batch: K_out and d_out go together");

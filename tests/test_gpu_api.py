@@ -212,3 +212,35 @@ def test_solve_scenarios_distributed_equals_per_scenario_calls(dp, golden, tag):
     for s in range(S):
         Xs, Us, Js, _ = dp.solve_distributed(prob, x0[s].reshape(1, -1), U0[s], 0.5, ignore_ids=[], verbose=False)
         assert (Xd[s] == Xs).all() and (Ud[s] == Us).all() and Jf[s] == Js, s
+
+
+def test_edge_cases_empty_batch_short_horizon_no_iterations(dp):
+    """The corners the reference's API allows: an empty batch, a one-step horizon, n_lqr_iter = 0 (solve() then
+    returns the rollout of the warm start, control.py:164-168), a window of one, and a bad argument's error code."""
+    from oracle import oracle as orc
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    rng = np.random.default_rng(3)
+    # empty batch
+    pb0 = dp.ProblemBatch([0, 0], [2, 2], np.zeros((0, 8)), Q, R, Qf, 0.5, 0.1, 5, B=0)
+    r0 = pb0.solve(np.zeros((0, 8)), np.zeros((0, 5, 4)))
+    assert r0["X"].shape == (0, 6, 8) and r0["J"].shape == (0,)
+    # one-step horizon, two agents, against the oracle
+    B, T, k = 3, 1, 2
+    xf = rng.normal(size=(B, 4 * k)); x0 = rng.normal(size=(B, 4 * k))
+    pb = dp.ProblemBatch([0] * k, [2] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    r = pb.solve(x0, np.zeros((B, T, 2 * k)), trace=True)
+    proto = orc.Problem([0] * k, [2] * k, xf[0], Q, R, Qf, 0.5, 0.1, T)
+    o = orc.solve_batch(proto, x0, xf, np.zeros((B, T, 2 * k)))
+    assert relerr(r["X"].cpu().numpy(), o["X"]) < TOL_SOLVE and (r["n_bwd"].cpu().numpy() == o["n_bwd"]).all()
+    # n_lqr_iter = 0: the rollout of the warm start, no backward pass
+    U0 = rng.normal(size=(B, T, 2 * k)) * 0.1
+    rz = pb.solve(x0, U0, n_lqr_iter=0)
+    Xr, Jr = pb.rollout(x0, U0)
+    assert (rz["X"] == Xr).all().item() and (rz["n_bwd"] == 0).all().item() and relerr(rz["J"].cpu().numpy(), Jr.cpu().numpy()) < 1e-14
+    # a window of one sub-problem in flight
+    r1 = pb.solve(x0, np.zeros((B, T, 2 * k)), window=1)
+    assert (r1["X"] == r["X"]).all().item()
+    # errors come back as codes + message, never as a crash
+    lib = dp._lib.load()
+    assert lib.dpilqr_backward_pass_tiles(1, 0, 4, 2, None, None, None, None, None, None, None, None) == -1   # DPILQR_EINVAL
+    assert b"bad sizes" in lib.dpilqr_last_error()
