@@ -67,3 +67,39 @@ def gather_results(r, group=None, pad_to=None):
     res = unpack_results(out, r["X"].shape[1:], r["U"].shape[1:])
     res["rows_per_rank"] = pad_to
     return res
+
+
+def solve_scenarios_sharded(problem, X, U, radius, xf=None, group=None, solver=None, device=None, **kwargs):
+    """cfg4's shape of run: S Monte-Carlo scenarios of one k-agent problem sharded over the ranks (one process per GPU),
+    each rank running the many-scenario front end (dispatch.solve_scenarios_distributed) on its contiguous slice, then
+    the path's one collective: an all-gather of the stitched (X_dec, U_dec, J_full) rows.  Every rank returns the
+    full arrays in scenario order.
+
+    solver(problem, X, U, radius, xf=..., **kwargs) -> (X_dec, U_dec, J, info): injectable for CPU tests of the
+    sharding / gather plumbing; device: where the gathered rows live (default: cuda if the backend is nccl)."""
+    if solver is None:
+        from .dispatch import solve_scenarios_distributed as solver
+    X = np.asarray(X, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
+    S = X.shape[0]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(S, world, rank)
+    xf_l = None if xf is None else np.asarray(xf, dtype=np.float64)[lo:hi]
+    if hi > lo:
+        Xd, Ud, J, info = solver(problem, X[lo:hi], U[lo:hi], radius, xf=xf_l, **kwargs)
+    else:   # more ranks than scenarios: this rank only takes part in the collective
+        T, n_u = U.shape[1], U.shape[2]
+        Xd, Ud, J, info = np.zeros((0, T + 1, X.shape[2])), np.zeros((0, T, n_u)), np.zeros((0,)), {}
+    pad = max(b - a for a, b in (shard_bounds(S, world, r) for r in range(world)))
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    nx, nu = int(np.prod(Xd.shape[1:])), int(np.prod(Ud.shape[1:]))
+    rows = torch.cat([torch.as_tensor(Xd).reshape(hi - lo, nx), torch.as_tensor(Ud).reshape(hi - lo, nu),
+                      torch.as_tensor(J).reshape(hi - lo, 1)], dim=1)
+    rows = torch.cat([rows, rows.new_zeros((pad - (hi - lo), rows.shape[1]))], dim=0).to(device).contiguous()
+    out = rows.new_empty((world * pad, rows.shape[1]))
+    dist.all_gather_into_tensor(out, rows, group=group)
+    keep = torch.cat([torch.arange(r * pad, r * pad + (b - a)) for r, (a, b) in
+                      enumerate(shard_bounds(S, world, r) for r in range(world))]).to(out.device)
+    out = out[keep].cpu().numpy()
+    return (out[:, :nx].reshape((S,) + Xd.shape[1:]), out[:, nx:nx + nu].reshape((S,) + Ud.shape[1:]), out[:, nx + nu],
+            dict(local=info, shard=(lo, hi)))
