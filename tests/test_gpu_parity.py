@@ -306,3 +306,25 @@ def test_sweep_six_state_family(dp, k):
         p = orc.Problem([4] * k, [3] * k, xf[i], Q, R, Qf, 0.5, 0.1, T)
         Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_sweep_twelve_state_family(dp, k):
+    """Quadcopter12D clusters (n_x = 12 k) through the workgroup-per-item sweep (k >= 2) and the size-generic one
+    (k = 1): gains against the oracle."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    rng = np.random.default_rng(70 + k)
+    B, T = 3, 8
+    xf = rng.normal(size=(B, 12 * k)) * 0.3; x0 = xf + rng.normal(size=(B, 12 * k)) * 0.05
+    U = rng.normal(size=(B, T, 4 * k)) * 1e-3
+    U[:, :, 3::4] += 9.80665 * 63.0 / 2000.0
+    Q, R, Qf = np.eye(12), np.eye(4), 100.0 * np.eye(12)
+    pb = dp.ProblemBatch([7] * k, [3] * k, xf, Q, R, Qf, 0.5, 0.05, T)
+    X, _ = pb.rollout(x0, U)
+    mu = rng.uniform(0, 1, size=B)
+    K, d = pb.backward_pass(X, U, to_dev(mu))
+    for i in range(B):
+        p = orc.Problem([7] * k, [3] * k, xf[i], Q, R, Qf, 0.5, 0.05, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
