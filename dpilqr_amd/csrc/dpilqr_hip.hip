@@ -156,7 +156,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
 #define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
     if (n == NN && m == MM) {                                                                                      \
         static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
-        static const int stagger = getenv("DPILQR_STAGGER") ? atoi(getenv("DPILQR_STAGGER")) : 100;                \
+        const int stagger = 100;   /* second wavefront of a SIMD starts half a step late (measured: no effect) */   \
         static const bool no8 = getenv("DPILQR_MFMA_WAVES4") != nullptr;                                           \
         const bool w8 = !no8 && grid_items > 1024;   /* enough items for two waves per SIMD */                     \
         const int wv = w8 ? 8 : 4;                                                                                 \

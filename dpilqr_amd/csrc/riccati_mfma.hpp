@@ -1,28 +1,30 @@
-// riccati_mfma.hpp -- K2 on the matrix pipe: the Riccati backward sweep with one wavefront per sub-problem
-// and every dense product issued as v_mfma_f64_16x16x4_f64 (ilqrSolver._backward_pass, control.py:116-148).
+// riccati_mfma.hpp -- K2 for n_x <= 20: the Riccati backward sweep with one wavefront per sub-problem, two per
+// SIMD (ilqrSolver._backward_pass, control.py:116-148).  The dominant kernel of the cfg2 benchmark.
 //
-// Why MFMA for 20-wide matrices: measured on MI355X (scripts/ubench/mfma_f64.hip) the fp64 MFMA delivers the
-// SAME peak FMA rate as the vector ALU (64 cycles per 16x16x4 instruction per SIMD = 16 FMA/clk), so padding
-// 20 -> 32 costs arithmetic efficiency -- but the VALU sweep (riccati_tiled.hpp) is bound by instruction
-// ISSUE, not by arithmetic: 1226 FMA + 294 LDS-read instructions per step.  One MFMA replaces 16 vector FMAs
-// and their operand reads with a single issue slot and two 8-byte LDS reads, and the matrix pipe runs beside
-// the vector pipe, which is left with the pivoted LU solve.  Per step at cfg2: 70 MFMAs + 73 operand reads.
+// Data flow, LDS residency and record prefetching are those of riccati_tiled.hpp (the previous, all-vector-pipe
+// version, kept as a fallback).  What differs:
 //
-// Data flow, LDS residency, prefetching, the in-register pivoted LU and the four-waves-per-workgroup packing
-// are those of riccati_tiled.hpp; only the products differ.  Every product has the form
-//     C[i][j] = sum_l X[l][i] * Y[l][j]
-// with X, Y row-major in LDS (rows = reduction index), which is the MFMA operand order:
-//     lane (g = lane/16, c = lane%16) supplies A = X[l0+g][i0+c], B = Y[l0+g][j0+c]  (4 reduction rows per MFMA)
-//     and owns D[i0 + g + 4v][j0 + c], v = 0..3   (layout verified by the micro-benchmark).
-// So every LDS / HBM address of a D element is  (lane term) + (compile-time tile/v term): no address tables;
-// what a lane may store is decided by a few lane predicates (column in range) and compile-time row ranges.
-// Reduction lengths that are not multiples of 4 (n_u = 10 -> 12) read zero rows kept at the end of [K|d].
-// Reads past a row's logical width wrap into finite neighbouring data and only feed outputs that are dropped.
+//  * the dense products are v_mfma_f64_16x16x4_f64 tiles.  Measured on MI355X (scripts/ubench/mfma_f64.hip): the
+//    fp64 MFMA delivers the SAME peak FMA rate as the vector ALU (64 cycles per instruction per SIMD = 16 FMA/clk)
+//    and shares that pipe, so it buys issue slots and operand reads (one MFMA replaces 16 vector FMAs and their LDS
+//    reads), not arithmetic time.  Every product has the form  C[i][j] = sum_l X[l][i] * Y[l][j]  with X, Y row-major
+//    in LDS (rows = reduction index), which is the MFMA operand order:
+//        lane (g = lane/16, c = lane%16) supplies A = X[l0+g][i0+c], B = Y[l0+g][j0+c]  (4 reduction rows per MFMA)
+//        and owns D[i0 + g + 4v][j0 + c], v = 0..3   (layout verified by the micro-benchmark).
+//    So every LDS address of a D element is (lane term) + (compile-time tile/v term); what a lane may store is decided
+//    by a few lane predicates and compile-time row ranges.  Reduction lengths that are not multiples of 4 (n_u = 10
+//    -> 12) read zero rows kept at the end of [K|d]; reads past a row's logical width wrap into finite neighbouring
+//    data and only feed outputs that are dropped.
+//  * NS > 0 (the library's own tiles): [A|B] is block diagonal, S1 and S2 need NS terms per output and run on the
+//    vector pipe (see the comment at the lane terms below); NS = 0 (plugin tiles): they are MFMA products too.
+//  * the pivoted LU keeps all 64 lanes busy and takes its multipliers by DPP row broadcast (see S3).
+//  * WAVES = 8: a 512-thread workgroup owns a CU (8 x 20 KB of LDS), two wavefronts per SIMD, placed
+//    deterministically; one wavefront alone gets only half of a SIMD's issue rate.
 //
-//   S1  [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (+ mu B^T on the B rows)          2x2 tiles x 5 k-steps
-//   S2  [T1;T2] [A|B] -> Q_xx, Q_ux, Q_uu                                          2x2 x 5
+//   S1  [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (+ mu B^T on the B rows)   dense: 2x2 tiles x 5 k-steps at cfg2
+//   S2  [T1;T2] [A|B] + l-values -> Q_xx, Q_ux, Q_uu                        dense: 2x2 x 5
 //   S3  LU solve in registers (vector pipe)
-//   S4  T3^T = Q_uu-contracted K                                                   1x2 x 3
+//   S4  T3^T = Q_uu-contracted K                                            1x2 x 3
 //   S5  a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] (its transpose supplies Q_ux^T K and Q_ux^T d)   2 x (2x2 x 3)
 //   S6  P <- (V + V^T)/2
 #pragma once
