@@ -328,3 +328,36 @@ def test_sweep_twelve_state_family(dp, k):
         p = orc.Problem([7] * k, [3] * k, xf[i], Q, R, Qf, 0.5, 0.05, T)
         Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+
+
+@pytest.mark.parametrize("model,k,T", [(0, 7, 20), (0, 13, 15), (0, 15, 12), (3, 7, 20), (3, 12, 12), (4, 8, 15)])
+def test_solve_large_clusters_vs_oracle(dp, model, k, T):
+    """Whole solves of 7..15-agent clusters: the workgroup-per-item sweep and the two / three-wavefront line search
+    against the CPU oracle, on the scenarios whose oracle solve is insensitive to a 1e-13 perturbation."""
+    from oracle import oracle as orc
+    from dpilqr_amd.util import random_setup
+    ns, nc = (6, 3) if model == 4 else (4, 2)
+    nd = 3 if ns == 6 else 2
+    B = 4
+    x0 = np.zeros((B, k * ns)); xf = np.zeros((B, k * ns))
+    for s in range(B):
+        np.random.seed(300 + s)
+        a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0)
+        x0[s], xf[s] = a.ravel(), b.ravel()
+    Q, R = (50.0 * np.eye(6), np.eye(3)) if ns == 6 else (np.diag([1.0, 1, 0, 0]), np.eye(2))
+    Qf = 1000.0 * np.eye(ns)
+    U0 = np.zeros((B, T, k * nc))
+    if model == 4:
+        U0[:, :, 0::3] = 9.80665
+    pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    r = pb.solve(x0, U0, n_lqr_iter=6)
+    proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.5, 0.1, T)
+    o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=6)
+    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, n_lqr_iter=6)
+    well = np.array([relerr(op["X"][i], o["X"][i]) < 1e-6 and op["n_fwd"][i] == o["n_fwd"][i] for i in range(B)])
+    assert well.any(), "every scenario of this set is chaotic in the oracle itself"
+    X = r["X"].cpu().numpy(); nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy()
+    for i in np.where(well)[0]:
+        assert nb[i] == o["n_bwd"][i] and nf[i] == o["n_fwd"][i], i
+        assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i].cpu().numpy(), o["U"][i]) < TOL_SOLVE, i
+    assert np.isfinite(X).all()
