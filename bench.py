@@ -174,7 +174,30 @@ def main():
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], _ = cpu_baseline(x0_h, xf_h, min(args.cpu_sample, x0_h.shape[0]))
+            ns = min(args.cpu_sample, x0_h.shape[0])
+            out["cpu_baseline"], o = cpu_baseline(x0_h, xf_h, ns)
+            # The oracle's solves of the same items double as a live parity check of this very run (untimed).  About
+            # 2-4 % of cfg2 scenarios are ill-conditioned IN THE REFERENCE ITSELF: the check
+            # classifies a sub-sample by the oracle's own sensitivity to a 1e-13 relative perturbation of x0.
+            Xg = r["X"][:ns].cpu().numpy()
+
+            def rel(a, b):
+                return np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / np.maximum(np.abs(b).reshape(b.shape[0], -1).max(axis=1), 1e-300)
+            err = rel(Xg, o["X"])
+            same_trace = (nb[:ns] == o["n_bwd"]) & (nf[:ns] == o["n_fwd"]) & (st[:ns] == o["status"])
+            nc = min(ns, 2048)
+            from oracle import oracle as orc
+            proto = orc.Problem([0] * K_AGENTS, [2] * K_AGENTS, xf_h[0], Q, R, Qf, 0.5, 0.1, T)
+            op = orc.solve_batch(proto, x0_h[:nc] * (1 + 1e-13), xf_h[:nc], np.zeros((nc, T, N_U)), n_threads=out["cpu_baseline"]["cores"])
+            well = (op["n_bwd"] == o["n_bwd"][:nc]) & (op["n_fwd"] == o["n_fwd"][:nc]) & (rel(op["X"], o["X"][:nc]) < 1e-6)
+            ok = same_trace[:nc] & (err[:nc] < 1e-5)
+            out["parity_vs_oracle"] = {
+                "items": int(ns), "identical_decision_trace_frac": float(same_trace.mean()),
+                "states_within_1e-5_frac": float((err < 1e-5).mean()),
+                "classified_items": int(nc), "well_conditioned_frac": float(well.mean()),
+                "match_frac_on_well_conditioned": float(ok[well].mean()) if well.any() else None,
+                "note": "well conditioned = the CPU oracle's own solve keeps its decision trace and moves < 1e-6 when x0 is "
+                        "perturbed by 1e-13 (relative); match = identical decision trace and states within 1e-5"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

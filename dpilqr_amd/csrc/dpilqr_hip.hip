@@ -385,11 +385,16 @@ constexpr int kMaxGlobalIter = 1 << 20;  // launches of the iteration loop one s
 
 int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || window > D.B) ? (D.B > 0 ? D.B : 1) : window; }
 
-struct Mailbox {  // pinned host words the device-side active counters are copied into
+// The host reads the device-side counters kHostLag iterations late: that many iterations of launches are always
+// queued behind the one the GPU is running, so a host thread that loses its core for a millisecond (a loaded box)
+// does not leave the GPU idle.  The price is kHostLag empty iterations (a dozen tiny launches) at the end of a solve.
+constexpr int kHostLag = 3, kMailRing = kHostLag + 1;
+
+struct Mailbox {  // pinned host words the admission kernel posts the active-list counters into
     int32_t* host = nullptr;
     int32_t* dev = nullptr;   // the same words as the device sees them
     std::vector<int32_t> hist;  // exact active-list length of every global iteration of the last solve
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[kMailRing] = {};
     ~Mailbox() {
         if (host) (void)hipHostFree(host);
         for (auto& e : ev)
@@ -647,10 +652,9 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     const int n = D.k * D.n_s, m = D.k * D.n_c;
 
     if (!g_mail.host) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 2 * kMailRing, hipHostMallocDefault));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_mail.dev), g_mail.host, 0));
-        HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[0], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g_mail.ev[1], hipEventDisableTiming));
+        for (auto& e : g_mail.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     g_mail.hist.clear();
 
@@ -677,6 +681,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     // one iteration late -- a full iteration of launches is always queued while it waits -- to learn
     // when everything has been started and nothing is left active.
     int32_t* admitted_dev = counts + kCountRing;
+    size_t n_iterations = 0;
     if (n_lqr_iter > 0) {
         // the tile producer of the loop writes only structurally non-zero entries: put the zeros in place once
         HIP_TRY(hipMemsetAsync(tiles, 0, W.K - W.tiles, st));
@@ -690,12 +695,13 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
         if (static_part_placed && (rc = launch_make_tiles(D, X, U, tiles, nullptr, nullptr, Wn, true, false, st))) return rc;
         int upper = Wn;
         for (int it = 0; it < kMaxGlobalIter; ++it) {
+            n_iterations = (size_t)it + 1;
             int32_t* cur = lists + (size_t)(it & 1) * Wn;
             int32_t* cur_n = counts + (it % kCountRing);
             int32_t* nxt_n = counts + ((it + 1) % kCountRing);
             hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn,
-                               g_mail.dev + 2 * (it & 1));
-            HIP_TRY(hipEventRecord(g_mail.ev[it & 1], st));
+                               g_mail.dev + 2 * (it % kMailRing));
+            HIP_TRY(hipEventRecord(g_mail.ev[it % kMailRing], st));
             S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
             S.next_count = nxt_n;
             g_prof.begin(0, it, st);
@@ -712,11 +718,12 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
                 return rc;
             g_prof.end(st);
             bool done = false;
-            if (it >= 1) {  // {active, admitted} of iteration it-1
-                HIP_TRY(hipEventSynchronize(g_mail.ev[(it - 1) & 1]));
-                const int32_t act = g_mail.host[2 * ((it - 1) & 1)], adm = g_mail.host[2 * ((it - 1) & 1) + 1];
+            if (it >= kHostLag) {  // {active, admitted} of iteration it - kHostLag
+                const int slot = (it - kHostLag) % kMailRing;
+                HIP_TRY(hipEventSynchronize(g_mail.ev[slot]));
+                const int32_t act = g_mail.host[2 * slot], adm = g_mail.host[2 * slot + 1];
                 g_mail.hist.push_back(act);
-                // everything started and the list already empty one iteration ago: iteration `it` was a no-op
+                // everything started and the list already empty back then: the iterations since were no-ops
                 done = (adm >= D.B && act == 0);
                 // once everything is admitted the list can only shrink: tighten the grid
                 upper = (adm >= D.B) ? std::min(Wn, std::max(act, 1)) : Wn;
@@ -730,9 +737,8 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     if (n_lqr_iter > 0) {
-        // the last iteration's exact length was copied but not yet consumed
-        const size_t have = g_mail.hist.size();
-        g_mail.hist.push_back(g_mail.host[2 * (have & 1)]);
+        // the last iterations' exact lengths were posted but not yet consumed
+        for (size_t j = g_mail.hist.size(); j < n_iterations; ++j) g_mail.hist.push_back(g_mail.host[2 * (j % kMailRing)]);
     }
     g_prof.collect(g_mail.hist, D.B);
     return DPILQR_OK;
