@@ -68,7 +68,10 @@ class ProblemBatch:
         self._R, rs = _shared_or_batched(expand(R, nc), B_, (k, nc, nc), torch.float64)
         self._Qf, fs = _shared_or_batched(expand(Qf, ns), B_, (k, ns, ns), torch.float64)
         self._radius, ras = _shared_or_batched(np.asarray(radius, dtype=np.float64), B_, (1,), torch.float64)
-        uniform = 1 + m0 if bool((model == m0).all()) else 0      # hint for model-specialised kernels
+        uniform = 1 + m0 if bool((model == m0).all()) else 0      # hints for model-specialised kernels (dpilqr_hip.h)
+        nd_all = np.asarray(n_dims, dtype=np.int32)
+        if nd_all.size and bool((nd_all == nd_all.reshape(-1)[0]).all()):
+            uniform |= (1 + int(nd_all.reshape(-1)[0])) << 8
         self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, uniform, self.dt, self.w_ref, self.w_prox,
                                    ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)

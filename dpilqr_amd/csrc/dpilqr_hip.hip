@@ -61,6 +61,10 @@ int32_t check_desc(const dpilqr_batch_desc* d) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
+inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
+inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
+
 template <typename Kern>
 int32_t allow_lds(Kern kern, size_t bytes) {
     if (bytes > (size_t)kMaxLds) return fail(DPILQR_EUNSUPPORTED, "needs %zu B of LDS per workgroup (> %d)", bytes, kMaxLds);
@@ -97,8 +101,12 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
     // kernels compiled per (model, agents), tiles_wave.hpp.  (Measured: for the other cases -- A, B to be written too,
     // or more than 6 agents -- the generic producer's sparse stores are the faster ones.)
     static const bool no_wave = getenv("DPILQR_TILES_GENERIC") != nullptr;   // A/B switch
-    if (sparse && dyn_only && !no_wave && D.uniform_model > 0) {
-        const int model = D.uniform_model - 1;
+    if (sparse && dyn_only && !no_wave && hint_model(D) >= 0) {
+        const int model = hint_model(D);
+        // rows of L_xx beyond the proximity cost's dimensions hold w_ref (Q + Q^T) only: with one Q, Q_f for the batch they
+        // were placed with A, B, L_uu and are skipped as well
+        const int und = hint_n_dims(D);
+        const int xx_rows = (D.Q_bstride == 0 && D.Qf_bstride == 0 && und >= 1 && und < D.n_s) ? und : D.n_s;
 #define DPILQR_TRY_TW(MODEL, KA, LINEAR)                                                                            \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
         constexpr int rpg = TilesWaveCfg<MODEL, KA, false>::RPG;                                                    \
@@ -107,7 +115,7 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
         const dim3 grid_w((n_groups + gpw - 1) / gpw, grid_items);                                                  \
         const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                                 \
         hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles, items, \
-                           n_items, gpw);                                                                           \
+                           n_items, gpw, xx_rows);                                                                  \
         HIP_TRY(hipGetLastError());                                                                                 \
         return DPILQR_OK;                                                                                           \
     }
@@ -236,8 +244,8 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
     if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
         return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
-    if (!no_wave_ro() && mode == kModeRollout && D.uniform_model > 0 && !items) {
-        const int model = D.uniform_model - 1;
+    if (!no_wave_ro() && mode == kModeRollout && hint_model(D) >= 0 && !items) {
+        const int model = hint_model(D);
 #define DPILQR_TRY_RO(MODEL, KA)                                                                                    \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
         using WR = WaveRolloutLds<MODEL, KA>;                                                                       \
@@ -262,8 +270,8 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
     // compiled for (model, agents), see forward_wave.hpp
     static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch
-    if (!no_wave && mode == kModeLineSearch && D.uniform_model > 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
-        const int model = D.uniform_model - 1;
+    if (!no_wave && mode == kModeLineSearch && hint_model(D) >= 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
+        const int model = hint_model(D);
 #define DPILQR_TRY_WAVE(MODEL, KA)                                                                                  \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
         using WF = WaveFwdLds<MODEL, KA>;                                                                           \
@@ -689,7 +697,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
         // item, so they are written once into all Wn slots here (with items 0..Wn-1 as stand-ins; their (X, U)
         // dependent entries are overwritten by each iteration's producer launch) and skipped afterwards.
         static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
-        const int um = D.uniform_model - 1;
+        const int um = hint_model(D);
         const bool static_part_placed = !no_static && D.R_bstride == 0 &&
                                         (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
         if (static_part_placed && (rc = launch_make_tiles(D, X, U, tiles, nullptr, nullptr, Wn, true, false, st))) return rc;

@@ -54,7 +54,8 @@ template <int MODEL, int KA, bool DYN_ONLY>
 __global__ __launch_bounds__(64) void k_make_tiles_wave(dpilqr_batch_desc D, const double* __restrict__ X,
                                                          const double* __restrict__ U, double* __restrict__ tiles,
                                                          const int32_t* __restrict__ items,
-                                                         const int32_t* __restrict__ n_items, int groups_per_wave) {
+                                                         const int32_t* __restrict__ n_items, int groups_per_wave,
+                                                         int xx_rows) {
     using C = TilesWaveCfg<MODEL, KA, DYN_ONLY>;
     constexpr int NS = C::NS, NC = C::NC, n = C::n, m = C::m, NPAIRS = C::NP, NP1 = C::NP1, RPG = C::RPG;
     constexpr int PD = NS < 3 ? NS : 3;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(64) void k_make_tiles_wave(dpilqr_batch_desc D, con
                     }
                     v[c] = val;
                 }
+                if (li >= xx_rows) continue;   // rows of w_ref (Q + Q^T) only: already in place (see the dispatch)
                 double* dst = recs + (int64_t)t * L.stride + L.oLxx + e;
                 if constexpr (XE == 2) k1_store_v2d(dst, v2d{v[0], v[1]}); else k1_store_f64(dst, v[0]);
             }

@@ -73,8 +73,10 @@ typedef struct dpilqr_batch_desc {
     int32_t n_s; /* per-agent state dim   (3, 4, 6 or 12)                        */
     int32_t n_c; /* per-agent control dim (2, 3 or 4)                            */
     int32_t T;   /* horizon N (control.py:56)                                    */
-    int32_t uniform_model; /* hint: 1 + Model enum when EVERY agent of EVERY item uses that model (lets the
-                              solver pick kernels compiled for it); 0 = unknown / mixed, always valid  */
+    int32_t uniform_model; /* hints, 0 = unknown / mixed (always valid).  Bits 0..7: 1 + Model enum when EVERY agent of
+                              EVERY item uses that model; bits 8..15: 1 + n_dims when every agent of every item has
+                              that ProximityCost.n_dims.  They let the solver pick kernels compiled per model and skip
+                              work that cannot depend on the item.                                              */
     double dt;     /* DynamicalModel.dt                                          */
     double w_ref;  /* GameCost.REF_WEIGHT  = 1   (cost.py:185)                   */
     double w_prox; /* GameCost.PROX_WEIGHT = 200 (cost.py:186)                   */
