@@ -155,13 +155,16 @@ __global__ __launch_bounds__(64) void k_make_tiles_wave(dpilqr_batch_desc D, con
         }
         {   // ---- phase B1: L_xx = w_ref blockdiag(Q+Q^T) + w_prox sum_pairs(+-H), whole rows in 16-byte pieces
             constexpr int XE = (n % 2 == 0) ? 2 : 1;
-            constexpr int per = n * n / XE;
+            // only the first xx_rows rows of every agent's block row are written (all NS of them unless the caller
+            // knows the others hold w_ref (Q + Q^T) only and has put them in place, see the dispatch)
+            const int per = KA * xx_rows * (n / XE);
             for (int idx = lane; idx < n_rec * per; idx += 64) {
-                const int r = idx / per, e = XE * (idx - r * per), t = t0 + r;
+                const int r = idx / per, w = idx - r * per, t = t0 + r;
                 const double* sr = lds + r * C::per_rec;
                 const double* QQ = (t == T) ? sQQf : sQQ;
-                const int i = e / n, j0 = e - i * n;
-                const int ai = i / NS, li = i - ai * NS;
+                const int rr = w / (n / XE), j0 = XE * (w - rr * (n / XE));
+                const int ai = rr / xx_rows, li = rr - ai * xx_rows;
+                const int i = ai * NS + li, e = i * n + j0;
                 double v[XE];
 #pragma unroll
                 for (int c = 0; c < XE; ++c) {
@@ -180,7 +183,6 @@ __global__ __launch_bounds__(64) void k_make_tiles_wave(dpilqr_batch_desc D, con
                     }
                     v[c] = val;
                 }
-                if (li >= xx_rows) continue;   // rows of w_ref (Q + Q^T) only: already in place (see the dispatch)
                 double* dst = recs + (int64_t)t * L.stride + L.oLxx + e;
                 if constexpr (XE == 2) k1_store_v2d(dst, v2d{v[0], v[1]}); else k1_store_f64(dst, v[0]);
             }
