@@ -207,19 +207,40 @@ template <> struct ModelDef<kQuadcopter12D> {
 // (Markstein's correction step; checked against the division on 6e8 random operands).  Subnormal quotients, where
 // the residual is no longer exact, take the division.  The RK4 update divides by 6 four to twelve times per
 // sub-step and sits on the forward pass's critical path.
-__device__ __forceinline__ double div6(double x) {
+__device__ __forceinline__ double div6_fast(double x) {   // exact unless the quotient is subnormal
     const double c = 0x1.5555555555555p-3;
-    double q = x * c;
+    const double q = x * c;
     const double r = fma(-6.0, q, x);
-    q = fma(r, c, q);
-    // wave-uniform test: a per-lane `if` is if-converted, i.e. the division would be evaluated every time
-    if (__builtin_amdgcn_ballot_w64(fabs(x) < 0x1p-1000 && x != 0.0) != 0ull) {
-        double xs = x;
-        asm volatile("" : "+v"(xs));   // or the compiler hoists the division above the branch it is meant to hide behind
-        const double qs = xs / 6.0;
-        if (fabs(x) < 0x1p-1000 && x != 0.0) q = qs;
+    return fma(r, c, q);
+}
+// v[0..N) <- v / 6.0, correctly rounded.  One wave-uniform test covers all N operands: the binary exponent
+// (v_frexp_exp: 0 for +-0) says whether any non-zero operand is small enough for a subnormal quotient, and only then is
+// the fp64 division evaluated (behind a real branch: a per-lane `if` would be if-converted and the division, or an
+// un-fenced one hoisted, evaluated every time).
+template <int N>
+__device__ __forceinline__ void div6_vec(double* v) {
+    int emin = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) emin = min(emin, __builtin_amdgcn_frexp_exp(v[i]));
+    double q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = div6_fast(v[i]);
+    if (__builtin_amdgcn_ballot_w64(emin <= -1000) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double xs = v[i];
+            asm volatile("" : "+v"(xs));
+            const double qs = xs / 6.0;
+            if (__builtin_amdgcn_frexp_exp(v[i]) <= -1000) q[i] = qs;
+        }
     }
-    return q;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = q[i];
+}
+__device__ __forceinline__ double div6(double x) {
+    double v[1] = {x};
+    div6_vec<1>(v);
+    return v[0];
 }
 
 // classical RK4 with 5 fixed sub-steps, zero-order-hold u (bbdynamics.cpp:39-93)
@@ -246,7 +267,10 @@ __device__ inline void integrate(const double* x, const double* u, double dt, do
         for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
         D::f(xb, u, k3);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xn[i] += div6(dh * (k0[i] + 2.0 * k1[i] + 2.0 * k2[i] + k3[i]));
+        for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + 2.0 * k1[i] + 2.0 * k2[i] + k3[i]);
+        div6_vec<NS>(xb);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xn[i] += xb[i];
     }
 }
 
