@@ -36,6 +36,9 @@ def describe(problem):
     refs = cost.ref_costs if isinstance(cost, GameCost) else [cost]
     prox = cost.prox_cost if isinstance(cost, GameCost) and isinstance(cost.prox_cost, ProximityCost) else None
     k = len(subs)
+    for r, sub in zip(refs, subs):
+        if np.size(r.xf) != sub.n_x:
+            raise ValueError(f"ReferenceCost.xf has {np.size(r.xf)} entries for a {sub.n_x}-state agent (id {getattr(r, 'id', None)})")
     return dict(model=np.array([m.model.value for m in subs], dtype=np.int32),
                 n_dims=np.array(prox.n_dims if prox is not None else [2] * k, dtype=np.int32),
                 xf=np.concatenate([r.xf for r in refs]),
