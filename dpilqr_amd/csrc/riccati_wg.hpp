@@ -42,6 +42,7 @@ struct WgCfg {
     static constexpr int oG = oR2 + szR2, oQx = oG + MK * LG, oEnd = oG + szG;
     static constexpr int total = round_up(oEnd + 64, 2);   // + store target of idle lanes, wrapped tile reads
     static constexpr bool AL = (NS % 2 == 0) && (NC % 2 == 0);   // every block offset even: 16-byte vector accesses
+    static constexpr bool ALA = (NS % 2 == 0);                   // ... at least the A-column blocks (offsets NS*agent)
     static constexpr int CG = (NP + 1) / 2;                  // S1: column groups of 2 over [P|p]
     static constexpr int NI1 = KA * CG, R1R = (NI1 + kWgThreads - 1) / kWgThreads;
     static constexpr int RPL = 2, RG = (NM + RPL - 1) / RPL;  // S2: row groups
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
     using C = WgCfg<N, M, NS, NC>;
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, KA = C::KA, NSC = C::NSC, LAB = C::LAB, LP = C::LP, LQ = C::LQ;
     constexpr int LG = C::LG, LK = C::LK, LTB = C::LTB, LM = C::LM, T_NP = C::T_NP, T_N = C::T_N;
-    constexpr bool AL = C::AL;
+    constexpr bool AL = C::AL, ALA = C::ALA;
     const int slot = blockIdx.x;
     if (slot >= (n_items ? *n_items : B)) return;
     const int b = items ? items[slot] : slot;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
             for (int q = 0; q < C::RPL; ++q) {
                 const int ip = ip2[r][q];
                 if (ip < N) {
-                    ld_row<NS, AL>(rec + L.oLxx + ip * N + NS * ag2[r], nL[r][q]);
+                    ld_row<NS, ALA>(rec + L.oLxx + ip * N + NS * ag2[r], nL[r][q]);
 #pragma unroll
                     for (int c = 0; c < NC; ++c) nL[r][q][NS + c] = 0.0;
                 } else {
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
 #pragma unroll
                 for (int l = 0; l < NS; ++l) {
                     double ab[NSC], pr[2];
-                    ld_row<NS, AL>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
+                    ld_row<NS, ALA>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
                     ld_row<NC, AL>(sAB + (NS * ag + l) * LAB + N + NC * ag, ab + NS);
                     ld_row<2, true>(sP + (NS * ag + l) * LP + j0, pr);
 #pragma unroll
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
             const int ag = ag2[r];
             double acc[C::RPL][NSC], tv[C::RPL][NS];
 #pragma unroll
-            for (int q = 0; q < C::RPL; ++q) ld_row<NS, AL>(sT + ip2[r][q] * LTB + NS * ag, tv[q]);
+            for (int q = 0; q < C::RPL; ++q) ld_row<NS, ALA>(sT + ip2[r][q] * LTB + NS * ag, tv[q]);
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
                 double ab[NSC];
-                ld_row<NS, AL>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
+                ld_row<NS, ALA>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
                 ld_row<NC, AL>(sAB + (NS * ag + l) * LAB + N + NC * ag, ab + NS);
 #pragma unroll
                 for (int q = 0; q < C::RPL; ++q)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
 #pragma unroll
                 for (int c = 0; c < NSC; ++c) o[c] = nL[r][q][c] + acc[q][c];
                 if (ip < N) {
-                    st_row<NS, AL>(sQ + ip * LQ + NS * ag, o);
+                    st_row<NS, ALA>(sQ + ip * LQ + NS * ag, o);
                 } else {
                     st_row<NS, AL>(sG + (ip - N) * LG + M + NS * ag, o);
                     st_row<NC, AL>(sG + (ip - N) * LG + NC * ag, o + NS);
