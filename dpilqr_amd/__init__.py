@@ -10,7 +10,8 @@ from .bbdynamics import Model, f, integrate, linearize  # noqa: F401
 from .control import ilqrSolver  # noqa: F401
 from .cost import Cost, GameCost, ProximityCost, ReferenceCost, quadraticize_distance  # noqa: F401
 from .dispatch import pairwise_graph, solve_problem_list, solve_scenarios_distributed  # noqa: F401
-from .distributed import define_inter_graph_threshold, solve_centralized, solve_distributed, solve_rhc  # noqa: F401
+from .distributed import (define_inter_graph_threshold, solve_centralized, solve_distributed, solve_rhc,  # noqa: F401
+                          solve_rhc_scenarios)
 from .dynamics import (CarDynamics3D, CppModel, DoubleIntDynamics4D, DoubleIntDynamics6D, DynamicalModel,  # noqa: F401
                        HumanDynamics6D, HumanDynamicsLin6D, MultiDynamicalModel, QuadcopterDynamics6D,
                        QuadcopterDynamics12D, UnicycleDynamics4D)

@@ -244,3 +244,28 @@ def test_edge_cases_empty_batch_short_horizon_no_iterations(dp):
     lib = dp._lib.load()
     assert lib.dpilqr_backward_pass_tiles(1, 0, 4, 2, None, None, None, None, None, None, None, None) == -1   # DPILQR_EINVAL
     assert b"bad sizes" in lib.dpilqr_last_error()
+
+
+@pytest.mark.parametrize("centralized", [True, False])
+def test_rhc_scenarios_equal_per_scenario_rhc(dp, golden, centralized):
+    """The lock-step receding-horizon loop over several scenarios must reproduce, scenario by scenario, what
+    solve_rhc (distributed.py:106-221) gives when run on each alone with the same warm start."""
+    z = golden("g4_solves_misc"); tag = "cfg1"
+    prob = problem_from(z, tag + "_")
+    n_x, n_u, N, S = 12, 6, 12, 3
+    rng = np.random.default_rng(11)
+    x0 = np.tile(z[tag + "_x0"].reshape(1, -1), (S, 1))
+    jit = rng.normal(scale=0.1, size=(S, 3, 4)); jit[:, :, 2:] = 0.0; jit[0] = 0.0
+    x0 = x0 + jit.reshape(S, -1)
+    U0 = np.zeros((S, N, n_u))
+    for s in range(S):
+        np.random.seed(40 + s)
+        U0[s] = np.random.rand(N, n_u) * 0.01
+    args = () if centralized else (0.5,)
+    kw = dict(centralized=centralized, step_size=4, dist_converge=0.6, t_diverge=2.0)
+    batched = dp.solve_rhc_scenarios(prob, x0, N, 0.5, U0=U0, **kw)
+    for s in range(S):
+        np.random.seed(40 + s)                      # solve_rhc draws its warm start from the global RNG
+        Xs, Us, Js = dp.solve_rhc(prob, x0[s], N, *args, **kw)
+        Xb, Ub, Jb, _ = batched[s]
+        assert Xb.shape == Xs.shape and (Xb == Xs).all() and (Ub == Us).all() and Jb == Js, s
