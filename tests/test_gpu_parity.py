@@ -361,3 +361,53 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
         assert nb[i] == o["n_bwd"][i] and nf[i] == o["n_fwd"][i], i
         assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i].cpu().numpy(), o["U"][i]) < TOL_SOLVE, i
     assert np.isfinite(X).all()
+
+
+def _fuzz_cases():
+    rng = np.random.default_rng(2024)
+    cases = []
+    for i in range(18):
+        model = int(rng.choice([0, 3, 4, 1, 5]))
+        k = int(rng.integers(1, 8))
+        T = int(rng.choice([1, 2, 3, 7, 16, 33]))
+        B = int(rng.choice([1, 2, 3, 5, 9, 13, 31]))
+        window = int(rng.choice([0, 1, 4, 7]))
+        cases.append((i, model, k, T, B, window))
+    return cases
+
+
+@pytest.mark.parametrize("seed,model,k,T,B,window", _fuzz_cases())
+def test_fuzz_shapes_against_oracle(dp, seed, model, k, T, B, window):
+    """Odd corners of the packing (batch sizes that do not fill a workgroup, horizons of 1..33 steps, windows smaller
+    than the batch, one..seven agents of five different models): rollout, one backward pass and a short solve against
+    the oracle."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    ns, nc = {0: (4, 2), 3: (4, 2), 4: (6, 3), 1: (6, 3), 5: (6, 3)}[model]
+    nd = 3 if ns == 6 else 2
+    rng = np.random.default_rng(1000 + seed)
+    xf = rng.normal(size=(B, k * ns)) * 1.5; x0 = rng.normal(size=(B, k * ns)) * 1.5
+    x0.reshape(B, k, ns)[:, :, nd:] *= 0.1; xf.reshape(B, k, ns)[:, :, nd:] = 0.0
+    U0 = rng.normal(size=(B, T, k * nc)) * 0.05
+    if model == 4:
+        U0[:, :, 0::3] += 9.80665
+    Q = np.eye(ns) * rng.uniform(0.5, 2.0); R = np.eye(nc); Qf = 100.0 * np.eye(ns)
+    pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.6, 0.1, T)
+    X, J = pb.rollout(x0, U0)
+    mu = rng.uniform(0, 1, size=B)
+    K, d = pb.backward_pass(X, U0, to_dev(mu))
+    r = pb.solve(x0, U0, n_lqr_iter=3, window=window or None)
+    for i in range(B):
+        p = orc.Problem([model] * k, [nd] * k, xf[i], Q, R, Qf, 0.6, 0.1, T)
+        Xo, Jo = p.rollout(x0[i], U0[i])
+        assert relerr(X[i].cpu().numpy(), Xo) < 1e-11 and abs(float(J[i]) - Jo) <= 1e-11 * abs(Jo), i
+        Ko, do = p.backward_pass(Xo, U0[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+    proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.6, 0.1, T)
+    o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=3)
+    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, n_lqr_iter=3)
+    nb = r["n_bwd"].cpu().numpy(); Xs = r["X"].cpu().numpy()
+    for i in range(B):
+        if relerr(op["X"][i], o["X"][i]) < 1e-7 and op["n_fwd"][i] == o["n_fwd"][i]:      # well conditioned in the oracle
+            assert nb[i] == o["n_bwd"][i] and relerr(Xs[i], o["X"][i]) < TOL_SOLVE, i
+    assert np.isfinite(Xs).all()
