@@ -157,13 +157,13 @@ class ProblemBatch:
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None):
         """ilqrSolver.solve (control.py:150-225) for all B items.
 
-        window: most items in flight at once (default min(B, 2048) = two sweep wavefronts per SIMD on an
+        window: most items in flight at once (default min(B, 6144) = three rounds of two sweep wavefronts per SIMD on an
         MI355X); finished items are retired on the device and replaced by not-yet-started ones, so launches
         stay full and memory is bounded.
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
-        window = min(B, 2048) if window is None else int(window)
+        window = min(B, 6144) if window is None else int(window)
         x0 = self._in(x0, (B, n))
         U = self._in(U0, (B, T, m)).clone()
         X = empty((B, T + 1, n)); J = empty((B,))
