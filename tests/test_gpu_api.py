@@ -269,3 +269,27 @@ def test_rhc_scenarios_equal_per_scenario_rhc(dp, golden, centralized):
         Xs, Us, Js = dp.solve_rhc(prob, x0[s], N, *args, **kw)
         Xb, Ub, Jb, _ = batched[s]
         assert Xb.shape == Xs.shape and (Xb == Xs).all() and (Ub == Us).all() and Jb == Js, s
+
+
+def test_scenarios_sharded_single_rank_equals_front_end(dp, golden):
+    """sharding.solve_scenarios_sharded with the real device solver behind it (one rank, gloo for the collective):
+    the gathered result must be the front end's own."""
+    import socket
+    import torch.distributed as dist
+    from dpilqr_amd.dispatch import solve_scenarios_distributed
+    from dpilqr_amd.sharding import solve_scenarios_sharded
+    z = golden("g5_dispatch"); tag = "uni5"
+    prob = problem_from(z, tag + "_")
+    S = 4
+    rng = np.random.default_rng(9)
+    x0 = np.tile(z[tag + "_x0"].reshape(1, -1), (S, 1)); x0[1:, 0::4] += rng.normal(scale=0.1, size=(S - 1, 5))
+    U0 = np.tile(z[tag + "_U0"][None], (S, 1, 1))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        Xg, Ug, Jg, info = solve_scenarios_sharded(prob, x0[:, None, :], U0, 0.5)
+    finally:
+        dist.destroy_process_group()
+    Xd, Ud, Jd, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5)
+    assert (Xg == Xd).all() and (Ug == Ud).all() and (Jg == Jd).all() and info["shard"] == (0, S)
