@@ -263,6 +263,15 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
         DPILQR_RO_15(kDoubleInt4D)
         DPILQR_RO_15(kUnicycle4D)
         DPILQR_RO_10(kQuadcopter6D)
+#define DPILQR_RO_6(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)                 \
+        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6)
+        DPILQR_RO_6(kDoubleInt6D)
+        DPILQR_RO_6(kCar3D)
+        DPILQR_RO_6(kHuman6D)
+        DPILQR_RO_6(kHumanLin6D)
+        DPILQR_TRY_RO(kQuadcopter12D, 1) DPILQR_TRY_RO(kQuadcopter12D, 2) DPILQR_TRY_RO(kQuadcopter12D, 3)
+        DPILQR_TRY_RO(kQuadcopter12D, 4) DPILQR_TRY_RO(kQuadcopter12D, 5)
+#undef DPILQR_RO_6
 #undef DPILQR_RO_15
 #undef DPILQR_RO_10
 #undef DPILQR_TRY_RO
@@ -291,6 +300,16 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
         DPILQR_WAVE_15(kDoubleInt4D)
         DPILQR_WAVE_15(kUnicycle4D)
         DPILQR_WAVE_10(kQuadcopter6D)
+        // the remaining models, up to six agents (one wavefront per sub-problem)
+#define DPILQR_WAVE_6(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)         \
+        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6)
+        DPILQR_WAVE_6(kDoubleInt6D)
+        DPILQR_WAVE_6(kCar3D)
+        DPILQR_WAVE_6(kHuman6D)
+        DPILQR_WAVE_6(kHumanLin6D)
+        DPILQR_TRY_WAVE(kQuadcopter12D, 1) DPILQR_TRY_WAVE(kQuadcopter12D, 2) DPILQR_TRY_WAVE(kQuadcopter12D, 3)
+        DPILQR_TRY_WAVE(kQuadcopter12D, 4) DPILQR_TRY_WAVE(kQuadcopter12D, 5)
+#undef DPILQR_WAVE_6
 #undef DPILQR_WAVE_15
 #undef DPILQR_WAVE_10
 #undef DPILQR_TRY_WAVE

@@ -366,9 +366,9 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
 def _fuzz_cases():
     rng = np.random.default_rng(2024)
     cases = []
-    for i in range(18):
-        model = int(rng.choice([0, 3, 4, 1, 5]))
-        k = int(rng.integers(1, 8))
+    for i in range(26):
+        model = int(rng.choice([0, 3, 4, 1, 5, 2, 6, 7]))
+        k = int(rng.integers(1, 8)) if model != 7 else int(rng.integers(1, 4))
         T = int(rng.choice([1, 2, 3, 7, 16, 33]))
         B = int(rng.choice([1, 2, 3, 5, 9, 13, 31]))
         window = int(rng.choice([0, 1, 4, 7]))
@@ -379,18 +379,21 @@ def _fuzz_cases():
 @pytest.mark.parametrize("seed,model,k,T,B,window", _fuzz_cases())
 def test_fuzz_shapes_against_oracle(dp, seed, model, k, T, B, window):
     """Odd corners of the packing (batch sizes that do not fill a workgroup, horizons of 1..33 steps, windows smaller
-    than the batch, one..seven agents of five different models): rollout, one backward pass and a short solve against
+    than the batch, one..seven agents of all eight models): rollout, one backward pass and a short solve against
     the oracle."""
     from oracle import oracle as orc
     from dpilqr_amd.device import to_dev
-    ns, nc = {0: (4, 2), 3: (4, 2), 4: (6, 3), 1: (6, 3), 5: (6, 3)}[model]
-    nd = 3 if ns == 6 else 2
+    ns, nc = {0: (4, 2), 3: (4, 2), 4: (6, 3), 1: (6, 3), 5: (6, 3), 2: (3, 2), 6: (6, 3), 7: (12, 4)}[model]
+    nd = 3 if ns >= 6 else 2
     rng = np.random.default_rng(1000 + seed)
     xf = rng.normal(size=(B, k * ns)) * 1.5; x0 = rng.normal(size=(B, k * ns)) * 1.5
     x0.reshape(B, k, ns)[:, :, nd:] *= 0.1; xf.reshape(B, k, ns)[:, :, nd:] = 0.0
     U0 = rng.normal(size=(B, T, k * nc)) * 0.05
     if model == 4:
         U0[:, :, 0::3] += 9.80665
+    if model == 7:   # the free rigid body tumbles chaotically in an open-loop rollout: stay near hover, few steps
+        T = min(T, 6); U0 = U0[:, :T] * 1e-4; U0[:, :, 3::4] += 9.80665 * 63.0 / 2000.0   # torque gains are ~5e4
+        x0.reshape(B, k, ns)[:, :, 3:] *= 0.02
     Q = np.eye(ns) * rng.uniform(0.5, 2.0); R = np.eye(nc); Qf = 100.0 * np.eye(ns)
     pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.6, 0.1, T)
     X, J = pb.rollout(x0, U0)
@@ -400,8 +403,9 @@ def test_fuzz_shapes_against_oracle(dp, seed, model, k, T, B, window):
     for i in range(B):
         p = orc.Problem([model] * k, [nd] * k, xf[i], Q, R, Qf, 0.6, 0.1, T)
         Xo, Jo = p.rollout(x0[i], U0[i])
-        assert relerr(X[i].cpu().numpy(), Xo) < 1e-11 and abs(float(J[i]) - Jo) <= 1e-11 * abs(Jo), i
-        Ko, do = p.backward_pass(Xo, U0[i], mu[i])
+        tol_roll = 1e-7 if model == 7 else 1e-11   # torque gains of 5e4: last-bit differences of sin / cos / tan grow fast
+        assert relerr(X[i].cpu().numpy(), Xo) < tol_roll and abs(float(J[i]) - Jo) <= tol_roll * abs(Jo), i
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U0[i], mu[i])          # same linearisation points as the device
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
     proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.6, 0.1, T)
     o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=3)
