@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
             }
         wg_barrier();
 
+        __builtin_amdgcn_s_setprio(1);   // vector-pipe phases win arbitration over another workgroup's MFMA phases
         // ---- S1: [A|B]^T [P|p], block diagonal
         {
             double acc[C::R1R][NSC][2];
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
         }
         prefetch_ab(tn);
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
         {
             v4d acc[C::TPW4];
