@@ -165,7 +165,7 @@ def main():
                        "mean_backward_passes": float(nb.mean()), "mean_forward_passes": float(nf.mean()),
                        "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_riccati_mfma<20,10,8,4,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_riccati_mfma<20,10,12,4,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
                          "algorithmic_bytes_per_launch": ric_bytes / max(ric["launches"], 1),

@@ -61,6 +61,17 @@ int32_t check_desc(const dpilqr_batch_desc* d) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// compute units of the current device (256 on MI355X): the sweep deals its items over rounds of this many workgroups
+int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    return cus;
+}
+
 // hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
 inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
 inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
@@ -164,17 +175,21 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
 #define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
     if (n == NN && m == MM) {                                                                                      \
         static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
-        const int stagger = 100;   /* second wavefront of a SIMD starts half a step late (measured: no effect) */   \
-        static const bool no8 = getenv("DPILQR_MFMA_WAVES4") != nullptr;                                           \
-        const bool w8 = !no8 && grid_items > 1024;   /* enough items for two waves per SIMD */                     \
-        const int wv = w8 ? 8 : 4;                                                                                 \
+        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;            \
+        /* wavefronts per workgroup = per CU: 4 (one per SIMD), 8, or 12 when the launch has the items for them */  \
+        const int wv = (bd && grid_items > 2048 && max_wv >= 12 && MfmaCfg<NN, MM>::total * 8 * 12 <= kMaxLds) ? 12 \
+                       : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
         const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
-        auto kern = w8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)                  \
-                       : (bd ? k_riccati_mfma<NN, MM, 4, 4, 2> : k_riccati_mfma<NN, MM, 4, 0, 0>);                 \
+        auto kern = wv == 12 ? k_riccati_mfma<NN, MM, 12, 4, 2>                                                    \
+                    : wv == 8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)           \
+                              : (bd ? k_riccati_mfma<NN, MM, 4, 4, 2> : k_riccati_mfma<NN, MM, 4, 0, 0>);          \
         int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
         if (rc_t) return rc_t;                                                                                     \
-        hipLaunchKernelGGL(kern, dim3((grid_items + wv - 1) / wv), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d, \
-                           singular, items, n_items, gains_by_item, stagger);                                      \
+        /* whole rounds of one workgroup per CU; the kernel deals the live items over them (riccati_mfma.hpp) */    \
+        const int cus = device_cus();                                                                              \
+        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d,                      \
+                           singular, items, n_items, gains_by_item, cus);                                          \
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }

@@ -47,23 +47,36 @@ struct MfmaCfg {
     static constexpr int LQ = LP;                      // [Q_xx | Q_x]
     static constexpr int LG = round_up(M + NP, 2);     // [Q_uu | Q_ux | Q_u]
     static constexpr int LK = LP;                      // [K | d]
-    static constexpr int LM = LP;                      // a2 = [K|d]^T [Q_ux|Q_u]  (NP x NP)
+    static constexpr int LM = N;                       // a2 = [K|d]^T [Q_ux|Q_u]: rows <= n, columns < n kept
     static constexpr int KROWS = MK + 2;               // [K|d] rows incl. zero rows (a 16-wide tile read may wrap a row)
     static constexpr int T_NM = (NM + 15) / 16, T_NP = (NP + 15) / 16, T_N = (N + 15) / 16, T_M = (M + 15) / 16;
-    // LDS carve (doubles).  sK, sT3 live inside sT's space (dead after S2); a2 lives inside sAB's (dead after S2).
-    static constexpr int szAB = round_up(N * LAB > NP * LM ? N * LAB : NP * LM, 2);
     static constexpr int LTB = LP;                     // block-diagonal variant: T row-major, [i'][j], j <= n
+    // LDS carve (doubles): three regions that change owner along the step -- 13.5 KB per wavefront at cfg2, so that
+    // three wavefronts fit a SIMD's share of the CU's 160 KB.  Every hand-over happens inside ONE wavefront, whose LDS
+    // operations execute in order, so the only rule is "a phase issues all its operand reads before its epilogue
+    // stores":
+    //   R1: [A|B] (S0 .. S2 operands)  ->  [Q_xx | Q_x] (S2 epilogue .. S5)
+    //   R2: [P|p] (S6 .. S1 operand) -> T (S1 epilogue .. S2 operand) -> [K|d] + T3^T (S3 .. S5 operands)
+    //       -> V (S5 epilogue, read transposed by S6) -> [P|p]
+    //   G : [Q_uu | Q_ux | Q_u] (S1/S2 epilogues .. S5 operands) + Q_x staging (S1 -> S2 epilogue) -> a2 (S5 epilogue,
+    //       read transposed).  Its reduction-padding rows >= M therefore hold finite left-overs instead of zeros;
+    //       they only ever multiply the zero padding rows of [K|d].
+    static constexpr int szR1 = round_up(N * LAB > N * LQ ? N * LAB : N * LQ, 2);
     static constexpr int szT0 = N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N;
-    static constexpr int szT = round_up(szT0 > NM * LTB ? szT0 : NM * LTB, 2);
+    static constexpr int szT1 = szT0 > NM * LTB ? szT0 : NM * LTB;
+    static constexpr int szR2 = round_up(szT1 > N * LP ? szT1 : N * LP, 2);
+    static constexpr int szG0 = MK * LG + round_up(N, 2);
+    static constexpr int szG = round_up(szG0 > NP * LM ? szG0 : NP * LM, 2);
     static constexpr int oAB = 0;
-    static constexpr int oT = oAB + szAB;
+    static constexpr int oQ = 0;
+    static constexpr int oT = oAB + szR1;
     static constexpr int oK = oT;
     static constexpr int oT3 = oK + KROWS * LK;
-    static constexpr int oP = oT + szT;
-    static constexpr int oQ = oP + N * LP;
-    static constexpr int oG = oQ + N * LQ;
-    static constexpr int oEnd = oG + MK * LG;          // sG has MK rows: rows >= M are never written (zero)
-    static constexpr int total = round_up(oEnd + 32, 2);   // slack for wrapped 16-wide reads of the last rows
+    static constexpr int oP = oT;
+    static constexpr int oG = oT + szR2;
+    static constexpr int oQx = oG + MK * LG;
+    static constexpr int oEnd = oG + szG;
+    static constexpr int total = round_up(oEnd + 8, 2);    // + store target of idle lanes
     static constexpr bool supported = (N % 4 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 40 * 1024);
     static constexpr int AB_PAIRS = N * NM / 2;
     static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
@@ -146,41 +159,66 @@ __device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool c
     }
 }
 
+// The lane id, optionally made opaque to the optimiser: see riccati_mfma_lane.inc.
+template <bool ON>
+__device__ __forceinline__ int phase_lane(int lane) {
+    if constexpr (ON) asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 // WAVES = 4: one wave per SIMD (launches that cannot fill two).  WAVES = 8: a 512-thread workgroup owns the
-// whole CU, waves w and w+4 share a SIMD, and waves 4..7 start `stagger` x 64 cycles late: a sweep step
-// alternates a matrix-pipe half (S1, S2, S4, S5) with a vector-pipe half (the LU solve), so two waves that
-// run in lockstep contend for one pipe at a time, while two waves half a step apart keep both pipes busy.
+// whole CU and waves w and w+4 share a SIMD.  A sweep step alternates a vector-pipe half (S1-S3) with a matrix-pipe
+// half (S4-S6); issue priorities by phase (below) keep the wavefronts of a SIMD in different halves.
+// WAVES = 12 (block-diagonal variant, launches of more than 2048 items): three wavefronts per SIMD in 168 registers
+// each and 13.5 KB of LDS per item (12 items = 158 KB of the CU's 160 KB).  The lane terms are recomputed per phase
+// group instead of being kept (riccati_mfma_lane.inc) and the S2 l-values are requested at the top of their own step.
 template <int N, int M, int WAVES, int NS, int NC>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items, int gains_by_item, int stagger) {
+    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus) {
     using C = MfmaCfg<N, M>;
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
     constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
+    // Items are DEALT to workgroups in layers, not blocked.  A workgroup owns a CU (its LDS), so a launch runs in rounds
+    // of n_cus workgroups, and the time of a round is set by the wavefronts per SIMD (measured per 50-step sweep:
+    // 327 us with two, 467 us with three -- whether or not the other SIMDs of the CU, or other CUs, are busy).  The grid
+    // is sized by the host's upper bound on the item count; the live count n is on the device.  Blocked assignment
+    // (slot = WAVES * block + wave) fills the first rounds and leaves a last round that costs as much as a full one.
+    // Instead: a LAYER is one wavefront on every SIMD of every CU (4 n_cus items); n items need ceil(n / layer) layers,
+    // spread as evenly as possible over the fewest rounds that hold them (five layers at WAVES = 12: a round of three
+    // and a round of two, 467 + 327 us instead of 2 x 467).  Surplus wavefronts and workgroups exit at once.
     const int wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * WAVES + wave;
-    if (slot >= (n_items ? *n_items : B)) return;
+    const int n = n_items ? *n_items : B;
+    constexpr int LPR = WAVES / 4;   // layers per round
+    const int per_layer = 4 * n_cus;
+    const int layers = (n + per_layer - 1) / per_layer;
+    const int rounds = (layers + LPR - 1) / LPR;
+    const int round = (int)blockIdx.x / n_cus, cu = (int)blockIdx.x - round * n_cus;
+    if (round >= rounds) return;
+    const int lo = layers / rounds, extra = layers - lo * rounds;   // rounds < extra run lo + 1 layers
+    const int my_layers = lo + (round < extra ? 1 : 0);
+    const int first_layer = round * lo + min(round, extra);
+    if (wave >= 4 * my_layers) return;
+    const int slot = (first_layer + (wave >> 2)) * per_layer + (wave & 3) * n_cus + cu;
+    if (slot >= n) return;
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
-    if (WAVES == 8 && wave >= 4) {   // wave-uniform
-        for (int s = 0; s < stagger; ++s) __builtin_amdgcn_s_sleep(1);
-    }
     const int64_t gslot = gains_by_item ? b : slot;
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, c16 = lane & 15;
+    const int lane0 = threadIdx.x & 63;
     const TileLayout L(N, M);
 
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds = lds_all + wave * C::total;
     double* sAB = lds + C::oAB;
-    double* sMt = sAB;                 // a2 (NP x NP), after S2
     double* sT = lds + C::oT;
     double* sK = lds + C::oK;          // [K | d], KROWS rows (rows >= M zero), after S2
     double* sT3 = lds + C::oT3;        // T3^T, MK rows, after S2
     double* sP = lds + C::oP;
     double* sQ = lds + C::oQ;
     double* sG = lds + C::oG;
+    double* sQx = lds + C::oQx;        // Q_x between the S1 and S2 epilogues
+    double* sMt = sG;                  // a2, after the S5 products
 
     const double mu = mu_arr[b];
     const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
@@ -189,6 +227,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     unsigned long long t_start = 0;
     if (stamps) t_start = __builtin_amdgcn_s_memrealtime();
 
+    constexpr bool ROWLU = (M < 16) && (4 * (16 - M) >= NP);
+    constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
+    constexpr bool BD = NS > 0;
+    constexpr int KA = BD ? N / (BD ? NS : 1) : 1, LPA = 64 / KA, NSC = NS + NC;
+    constexpr int CPL = 2 * ((NP + 2 * LPA - 1) / (2 * LPA));
+    constexpr int RPL = (NM + LPA - 1) / LPA;
+    constexpr int LTB = C::LTB;
+    static_assert(!BD || (NS % 2 == 0 && NC % 2 == 0 && N % 2 == 0 && M % 2 == 0 && CPL == 2),
+                  "block-diagonal variant: 16-byte vector accesses need even block sizes");
+    v2d nbL[RPL][NSC / 2 > 0 ? NSC / 2 : 1];
+    v2d nbX[NSC / 2 > 0 ? NSC / 2 : 1];
+    // WAVES = 12 (three wavefronts per SIMD, 168 registers each): the S2 l-values are requested at the top of their own
+    // step instead of a step ahead, so that they are not held across the register-hungry phases S3-S6
+    constexpr bool LATE_L = BD && (WAVES == 12);
+    v2d nAB[C::AB_ROUNDS];
+    double nL[T_NM][T_NM][4];
+    double nLxu[T_NM][4];
+    constexpr bool REMAT = (WAVES == 12);   // see riccati_mfma_lane.inc
+    {
+    const int lane = lane0;
     for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
     DPILQR_LDS_FENCE();
     {
@@ -200,169 +258,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         for (int i = lane; i < N; i += 64) sP[i * LP + N] = rec[L.oLx + i];
     }
 
-    // ---- lane terms.  For column tile jt this lane's column is j = 16 jt + c16.
-    bool colN[T_NM], colP[T_NM], colNM[T_NM], colLE[T_NM];   // j < n ; j == n ; j < n+m ; j <= n
-    int colG[T_NM];                                          // column of [Q_uu | Q_ux | Q_u] (and of UG in the record) holding global column j
-#pragma unroll
-    for (int jt = 0; jt < T_NM; ++jt) {
-        const int j = 16 * jt + c16;
-        colN[jt] = j < N; colP[jt] = j == N; colNM[jt] = j < NM; colLE[jt] = j <= N;
-        colG[jt] = (j < N) ? M + j : j - N;
-    }
-    // operand pointers X[g][c16]
-    const double* pAB = sAB + g * LAB + c16;
-    const double* pP = sP + g * LP + c16;
-    const double* pT = sT + g * LT + c16;
-    const double* pGuu = sG + g * LG + c16;          // Q_uu columns
-    const double* pGux = sG + g * LG + M + c16;      // [Q_ux | Q_u] columns
-    const double* pK = sK + g * LK + c16;
-    const double* pT3 = sT3 + g * N + c16;
-    // D-element pointers: row-major "[i][j]" = buf + g*LD + c16 ; transposed "[j][i]" = buf + c16*LD + g
-    double* dTt = sT + c16 * LT + g;                 // T^T[j][i']
-    const double* dBt = sAB + c16 * LAB + g;         // B[j][a] sits at [A|B][j][i'] with i' = n + a
-    double* dQ = sQ + g * LQ + c16;                  // Q_xx / V [i][j]
-    const double* dQt = sQ + c16 * LQ + g;           // V[j][i]
-    double* dG = sG + g * LG;                        // + colG[jt]
-    double* dT3 = sT3 + g * N + c16;
-    double* dMt = sMt + g * LM + c16;                // a2[i][j]
-    const double* dMtT = sMt + c16 * LM + g;         // a2[j][i]
-    double* dP = sP + g * LP + c16;
-    // record offsets of this lane's l-values (row part g*ld + column part), see TileLayout
-    const int gLxx = L.oLxx + g * N + c16;           // + 16 jt + (row const) * N
-    const int gUG = L.oLuu + g * L.ldUG;             // + colG[jt] + (row const) * ldUG
-    const int gLxu = L.oLx + g;                      // [l_x ; l_u][i']
-    // [A|B] prefetch -> LDS, S3 epilogue patterns (as in riccati_tiled.hpp)
-    double* sTrash = lds + C::oEnd;
-    double* ab_dst[C::AB_ROUNDS];
-    int ab_src[C::AB_ROUNDS];
-#pragma unroll
-    for (int q = 0; q < C::AB_ROUNDS; ++q) {
-        const int e = 2 * (lane + 64 * q);
-        const int row = e / NM, col = e - row * NM;
-        ab_dst[q] = (e < N * NM) ? sAB + row * LAB + col : sTrash;
-        ab_src[q] = (e < N * NM) ? L.oA + e : 0;
-    }
-    // S3 lane layout.  ROWLU (every size instantiated today): each 16-lane row holds its own copy of the M columns of
-    // Q_uu (lanes 0..M-1 of the row) and 16-M of the n+1 right-hand sides, so that a multiplier or a U entry is
-    // always in the consuming lane's own row (DPP row broadcast) and all 64 lanes work.  Otherwise: lane = column.
-    constexpr bool ROWLU = (M < 16) && (4 * (16 - M) >= NP);
-    const int s3_q = ROWLU ? (16 - M) * g + (c16 - M) : lane - M;                 // right-hand side index
-    const bool s3_rhs = ROWLU ? (c16 >= M && s3_q < NP) : (lane >= M && lane <= M + N);
-    const int s3_col = ROWLU ? (c16 < M ? c16 : min(M + s3_q, M + N)) : (lane < M + N + 1 ? lane : M + N);
-    double* s3_k = s3_rhs ? sK + s3_q : sT3;   // sT3 is not live during S3
-    static_assert((M - 1) * LK < MK * N, "S3's masked columns must fit the dead T3 buffer");
-    constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + 63) / 64;
-    int k_in[K_ROUNDS], k_out[K_ROUNDS];
-#pragma unroll
-    for (int q = 0; q < K_ROUNDS; ++q) {
-        const int e2 = min(lane + 64 * q, K_PAIRS - 1), e = 2 * e2;
-        k_out[q] = e;
-        k_in[q] = (e / N) * LK + (e % N);
-    }
-    const int d_idx = min(lane, M - 1);
-
-    // ---- block-diagonal variant (NS > 0): [A|B] of a MultiDynamicalModel is block diagonal (dynamics.py:173-186:
-    // uniform_block_diag of the agents' (A_i, B_i)), so column i' of [A|B] has its non-zeros in the NS rows of ONE
-    // agent and S1 / S2 need NS terms per output instead of n.  The skipped terms are exact zeros (x + 0*y == x),
-    // so the results are those of the dense sum, term for term.  The record is still read in full -- it is the
-    // dense plugin format -- only the multiplications by structural zeros are dropped; these two phases run on
-    // the vector pipe (NS = 4 rows per block is one MFMA reduction step: a 16-row tile would use 4 of its rows).
-    // Lane (ag, sub): agent ag = lane / LPA.  S1: rows i' of agent ag (NS columns of A, NC of B) x CPL columns
-    // of [P|p];  S2: RPL rows of T x the NS + NC columns of agent ag.  Idle lanes duplicate a working lane
-    // (same addresses, same values), so nothing is predicated.
-    constexpr bool BD = NS > 0;
-    constexpr int KA = BD ? N / (BD ? NS : 1) : 1, LPA = 64 / KA, NSC = NS + NC;
-    constexpr int CPL = 2 * ((NP + 2 * LPA - 1) / (2 * LPA));
-    constexpr int RPL = (NM + LPA - 1) / LPA;
-    constexpr int LTB = C::LTB;
-    static_assert(!BD || (NS % 2 == 0 && NC % 2 == 0 && N % 2 == 0 && M % 2 == 0 && CPL == 2),
-                  "block-diagonal variant: 16-byte vector accesses need even block sizes");
-    const int ag = min(lane / LPA, KA - 1);
-    const int sub1 = min(lane - (lane / LPA) * LPA, (NP - 1) / CPL), j0 = CPL * sub1;   // S1 columns j0, j0+1
-    const int sub2 = min(lane - (lane / LPA) * LPA, (NM - 1) / RPL);
-    const double* bP = sP + NS * ag * LP + j0;                 // P[NS ag + l][j0 ..]
-    const double* bABa = sAB + NS * ag * LAB + NS * ag;        // A block row l
-    const double* bABb = sAB + NS * ag * LAB + N + NC * ag;    // B block row l
-    const double* bBmu[CPL];                                   // B[j][NC ag ..] for the mu B^T term (j < n)
-    bool bMuOn[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) { bMuOn[c] = j0 + c < N; bBmu[c] = sAB + min(j0 + c, N - 1) * LAB + N + NC * ag; }
-    double* bTa = sT + NS * ag * LTB + j0;                     // T[NS ag + r][j0 ..]   (A^T P rows)
-    double* bTb = sT + (N + NC * ag) * LTB + j0;               // T[n + NC ag + r][j0 ..] (B^T P rows)
-    const bool bPcol = (j0 == N);                              // this lane holds A^T p, B^T p
-    const double* bT2[RPL];                                    // S2: T[i'_r][NS ag ..]
-    double* bDa[RPL];                                          // S2 outputs over A's columns: Q_xx row or Q_ux row
-    double* bDb[RPL];                                          //            over B's columns: Q_uu row (or dropped)
-    int bSa[RPL], bSb[RPL];                                    // record offsets of the matching l-values
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-        const int ip = min(RPL * sub2 + r, NM - 1);
-        bT2[r] = sT + ip * LTB + NS * ag;
-        if (ip < N) {
-            bDa[r] = sQ + ip * LQ + NS * ag; bSa[r] = L.oLxx + ip * N + NS * ag;
-            bDb[r] = lds + C::oEnd;          bSb[r] = bSa[r];
-        } else {
-            bDa[r] = sG + (ip - N) * LG + M + NS * ag; bSa[r] = L.oLux + (ip - N) * L.ldUG + NS * ag;
-            bDb[r] = sG + (ip - N) * LG + NC * ag;     bSb[r] = L.oLuu + (ip - N) * L.ldUG + NC * ag;
-        }
-    }
-    const int bSx = L.oLx + NS * ag, bSu = L.oLu + NC * ag;
-    v2d nbL[RPL][NSC / 2 > 0 ? NSC / 2 : 1];
-    v2d nbX[NSC / 2 > 0 ? NSC / 2 : 1];
-    auto prefetch_bd = [&](int t) {
-        const double* rec = base + (int64_t)t * L.stride;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-#pragma unroll
-            for (int q = 0; q < NS / 2; ++q) nbL[r][q] = *reinterpret_cast<const v2d*>(rec + bSa[r] + 2 * q);
-#pragma unroll
-            for (int q = 0; q < NC / 2; ++q) nbL[r][NS / 2 + q] = *reinterpret_cast<const v2d*>(rec + bSb[r] + 2 * q);
-        }
-#pragma unroll
-        for (int q = 0; q < NS / 2; ++q) nbX[q] = *reinterpret_cast<const v2d*>(rec + bSx + 2 * q);
-#pragma unroll
-        for (int q = 0; q < NC / 2; ++q) nbX[NS / 2 + q] = *reinterpret_cast<const v2d*>(rec + bSu + 2 * q);
-    };
-
-    // ---- prefetch registers (one record ahead), re-filled right after they are consumed.  They mirror the D
-    // layout: nL[it][jt][v] is the l-value added to element (it, jt, v) of the S2 product.
-    v2d nAB[C::AB_ROUNDS];
-    double nL[T_NM][T_NM][4];
-    double nLxu[T_NM][4];
-    auto prefetch_ab = [&](int t) {
-        const double* rec = base + (int64_t)t * L.stride;
-#pragma unroll
-        for (int q = 0; q < C::AB_ROUNDS; ++q) nAB[q] = *reinterpret_cast<const v2d*>(rec + ab_src[q]);
-    };
-    auto prefetch_lxu = [&](int t) {   // only the lanes of the p column need it
-        const double* rec = base + (int64_t)t * L.stride + gLxu;
-#pragma unroll
-        for (int it = 0; it < T_NM; ++it) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) nLxu[it][v] = 0.0;
-            for_rows(16 * it, 0, NM, g, colP[N / 16], [&](int v, int r) { nLxu[it][v] = rec[r]; });
-        }
-    };
-    auto prefetch_l = [&](int t) {
-        const double* rec = base + (int64_t)t * L.stride;
-#pragma unroll
-        for (int it = 0; it < T_NM; ++it)
-#pragma unroll
-            for (int jt = 0; jt < T_NM; ++jt) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) nL[it][jt][v] = 0.0;
-                for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { nL[it][jt][v] = rec[gLxx + 16 * jt + r * N]; });
-                for_rows(16 * it, N, NM, g, colNM[jt], [&](int v, int r) { nL[it][jt][v] = rec[gUG + colG[jt] + r * L.ldUG]; });
-            }
-    };
+#include "riccati_mfma_lane.inc"
     prefetch_ab(T - 1);
     if constexpr (BD) {
-        prefetch_bd(T - 1);
+        prefetch_bd_x(T - 1);
+        if constexpr (!LATE_L) prefetch_bd_l(T - 1);
     } else {
         prefetch_lxu(T - 1);
         prefetch_l(T - 1);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see riccati_tiled.hpp
+    }
 
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
@@ -372,10 +278,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 #endif
     for (int t = T - 1; t >= 0; --t) {
         const int tn = t > 0 ? t - 1 : 0;
-        // ---- S0
+        {   // ---- S0, S1
+        const int lane = phase_lane<REMAT>(lane0);
+#include "riccati_mfma_lane.inc"
 #pragma unroll
         for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
         DPILQR_LDS_FENCE();
+        if constexpr (LATE_L) prefetch_bd_l(t);
         prefetch_ab(tn);
         MPHASE(0)
 
@@ -426,7 +335,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
             if (bPcol) {
 #pragma unroll
-                for (int r = 0; r < NS; ++r) sQ[(NS * ag + r) * LQ + N] = ((r & 1) ? nbX[r / 2].y : nbX[r / 2].x) + acc[r][0];
+                for (int r = 0; r < NS; ++r) sQx[NS * ag + r] = ((r & 1) ? nbX[r / 2].y : nbX[r / 2].x) + acc[r][0];
 #pragma unroll
                 for (int r = 0; r < NC; ++r)
                     sG[(NC * ag + r) * LG + M + N] = ((r & 1) ? nbX[NS / 2 + r / 2].y : nbX[NS / 2 + r / 2].x) + acc[NS + r][0];
@@ -447,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                     });
                     // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
                     if (16 * jt <= N && N < 16 * jt + 16) {
-                        for_rows(16 * it, 0, N, g, colP[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = nLxu[it][v] + acc[it][jt][v]; });
+                        for_rows(16 * it, 0, N, g, colP[jt], [&](int v, int r) { sQx[g + r] = nLxu[it][v] + acc[it][jt][v]; });
                         for_rows(16 * it, N, NM, g, colP[jt], [&](int v, int r) { dG[M + N + r * LG] = nLxu[it][v] + acc[it][jt][v]; });
                     }
                 }
@@ -455,18 +364,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         DPILQR_LDS_FENCE();
         if constexpr (!BD) prefetch_lxu(tn);
         MPHASE(1)
+        }
+        {
+        const int lane = phase_lane<REMAT>(lane0);
+#include "riccati_mfma_lane.inc"
 
         // ---- S2: [T1;T2][A|B] -> Q_xx (rows < n, cols < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped
         if constexpr (BD) {
             double acc[RPL][NSC];
             double tv[RPL][NS];
+            {
 #pragma unroll
-            for (int r = 0; r < RPL; ++r)
+                for (int r = 0; r < RPL; ++r)
 #pragma unroll
-                for (int q = 0; q < NS / 2; ++q) {
-                    const v2d v = *reinterpret_cast<const v2d*>(bT2[r] + 2 * q);
-                    tv[r][2 * q] = v.x; tv[r][2 * q + 1] = v.y;
-                }
+                    for (int q = 0; q < NS / 2; ++q) {
+                        const v2d v = *reinterpret_cast<const v2d*>(bT2[r] + 2 * q);
+                        tv[r][2 * q] = v.x; tv[r][2 * q + 1] = v.y;
+                    }
+            }
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
                 double ab[NSC];
@@ -481,9 +396,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                     ab[NS + 2 * q] = v.x; ab[NS + 2 * q + 1] = v.y;
                 }
 #pragma unroll
-                for (int r = 0; r < RPL; ++r)
+                for (int r = 0; r < RPL; ++r) {
+                    const double tvl = tv[r][l];
 #pragma unroll
-                    for (int c = 0; c < NSC; ++c) acc[r][c] = (l == 0) ? tv[r][l] * ab[c] : fma(tv[r][l], ab[c], acc[r][c]);
+                    for (int c = 0; c < NSC; ++c) acc[r][c] = (l == 0) ? tvl * ab[c] : fma(tvl, ab[c], acc[r][c]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
@@ -508,10 +425,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 }
         }
         DPILQR_LDS_FENCE();
-        if constexpr (BD) prefetch_bd(tn); else prefetch_l(tn);
+        if (lane < N) sQ[lane * LQ + N] = sQx[lane];   // Q_x joins Q_xx now that [A|B] is dead
+        if constexpr (BD) { prefetch_bd_x(tn); if constexpr (!LATE_L) prefetch_bd_l(tn); } else prefetch_l(tn);
         // sT is dead from here on and becomes [K | d] + T3^T: the reduction-padding rows of [K | d] must read as zero
         for (int e = lane; e < (C::KROWS - M) * LK; e += 64) sK[M * LK + e] = 0.0;
         MPHASE(2)
+        }
+        {
+        const int lane = phase_lane<REMAT>(lane0);
+#include "riccati_mfma_lane.inc"
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers (vector pipe)
         {
@@ -591,6 +513,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         }
         DPILQR_LDS_FENCE();
         MPHASE(3)
+        }
+        {
+        const int lane = phase_lane<REMAT>(lane0);
+#include "riccati_mfma_lane.inc"
 
         __builtin_amdgcn_s_setprio(0);
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
@@ -609,6 +535,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 
         // ---- S5: a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] ; V = ((Q + a1) + a2) + a2^T   (rows < n, cols <= n)
         {
+            double vb[T_NP][T_NP][4];
             v4d a1[T_NP][T_NP], a2[T_NP][T_NP];
             zero_tiles(a1);
             zero_tiles(a2);
@@ -618,9 +545,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_NP; ++jt)
-                    for_rows(16 * it, 0, NP, g, colLE[jt], [&](int v, int r) { dMt[16 * jt + r * LM] = a2[it][jt][v]; });
+                    for_rows(16 * it, 0, NP, g, colN[jt], [&](int v, int r) { dMt[16 * jt + r * LM] = a2[it][jt][v]; });
             DPILQR_LDS_FENCE();
-            double vb[T_NP][T_NP][4];
 #pragma unroll
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
@@ -636,7 +562,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_NP; ++jt)
-                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = vb[it][jt][v]; });
+                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) { dP[16 * jt + r * LP] = vb[it][jt][v]; });   // V over [K|d], T3^T
             DPILQR_LDS_FENCE();
             // ---- S6: P <- (V + V^T)/2 ; p <- V[:, n]
 #pragma unroll
@@ -644,7 +570,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 #pragma unroll
                 for (int jt = 0; jt < T_NP; ++jt) {
                     for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) {
-                        vb[it][jt][v] = 0.5 * (vb[it][jt][v] + dQt[16 * jt * LQ + r]);
+                        vb[it][jt][v] = 0.5 * (vb[it][jt][v] + dPt[16 * jt * LP + r]);
                     });
                 }
             DPILQR_LDS_FENCE();
@@ -652,13 +578,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_NP; ++jt)
-                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) { dP[16 * jt + r * LP] = vb[it][jt][v]; });
+                    for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { dP[16 * jt + r * LP] = vb[it][jt][v]; });   // p is in place
         }
         DPILQR_LDS_FENCE();
         MPHASE(5)
+        }
     }
-    if (singular && sing && lane == 0) singular[b] = 1;
-    if (stamps && lane == 0) {
+    if (singular && sing && lane0 == 0) singular[b] = 1;
+    if (stamps && lane0 == 0) {
         unsigned hw_id, xcc_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
