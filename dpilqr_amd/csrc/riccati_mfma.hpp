@@ -159,6 +159,66 @@ __device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool c
     }
 }
 
+// In-register LU of S3: lane = column (of Q_uu or of a right-hand side), v[r] = its entry in row r.  SEARCH: with
+// dgetf2's partial pivoting; without, for matrices that are known not to need a row swap (see S3).
+template <bool SEARCH, int M, bool ROWLU>
+__device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[M], int& sing) {
+    double v[M];   // a local copy: the row swap below must stay a chain of register moves, never an indexed access
+#pragma unroll
+    for (int r = 0; r < M; ++r) v[r] = v_io[r];
+#pragma unroll
+    for (int kk = 0; kk < M; ++kk) {
+        if constexpr (SEARCH) {
+            // partial pivoting (dgetf2's idamax): a row swap is needed iff some |v[r]|, r > kk, is strictly
+            // larger than |v[kk]| in column kk.  One max per row decides that; the index search and the
+            // swap run only then.
+            double mx = 0.0;
+#pragma unroll
+            for (int r = kk + 1; r < M; ++r) mx = fmax(mx, fabs(v[r]));
+            const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > fabs(v[kk]));
+            if ((need >> kk) & 1ull) {
+                int piv = kk;
+                double best = fabs(v[kk]);
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r) {
+                    const double av = fabs(v[r]);
+                    piv = (av > best) ? r : piv;
+                    best = fmax(best, av);
+                }
+                piv = __builtin_amdgcn_readlane(piv, kk);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = kk + 1; r < M; ++r)
+                    if (r == piv) {
+                        asm volatile("" ::: "memory");
+                        const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
+                    }
+            }
+        }
+        const double pv = ROWLU ? mov_row(v[kk], kk) : readlane_f64(v[kk], kk);
+        if (SEARCH && pv == 0.0) sing = 1;
+        double inv = __builtin_amdgcn_rcp(pv);
+        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+        invd[kk] = inv;
+        if constexpr (ROWLU) {
+            // every lane scales its own entries; the one that matters (minus the multiplier, in lane kk of the row)
+            // reaches the row inside the fused multiply-add: fma(-l, v[kk], v[r]) with l = v[r]@kk * inv, bit for bit
+            const double ninv = -inv;
+#pragma unroll
+            for (int r = kk + 1; r < M; ++r) v[r] = fmac_row(v[r], v[r] * ninv, v[kk], kk);
+        } else {
+#pragma unroll
+            for (int r = kk + 1; r < M; ++r) {
+                const double l = readlane_f64(v[r], kk) * inv;
+                v[r] = fma(-l, v[kk], v[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) v_io[r] = v[r];
+}
+
 // The lane id, optionally made opaque to the optimiser: see riccati_mfma_lane.inc.
 template <bool ON>
 __device__ __forceinline__ int phase_lane(int lane) {
@@ -441,45 +501,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             double v[M], invd[M];
 #pragma unroll
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + col];
+            // Shortcut for the common case.  If every column of Q_uu is strictly diagonally dominant, partial pivoting
+            // (dgetf2's idamax) moves no row: the diagonal is the strict maximum of its column, and the dominance gap
+            // |a_jj| - sum_{i != j} |a_ij| of a column does not shrink from one Schur complement to the next.  The
+            // 2^-20 relative margin dwarfs the rounding of ten eliminations (element growth <= 2), so the test decides
+            // exactly what the per-column search would decide, and the elimination then runs without the search -- the
+            // ten serial max chains are what the LU's critical path could least afford.  NaNs fail the test.
+            double colsum = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < M; ++kk) {
-                // partial pivoting (dgetf2's idamax): a row swap is needed iff some |v[r]|, r > kk, is strictly
-                // larger than |v[kk]| in column kk.  One max per row decides that; the index search and the swap
-                // run only then (never on the bench's data: Q_uu is strongly diagonal).
-                double mx = 0.0;
-#pragma unroll
-                for (int r = kk + 1; r < M; ++r) mx = fmax(mx, fabs(v[r]));
-                const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > fabs(v[kk]));
-                if ((need >> kk) & 1ull) {
-                    int piv = kk;
-                    double best = fabs(v[kk]);
-#pragma unroll
-                    for (int r = kk + 1; r < M; ++r) {
-                        const double av = fabs(v[r]);
-                        piv = (av > best) ? r : piv;
-                        best = fmax(best, av);
-                    }
-                    piv = __builtin_amdgcn_readlane(piv, kk);
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int r = kk + 1; r < M; ++r)
-                        if (r == piv) {
-                            asm volatile("" ::: "memory");
-                            const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
-                        }
-                }
-                const double pv = ROWLU ? mov_row(v[kk], kk) : readlane_f64(v[kk], kk);
-                if (pv == 0.0) sing = 1;
-                double inv = __builtin_amdgcn_rcp(pv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                invd[kk] = inv;
-#pragma unroll
-                for (int r = kk + 1; r < M; ++r) {
-                    const double l = (ROWLU ? mov_row(v[r], kk) : readlane_f64(v[r], kk)) * inv;
-                    v[r] = fma(-l, v[kk], v[r]);
-                }
-            }
+            for (int r = 0; r < M; ++r) colsum = colsum + fabs(v[r]);
+            const double dg = fabs(sG[s3_dg]);
+            const bool dominant = !s3_lhs || dg * (1.0 - 0x1p-20) > colsum - dg;
+            const bool no_swaps = __builtin_amdgcn_ballot_w64(!dominant) == 0ull;
+            if (no_swaps) lu_eliminate<false, M, ROWLU>(v, invd, sing); else lu_eliminate<true, M, ROWLU>(v, invd, sing);
             if constexpr (ROWLU) {
                 double nv[M];   // minus the solved rows: fma(-U, x, s) == fma(U, -x, s)
 #pragma unroll

@@ -288,42 +288,15 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
             double v[M], invd[M];
 #pragma unroll
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + s3_col];
+            // strictly column-dominant Q_uu: no row moves, the elimination runs without the pivot search
+            // (see S3 of k_riccati_mfma for the argument and the margin)
+            double colsum = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < M; ++kk) {
-                double mx = 0.0;
-#pragma unroll
-                for (int r = kk + 1; r < M; ++r) mx = fmax(mx, fabs(v[r]));
-                const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > fabs(v[kk]));
-                if ((need >> kk) & 1ull) {   // a row must move (dgetf2's idamax): find it, swap
-                    int piv = kk;
-                    double best = fabs(v[kk]);
-#pragma unroll
-                    for (int r = kk + 1; r < M; ++r) {
-                        const double av = fabs(v[r]);
-                        piv = (av > best) ? r : piv;
-                        best = fmax(best, av);
-                    }
-                    piv = __builtin_amdgcn_readlane(piv, kk);
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int r = kk + 1; r < M; ++r)
-                        if (r == piv) {
-                            asm volatile("" ::: "memory");
-                            const double tv = v[r]; v[r] = v[kk]; v[kk] = tv;
-                        }
-                }
-                const double pv = readlane_f64(v[kk], kk);
-                if (pv == 0.0) sing = 1;
-                double inv = __builtin_amdgcn_rcp(pv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                invd[kk] = inv;
-#pragma unroll
-                for (int r = kk + 1; r < M; ++r) {
-                    const double l = readlane_f64(v[r], kk) * inv;
-                    v[r] = fma(-l, v[kk], v[r]);
-                }
-            }
+            for (int r = 0; r < M; ++r) colsum = colsum + fabs(v[r]);
+            const double dg = fabs(sG[min(lane, M - 1) * (LG + 1)]);
+            const bool dominant = lane >= M || dg * (1.0 - 0x1p-20) > colsum - dg;
+            if (__builtin_amdgcn_ballot_w64(!dominant) == 0ull) lu_eliminate<false, M, false>(v, invd, sing);
+            else lu_eliminate<true, M, false>(v, invd, sing);
 #pragma unroll
             for (int r = M - 1; r >= 0; --r) {
                 double s = v[r];
