@@ -287,6 +287,47 @@ def test_sweep_row_pivoting_on_plugin_tiles(dp, k, blocks):
     assert swaps >= B                                       # rows really are exchanged
 
 
+@pytest.mark.parametrize("k,blocks", [(5, (4, 2)), (5, None), (8, (4, 2)), (3, (4, 2))])
+def test_sweep_dominance_shortcut_boundary(dp, k, blocks):
+    """The sweeps skip the pivot search when Q_uu is strictly column dominant (with a 2^-20 margin).  One launch
+    mixes items on both sides of that test: clearly dominant, dominant by less than the margin, not dominant but
+    with the diagonal still the largest entry of its column (no swap either way), and with one larger off-diagonal
+    entry (a swap).  B = 0 makes Q_uu = L_uu at every step, so the test controls the matrix exactly."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(100 + k)
+    n, m, T = 4 * k, 2 * k, 4
+    kinds = ["dominant", "inside_margin", "diag_is_max", "swap"] * 2
+    B = len(kinds)
+    A = np.zeros((B, T, n, n)); Bm = np.zeros((B, T, n, m))
+    for a in range(k):
+        A[:, :, 4 * a:4 * a + 4, 4 * a:4 * a + 4] = np.eye(4) + 0.1 * rng.normal(size=(B, T, 4, 4))
+    S = rng.normal(size=(B, T + 1, n, n)); Lxx = S @ S.transpose(0, 1, 3, 2) / n + np.eye(n)
+    Luu = np.zeros((B, T + 1, m, m))
+    for b, kind in enumerate(kinds):
+        for t in range(T + 1):
+            off = rng.uniform(0.2, 1.0, size=(m, m)) * rng.choice([-1.0, 1.0], size=(m, m))
+            np.fill_diagonal(off, 0.0)
+            colsum = np.abs(off).sum(0)
+            if kind == "dominant":
+                diag = 1.5 * colsum
+            elif kind == "inside_margin":
+                diag = colsum * (1.0 + 2.0 ** -22)       # dominant, but by less than the kernel's margin
+            elif kind == "diag_is_max":
+                diag = np.full(m, 1.05)                   # every |off| <= 1.0 < 1.05, column sums far larger
+            else:
+                diag = np.full(m, 1.05)
+                off[m - 1, 0] = 1.3                       # column 0: the last row must come up
+            Luu[b, t] = off + np.diag(diag * rng.choice([-1.0, 1.0], size=m))
+    Lux = 0.2 * rng.normal(size=(B, T + 1, m, n))
+    Lx = rng.normal(size=(B, T + 1, n)); Lu = rng.normal(size=(B, T + 1, m))
+    tiles = dp.pack_tiles(A, Bm, Lx, Lu, Lxx, Luu, Lux)
+    K, d = dp.backward_pass_tiles(tiles, B, T, n, m, 0.5, blocks=blocks)
+    K, d = K.cpu().numpy(), d.cpu().numpy()
+    for b in range(B):
+        Ko, do = orc.backward_pass_tiles(A[b], Bm[b], Lx[b], Lu[b], Lxx[b], Luu[b], Lux[b], 0.5)
+        assert relerr(K[b], Ko) < 1e-9 and relerr(d[b], do) < 1e-9, (b, kinds[b])
+
+
 @pytest.mark.parametrize("k", [1, 2, 4, 7, 10])
 def test_sweep_six_state_family(dp, k):
     """The 6-state / 3-control family (Quadcopter6D; odd block sizes: no 16-byte alignment to lean on) through the
