@@ -287,6 +287,41 @@ def test_sweep_row_pivoting_on_plugin_tiles(dp, k, blocks):
     assert swaps >= B                                       # rows really are exchanged
 
 
+@pytest.mark.parametrize("upper", [1500, 2600, 6144])
+def test_sweep_item_dealing_over_rounds(dp, upper):
+    """The wavefront sweep sizes its grid by an upper bound and deals the LIVE items (a device-side count) to the CUs
+    in layers of one wavefront per SIMD, over as few rounds as hold them (riccati_mfma.hpp).  Whatever the live count
+    -- one layer, several layers in one round, uneven layers over two rounds, a partly filled last layer -- every
+    live slot must get exactly the gains of a small single-layer launch, and no other slot may be written."""
+    import torch
+    from dpilqr_amd import _lib
+    from dpilqr_amd.device import empty, ptr, stream_handle, to_dev
+    rng = np.random.default_rng(upper)
+    k, T = 5, 6
+    n, m = 4 * k, 2 * k
+    xf = rng.normal(size=(upper, n)); x0 = rng.normal(size=(upper, n)); U = rng.normal(size=(upper, T, m)) * 0.2
+    pb = dp.ProblemBatch([0] * k, [2] * k, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
+    X, _ = pb.rollout(x0, U)
+    tiles = pb.make_tiles(X, U)
+    mu = to_dev(rng.uniform(0, 1, size=upper))
+    lib = _lib.load()
+    K_ref = empty((upper, T, m, n)); d_ref = empty((upper, T, m))
+    for lo in range(0, upper, 200):     # reference: launches that fit one layer on any part
+        cnt = min(200, upper - lo)
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(cnt, T, n, m, 4, 2, ptr(tiles[lo:]), ptr(mu[lo:]), ptr(K_ref[lo:]),
+                                                         ptr(d_ref[lo:]), None, None, None, stream_handle()))
+    items = torch.arange(upper, dtype=torch.int32, device="cuda")
+    lives = sorted({1, 255, 257, 1024, 1025, upper // 2 + 3, upper - 1, upper})
+    for live in [v for v in lives if v <= upper]:
+        K = torch.full((upper, T, m, n), -7.0, dtype=torch.float64, device="cuda"); d = torch.full((upper, T, m), -7.0, dtype=torch.float64, device="cuda")
+        n_items = torch.tensor([live], dtype=torch.int32, device="cuda")
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(upper, T, n, m, 4, 2, ptr(tiles), ptr(mu), ptr(K), ptr(d), None,
+                                                         ptr(items), ptr(n_items), stream_handle()))
+        torch.cuda.synchronize()
+        assert torch.equal(K[:live], K_ref[:live]) and torch.equal(d[:live], d_ref[:live]), live
+        assert bool((K[live:] == -7.0).all()) and bool((d[live:] == -7.0).all()), live
+
+
 @pytest.mark.parametrize("k,blocks", [(5, (4, 2)), (5, None), (8, (4, 2)), (3, (4, 2))])
 def test_sweep_dominance_shortcut_boundary(dp, k, blocks):
     """The sweeps skip the pivot search when Q_uu is strictly column dominant (with a 2^-20 margin).  One launch
