@@ -110,7 +110,9 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
         sel = np.nonzero(u_size == kc)[0]                                                 # sub-problems of this size
         members = np.nonzero(u_mask[sel])[1].reshape(len(sel), kc)                        # sorted agent ids, (Bk, kc)
         rows = u_s[sel][:, None]
-        with torch.cuda.stream(torch.cuda.Stream()):
+        # the current HIP device is per host thread and a new thread starts on device 0: pin this worker to the
+        # caller's GPU (one process per GPU: rank r's buckets must not land on GPU 0)
+        with torch.cuda.device(dev_index), torch.cuda.stream(torch.cuda.Stream(device=dev_index)):
             pb = ProblemBatch(d["model"][members], d["n_dims"][members], xfk[rows, members].reshape(len(sel), kc * n_s),
                               d["Q"][members], d["R"][members], d["Qf"][members], d["radius"], d["dt"], T,
                               w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(sel))
@@ -125,6 +127,7 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
     # buckets are independent and, for a handful of scenarios, small: their solves run concurrently, each on its own
     # HIP stream from its own host thread (the library keeps its per-solve state per thread)
     sizes = [int(v) for v in np.unique(u_size)]
+    dev_index = torch.cuda.current_device()
     torch.cuda.synchronize()
     if concurrent and len(sizes) > 1:
         from concurrent.futures import ThreadPoolExecutor
