@@ -1,5 +1,5 @@
-// riccati_mfma.hpp -- K2 for n_x <= 20: the Riccati backward sweep with one wavefront per sub-problem, two per
-// SIMD (ilqrSolver._backward_pass, control.py:116-148).  The dominant kernel of the cfg2 benchmark.
+// riccati_mfma.hpp -- K2 for n_x <= 20: the Riccati backward sweep with one wavefront per sub-problem, up to three
+// per SIMD (ilqrSolver._backward_pass, control.py:116-148).  The dominant kernel of the cfg2 benchmark.
 //
 // Data flow, LDS residency and record prefetching are those of riccati_tiled.hpp (the previous, all-vector-pipe
 // version, kept as a fallback).  What differs:
@@ -17,9 +17,11 @@
 //    data and only feed outputs that are dropped.
 //  * NS > 0 (the library's own tiles): [A|B] is block diagonal, S1 and S2 need NS terms per output and run on the
 //    vector pipe (see the comment at the lane terms below); NS = 0 (plugin tiles): they are MFMA products too.
-//  * the pivoted LU keeps all 64 lanes busy and takes its multipliers by DPP row broadcast (see S3).
-//  * WAVES = 8: a 512-thread workgroup owns a CU (8 x 20 KB of LDS), two wavefronts per SIMD, placed
-//    deterministically; one wavefront alone gets only half of a SIMD's issue rate.
+//  * the pivoted LU keeps all 64 lanes busy, takes its multipliers by DPP row broadcast and skips the pivot search
+//    for column-dominant Q_uu (see S3 and lu_eliminate).
+//  * a workgroup owns a CU and holds WAVES = 4, 8 or 12 wavefronts (13.5 KB of LDS each), i.e. one, two or three per
+//    SIMD, placed deterministically; one wavefront alone gets only half of a SIMD's issue rate.  The live items of a
+//    launch are dealt to the CUs in layers (see the kernel's first lines).
 //
 //   S1  [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (+ mu B^T on the B rows)   dense: 2x2 tiles x 5 k-steps at cfg2
 //   S2  [T1;T2] [A|B] + l-values -> Q_xx, Q_ux, Q_uu                        dense: 2x2 x 5
