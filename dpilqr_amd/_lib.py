@@ -57,6 +57,7 @@ SIGNATURES = {
     "dpilqr_debug_stamps": (i32, [vp]),
     "dpilqr_profile_enable": (i32, [i32]),
     "dpilqr_profile_read": (i32, [C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
+    "dpilqr_profile_read_sweep": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(i64), i32]),
     "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
 }
 
@@ -119,6 +120,13 @@ def profile_read(reset=True):
     check(load().dpilqr_profile_read(C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
     names = ["tiles", "riccati", "forward", "rollout"]
     return {n: dict(ms=ms[i], launches=ln[i], items=it[i]) for i, n in enumerate(names)}
+
+
+def profile_read_sweep(waves, reset=True):
+    """The wavefront sweep's launches of one variant (waves = 4, 8 or 12 wavefronts per workgroup): ms, launches, items."""
+    ms, ln, it = f64(), i64(), i64()
+    check(load().dpilqr_profile_read_sweep(int(waves), C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
+    return dict(ms=ms.value, launches=ln.value, items=it.value)
 
 
 _device_ok = None

@@ -158,9 +158,12 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
 // compile-time-sized sweeps (one wavefront per sub-problem); everything else takes the generic kernel
 #define DPILQR_TILED_SIZES(X) X(4, 2) X(8, 4) X(12, 6) X(16, 8) X(20, 10)
 
+thread_local int g_sweep_waves = 0;   // wavefronts per workgroup of the last launch_riccati (0: not the wavefront sweep)
+
 int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
                        int gains_by_item, int block_ns, int block_nc, hipStream_t st) {
+    g_sweep_waves = 0;
     if (grid_items <= 0) return DPILQR_OK;
     // block_ns > 0: the caller guarantees that [A|B] is block diagonal with block_ns x (block_ns + block_nc) blocks
     // (tiles made by k_make_tiles from a MultiDynamicalModel); 0: arbitrary dense tiles (the plugin boundary).
@@ -179,6 +182,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         /* wavefronts per workgroup = per CU: 4 (one per SIMD), 8, or 12 when the launch has the items for them */  \
         const int wv = (bd && grid_items > 2048 && max_wv >= 12 && MfmaCfg<NN, MM>::total * 8 * 12 <= kMaxLds) ? 12 \
                        : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
+        g_sweep_waves = wv;                                                                                        \
         const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
         auto kern = wv == 12 ? k_riccati_mfma<NN, MM, 12, 4, 2>                                                    \
                     : wv == 8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)           \
@@ -453,8 +457,11 @@ struct Profiler {
     bool skip = false;
     double ms[4] = {0, 0, 0, 0};
     int64_t launches[4] = {0, 0, 0, 0}, items[4] = {0, 0, 0, 0};
+    // the wavefront sweep's launches by variant (4, 8, 12 wavefronts per workgroup -> index 0, 1, 2)
+    double sweep_ms[3] = {0, 0, 0};
+    int64_t sweep_launches[3] = {0, 0, 0}, sweep_items[3] = {0, 0, 0};
     std::vector<hipEvent_t> pool;
-    struct Rec { int cls, iter; size_t e0; };
+    struct Rec { int cls, iter; size_t e0; int tag; };
     std::vector<Rec> recs;
     size_t used = 0;
     hipEvent_t next() {
@@ -468,14 +475,15 @@ struct Profiler {
     void begin(int cls, int iter, hipStream_t st) {
         skip = !on || !((mask >> cls) & 1);
         if (skip) return;
-        recs.push_back({cls, iter, used});
+        recs.push_back({cls, iter, used, 0});
         hipEvent_t e = next();
         if (e) (void)hipEventRecord(e, st);
     }
-    void end(hipStream_t st) {
+    void end(hipStream_t st, int tag = 0) {   // tag: which variant ran (the sweep: wavefronts per workgroup, else 0)
         if (skip) return;
         hipEvent_t e = next();
         if (e) (void)hipEventRecord(e, st);
+        recs.back().tag = tag;
     }
     // after the stream has been synchronised; active[it] = items processed by iteration it
     void collect(const std::vector<int32_t>& active, int B) {
@@ -483,9 +491,14 @@ struct Profiler {
         for (const Rec& r : recs) {
             float t = 0.f;
             if (r.e0 + 1 < pool.size() && hipEventElapsedTime(&t, pool[r.e0], pool[r.e0 + 1]) == hipSuccess) {
+                const int64_t n_it = (r.iter < 0) ? B : (r.iter < (int)active.size() ? active[r.iter] : 0);
                 ms[r.cls] += t;
                 launches[r.cls] += 1;
-                items[r.cls] += (r.iter < 0) ? B : (r.iter < (int)active.size() ? active[r.iter] : 0);
+                items[r.cls] += n_it;
+                if (r.cls == 1 && (r.tag == 4 || r.tag == 8 || r.tag == 12)) {
+                    const int v = r.tag / 4 - 1;
+                    sweep_ms[v] += t; sweep_launches[v] += 1; sweep_items[v] += n_it;
+                }
             }
         }
         recs.clear();
@@ -753,7 +766,7 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
             if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, D.n_s, D.n_c,
                                      st)))
                 return rc;
-            g_prof.end(st);
+            g_prof.end(st, g_sweep_waves);
             g_prof.begin(2, it, st);
             if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr, S,
                                      cur, cur_n, upper, st)))
@@ -805,6 +818,15 @@ int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4],
         ms[c] = g_prof.ms[c]; launches[c] = g_prof.launches[c]; items[c] = g_prof.items[c];
         if (reset) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; g_prof.items[c] = 0; }
     }
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_profile_read_sweep(int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset) {
+    if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read_sweep: NULL pointer");
+    if (waves != 4 && waves != 8 && waves != 12) return fail(DPILQR_EINVAL, "profile_read_sweep: waves=%d (4, 8 or 12)", waves);
+    const int v = waves / 4 - 1;
+    *ms = g_prof.sweep_ms[v]; *launches = g_prof.sweep_launches[v]; *items = g_prof.sweep_items[v];
+    if (reset) { g_prof.sweep_ms[v] = 0; g_prof.sweep_launches[v] = 0; g_prof.sweep_items[v] = 0; }
     return DPILQR_OK;
 }
 

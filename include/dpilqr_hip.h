@@ -195,6 +195,9 @@ int32_t dpilqr_profile_enable(int32_t enable);
  * {start, end} wall-clock stamps (100 MHz) and the HW_ID / XCC_ID registers of the wave that ran it.   */
 int32_t dpilqr_debug_stamps(void* device_buffer);
 int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset);
+/* the wavefront sweep's share of class 1, by variant: waves = wavefronts per workgroup (4, 8 or 12), i.e. the
+ * k_riccati_mfma<n_x, n_u, waves, ...> instantiation a rocprofv3 kernel trace lists under that name               */
+int32_t dpilqr_profile_read_sweep(int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset);
 
 /* -------------------------------------------------- (6) dispatch front end ("next" row)
  * define_inter_graph_threshold (distributed.py:224-247) for S scenarios at once:
