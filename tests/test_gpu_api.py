@@ -293,3 +293,29 @@ def test_scenarios_sharded_single_rank_equals_front_end(dp, golden):
         dist.destroy_process_group()
     Xd, Ud, Jd, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5)
     assert (Xg == Xd).all() and (Ug == Ud).all() and (Jg == Jd).all() and info["shard"] == (0, S)
+
+
+def test_profile_totals_by_sweep_variant(dp):
+    """dpilqr_profile_read_sweep splits the sweep's profile class by the variant that ran (wavefronts per workgroup),
+    which is how bench.py's roofline object follows ONE kernel name of a rocprofv3 trace: the variants' launches and
+    items add up to the class totals, and the items equal the backward passes the solver counted."""
+    from dpilqr_amd import _lib
+    rng = np.random.default_rng(5)
+    B, k, T = 2500, 5, 8
+    xf = rng.normal(size=(B, 4 * k)); x0 = xf + 0.3 * rng.normal(size=(B, 4 * k))
+    pb = dp.ProblemBatch([0] * k, [2] * k, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
+    _lib.profile_enable(True); _lib.profile_read(reset=True)
+    for w in (4, 8, 12):
+        _lib.profile_read_sweep(w, reset=True)
+    try:
+        r = pb.solve(x0, np.zeros((B, T, 2 * k)), n_lqr_iter=6, tol=1e-3)
+        tot = _lib.profile_read(reset=True)["riccati"]
+        var = {w: _lib.profile_read_sweep(w, reset=True) for w in (4, 8, 12)}
+    finally:
+        _lib.profile_enable(False)
+    assert var[12]["launches"] >= 1 and var[12]["items"] >= B            # the first iteration sweeps all 2500 items
+    assert sum(v["launches"] for v in var.values()) == tot["launches"]
+    assert sum(v["items"] for v in var.values()) == tot["items"] == int(r["n_bwd"].sum().item())
+    assert abs(sum(v["ms"] for v in var.values()) - tot["ms"]) < 1e-6 * max(tot["ms"], 1.0)
+    with pytest.raises(Exception):
+        _lib.profile_read_sweep(5)
