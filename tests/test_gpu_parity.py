@@ -287,17 +287,19 @@ def test_sweep_row_pivoting_on_plugin_tiles(dp, k, blocks):
     assert swaps >= B                                       # rows really are exchanged
 
 
-@pytest.mark.parametrize("upper", [1500, 2600, 6144])
-def test_sweep_item_dealing_over_rounds(dp, upper):
+@pytest.mark.parametrize("upper,k", [(1500, 5), (2600, 5), (6144, 5), (2600, 1), (2600, 2), (3300, 3), (2600, 4)])
+def test_sweep_item_dealing_over_rounds(dp, upper, k):
     """The wavefront sweep sizes its grid by an upper bound and deals the LIVE items (a device-side count) to the CUs
     in layers of one wavefront per SIMD, over as few rounds as hold them (riccati_mfma.hpp).  Whatever the live count
     -- one layer, several layers in one round, uneven layers over two rounds, a partly filled last layer -- every
-    live slot must get exactly the gains of a small single-layer launch, and no other slot may be written."""
+    live slot must get exactly the gains of a small single-layer launch, and no other slot may be written.  The
+    reference launches take the one-wavefront-per-SIMD variant, launches of more than 2048 slots the three-per-SIMD
+    one (recomputed lane terms, late l-value prefetch): bit-identical gains for every cluster size it serves."""
     import torch
     from dpilqr_amd import _lib
     from dpilqr_amd.device import empty, ptr, stream_handle, to_dev
-    rng = np.random.default_rng(upper)
-    k, T = 5, 6
+    rng = np.random.default_rng(upper + k)
+    T = 6
     n, m = 4 * k, 2 * k
     xf = rng.normal(size=(upper, n)); x0 = rng.normal(size=(upper, n)); U = rng.normal(size=(upper, T, m)) * 0.2
     pb = dp.ProblemBatch([0] * k, [2] * k, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
