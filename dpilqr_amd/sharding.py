@@ -23,8 +23,7 @@ def shard_bounds(n_items, world, rank, cost=None):
     c = np.cumsum(np.asarray(cost, dtype=np.float64))
     total = c[-1] if n_items else 0.0
     cuts = [0] + [int(np.searchsorted(c, total * (r + 1) / world, side="left")) + 1 for r in range(world - 1)] + [n_items]
-    cuts = np.minimum.accumulate(np.array(cuts[::-1]))[::-1] if False else np.array(cuts)
-    cuts = np.clip(cuts, 0, n_items)
+    cuts = np.clip(np.array(cuts), 0, n_items)
     for i in range(1, len(cuts)):
         cuts[i] = max(cuts[i], cuts[i - 1])
     return int(cuts[rank]), int(cuts[rank + 1])
