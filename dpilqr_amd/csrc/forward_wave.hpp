@@ -95,11 +95,16 @@ template <int MODEL, int KA>
 struct WaveFwdLds {
     static constexpr int NS = ModelDef<MODEL>::NS, NC = ModelDef<MODEL>::NC;
     static constexpr int n = KA * NS, m = KA * NC, NP = KA * (KA - 1) / 2, NP1 = NP > 0 ? NP : 1;
+    // a candidate's row of dx / x': lanes of different candidates read the same column at once, so the row stride (in
+    // 4-byte banks, mod 64) must not repeat among the 10 candidates: 20 doubles = 40 banks collides for candidates 0/8
+    // and 1/9, 22 doubles does not -- any n that is a multiple of 4 collides.  Line search 0.361 -> 0.345 ms per bench
+    // step.  (The same padding of K[t]'s rows, read by lanes of different agents, measured slower: 0.398 ms.)
+    static constexpr int LDG = (n % 4 == 0) ? n + 2 : n;
     static constexpr int oK = 0;                                   // K[t]  m x n
     static constexpr int od = oK + m * n;                          // d[t]  m
     static constexpr int odx = (od + m + 1) & ~1;                  // dx    [g][n]
-    static constexpr int oxs = odx + DPILQR_N_ALPHA * n;           // x'    [g][n]
-    static constexpr int ocr = oxs + DPILQR_N_ALPHA * n;           // ref cost  [parity][g][KA]
+    static constexpr int oxs = odx + DPILQR_N_ALPHA * LDG;         // x'    [g][LDG]
+    static constexpr int ocr = oxs + DPILQR_N_ALPHA * LDG;         // ref cost  [parity][g][KA]
     static constexpr int ocp = ocr + 2 * DPILQR_N_ALPHA * KA;      // pair cost [parity][g][NP1]
     static constexpr int oJ = ocp + 2 * DPILQR_N_ALPHA * NP1;      // J [g]
     static constexpr int NW = (KA * DPILQR_N_ALPHA + 63) / 64;     // wavefronts per sub-problem
@@ -179,8 +184,8 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 
     double* sK = lds + W::oK;
     double* sd = lds + W::od;
-    double* sdx = lds + W::odx + g * n;
-    double* sxs = lds + W::oxs + g * n;
+    double* sdx = lds + W::odx + g * W::LDG;
+    double* sxs = lds + W::oxs + g * W::LDG;
     double* scr0 = lds + W::ocr + g * KA;            // + parity * NG * KA
     double* scp0 = lds + W::ocp + g * NP1;           // + parity * NG * NP1
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
             if (n % 2 == 0) {
 #pragma unroll 5
                 for (int j = 0; j < n; j += 2) {
-                    const v2d dx2 = *reinterpret_cast<const v2d*>(lds + W::odx + g * n + j);
+                    const v2d dx2 = *reinterpret_cast<const v2d*>(lds + W::odx + g * W::LDG + j);
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
             } else {
 #pragma unroll
                 for (int j = 0; j < n; ++j) {
-                    const double dxj = lds[W::odx + g * n + j];
+                    const double dxj = lds[W::odx + g * W::LDG + j];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
                 }
