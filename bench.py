@@ -9,7 +9,7 @@ One "step" = one complete ilqrSolver.solve of every sub-problem of one such batc
 x0/xf/U0 of all K steps are in HBM before the clock starts).  The K batches (K x 1024 different seeds per
 GPU) are handed to the solver together, the way a Monte-Carlo driver would, and it keeps a WINDOW of 6144
 sub-problems in flight: sub-problems need 1..25 iLQR iterations, so finished ones are retired on the device
-and replaced by not-yet-started ones, and every launch of the hot kernels works on ~6144 sub-problems (three rounds of two sweep wavefronts per SIMD).  All
+and replaced by not-yet-started ones, and every launch of the hot kernels works on ~6144 sub-problems (two rounds of three sweep wavefronts per SIMD).  All
 K x 1024 solves complete inside the timed region.  For N>1 the region also contains the path's one
 collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) of all ranks.
 
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
-    ap.add_argument("--window", type=int, default=6144, help="sub-problems in flight per GPU (a multiple of 2048 = two sweep wavefronts per SIMD)")
+    ap.add_argument("--window", type=int, default=6144, help="sub-problems in flight per GPU (a multiple of 3072 = three sweep wavefronts per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events in the timed run "
                     "(per-kernel breakdown; costs ~4 %% of throughput in dispatch gaps) instead of the Riccati sweep only")

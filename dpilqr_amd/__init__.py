@@ -5,7 +5,7 @@ over hand-written HIP kernels (libdpilqr_hip.so, C ABI in include/dpilqr_hip.h).
 every cost / dynamics / solver evaluation of the recognised plugin types runs on the GPU.
 """
 from . import _lib  # noqa: F401
-from .batch import ProblemBatch, backward_pass_tiles, pack_tiles  # noqa: F401
+from .batch import ProblemBatch, backward_pass_tiles, pack_tiles, release_workspaces  # noqa: F401
 from .bbdynamics import Model, f, integrate, linearize  # noqa: F401
 from .control import ilqrSolver  # noqa: F401
 from .cost import Cost, GameCost, ProximityCost, ReferenceCost, quadraticize_distance  # noqa: F401

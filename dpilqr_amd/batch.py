@@ -31,6 +31,50 @@ def _shared_or_batched(a, B, per_item_shape, dtype):
     raise ValueError(f"expected {per_item_shape} or {(B,) + tuple(per_item_shape)}, got {a.shape}")
 
 
+class _WorkspacePool:
+    """Solve workspaces (GBs each: tile records, gains, line-search candidates of a window of items), shared by all
+    ProblemBatch objects and host threads of the process.  The dispatch front end solves one bucket per cluster size,
+    concurrently, with a different workspace size each and different sizes again on the next call; handing every one
+    to the caching allocator as a fresh odd-sized block made it hoard > 200 GB and then stall for seconds while it
+    gave them back.  Buffers are rounded up to 256 MiB, the smallest free one that fits is reused, a solve returns its
+    buffer when dpilqr_solve_batch has synchronised."""
+    GRANULE = 1 << 28
+    MAX_FREE = 12
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._free = []
+
+    def acquire(self, nbytes):
+        dev = device()
+        with self._lock:
+            fit = [i for i, t in enumerate(self._free) if t.device == dev and t.numel() >= nbytes]
+            if fit:
+                return self._free.pop(min(fit, key=lambda i: self._free[i].numel()))
+        size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
+        return torch.empty(size, dtype=torch.uint8, device=dev)
+
+    def release(self, buf):
+        with self._lock:
+            self._free.append(buf)
+            if len(self._free) > self.MAX_FREE:   # keep the large ones: they serve every request
+                self._free.pop(min(range(len(self._free)), key=lambda i: self._free[i].numel()))
+
+
+    def clear(self):
+        with self._lock:
+            self._free.clear()
+
+
+_workspace_pool = _WorkspacePool()
+
+
+def release_workspaces():
+    """Hand the pooled solve workspaces back to the allocator (they are kept between solves otherwise)."""
+    _workspace_pool.clear()
+
+
 class ProblemBatch:
     """B independent sub-problems with identical (k, n_s, n_c, T), resident in HBM.
 
@@ -76,7 +120,6 @@ class ProblemBatch:
                                    ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
         self._lib = lib
-        self._ws = None
         self.tile_offsets, self.tile_stride = _lib.tile_layout(self.n_x, self.n_u)
 
     # ------------------------------------------------------------------ helpers
@@ -146,24 +189,30 @@ class ProblemBatch:
         return out
 
     # ------------------------------------------------------------------ whole solve
-    def workspace(self, window, gains_in_ws):
-        key = (int(window), bool(gains_in_ws))
-        if self._ws is None or self._ws[0] != key:
-            nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d, key[0], int(key[1]))
-            _lib.check(nbytes)
-            self._ws = (key, torch.empty(nbytes, dtype=torch.uint8, device=device()))
-        return self._ws[1]
+    def workspace_bytes(self, window, gains_in_ws):
+        nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d, int(window), int(bool(gains_in_ws)))
+        _lib.check(nbytes)
+        return int(nbytes)
+
+    def default_window(self):
+        """Items in flight when the caller does not say: 6144 (two rounds of three sweep wavefronts per SIMD on an
+        MI355X) for small clusters, fewer where the per-item buffers are large -- a 10-quadcopter item owns 8.8 MB of
+        tile records, gains and line-search candidates, and several cluster sizes are solved concurrently
+        (dispatch.py) -- so that one solve's workspace stays near 12 GB; never below 1024 (four rounds of the
+        workgroup-per-item sweep)."""
+        T, n, m = self.T, self.n_x, self.n_u
+        per_item = 8 * ((T + 1) * self.tile_stride + T * m * (n + 1) + 10 * ((T + 1) * n + T * m))
+        return int(min(self.B, 6144, max(1024, (12 << 30) // per_item)))
 
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None):
         """ilqrSolver.solve (control.py:150-225) for all B items.
 
-        window: most items in flight at once (default min(B, 6144) = three rounds of two sweep wavefronts per SIMD on an
-        MI355X); finished items are retired on the device and replaced by not-yet-started ones, so launches
-        stay full and memory is bounded.
+        window: most items in flight at once (default: default_window()); finished items are retired on the device and
+        replaced by not-yet-started ones, so launches stay full and memory is bounded.
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
-        window = min(B, 6144) if window is None else int(window)
+        window = self.default_window() if window is None else int(window)
         x0 = self._in(x0, (B, n))
         U = self._in(U0, (B, T, m)).clone()
         X = empty((B, T + 1, n)); J = empty((B,))
@@ -171,10 +220,13 @@ class ProblemBatch:
         tr = torch.full((B, max(n_lqr_iter, 1), 5), float("nan"), dtype=torch.float64, device=device()) if trace else None
         K = empty((B, T, m, n)) if gains else None
         d = empty((B, T, m)) if gains else None
-        ws = self.workspace(window, not gains)
-        _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws),
-                                                ws.numel(), ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd),
-                                                ptr(tr), ptr(K), ptr(d), stream_handle()))
+        ws = _workspace_pool.acquire(self.workspace_bytes(window, not gains))
+        try:
+            _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws),
+                                                    ws.numel(), ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd),
+                                                    ptr(tr), ptr(K), ptr(d), stream_handle()))
+        finally:
+            _workspace_pool.release(ws)   # solve_batch has synchronised its stream: the buffer is idle
         out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
         if trace:
             out["trace"] = tr

@@ -319,3 +319,31 @@ def test_profile_totals_by_sweep_variant(dp):
     assert abs(sum(v["ms"] for v in var.values()) - tot["ms"]) < 1e-6 * max(tot["ms"], 1.0)
     with pytest.raises(Exception):
         _lib.profile_read_sweep(5)
+
+
+def test_solve_workspaces_are_pooled(dp):
+    """Solve workspaces come from one process-wide pool (batch._WorkspacePool): a second solve of any ProblemBatch
+    reuses the first one's buffer, a larger request gets a new (rounded) one, release_workspaces() empties the pool."""
+    from dpilqr_amd import batch
+    rng = np.random.default_rng(11)
+    dp.release_workspaces()
+    pool = batch._workspace_pool
+
+    def solve(B, k):
+        xf = rng.normal(size=(B, 4 * k)); x0 = xf + 0.2 * rng.normal(size=(B, 4 * k))
+        pb = dp.ProblemBatch([0] * k, [2] * k, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, 5)
+        return pb.solve(x0, np.zeros((B, 5, 2 * k)), n_lqr_iter=3)
+
+    solve(64, 3)
+    assert len(pool._free) == 1
+    first = pool._free[0].data_ptr()
+    assert pool._free[0].numel() % batch._WorkspacePool.GRANULE == 0
+    solve(32, 2)                                   # smaller request: the same buffer serves it
+    assert len(pool._free) == 1 and pool._free[0].data_ptr() == first
+    big = pool._free[0].numel() + 1
+    buf = pool.acquire(big)                        # larger than anything pooled: a new buffer, the old one stays
+    assert buf.numel() >= big and len(pool._free) == 1
+    pool.release(buf)
+    assert len(pool._free) == 2
+    dp.release_workspaces()
+    assert len(pool._free) == 0
