@@ -122,7 +122,7 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
         constexpr int rpg = TilesWaveCfg<MODEL, KA, false>::RPG;                                                    \
         const int n_groups = (D.T + 1 + rpg - 1) / rpg;                                                             \
-        const int gpw = n_groups >= 12 ? (n_groups + 3) / 4 : (n_groups + 2) / 3;   /* 3-4 wavefronts per item */   \
+        const int gpw = 1;   /* one wavefront per group of records: measured against 2, 3, 5, 9 groups per wavefront */ \
         const dim3 grid_w((n_groups + gpw - 1) / gpw, grid_items);                                                  \
         const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                                 \
         hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles, items, \

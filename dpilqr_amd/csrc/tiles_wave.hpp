@@ -6,7 +6,7 @@
 // linearize dynamics.py:173-186, GameCost.quadraticize cost.py:208-239, ProximityCost.quadraticize cost.py:135-171).
 // The generic producer gives every (item, step) record its own wavefront, most of whose lanes idle through the pair
 // derivatives and whose instruction stream is index arithmetic and per-entry parameter loads.  Here a wavefront owns a
-// run of consecutive records of one item:
+// run of consecutive records of one item (the solve loop launches one group of RPG records per wavefront):
 //   * Q + Q^T, Q_f + Q_f^T, R + R^T, x_f, n_dims are staged in LDS once per wavefront;
 //   * records are processed in groups of RPG so that the fp64 sqrt / divisions of the pair derivatives run on full
 //     lanes (cfg2: 6 records x 10 pairs = 60 lanes);
