@@ -8,8 +8,8 @@
 // derivatives and whose instruction stream is index arithmetic and per-entry parameter loads.  Here a wavefront owns a
 // run of consecutive records of one item (the solve loop launches one group of RPG records per wavefront):
 //   * Q + Q^T, Q_f + Q_f^T, R + R^T, x_f, n_dims are staged in LDS once per wavefront;
-//   * records are processed in groups of RPG so that the fp64 sqrt / divisions of the pair derivatives run on full
-//     lanes (cfg2: 6 records x 10 pairs = 60 lanes);
+//   * records are processed in groups of RPG so that the fp64 sqrt / divisions of the pair derivatives of several
+//     records run side by side (cfg2: 3 records x 10 pairs = 30 lanes);
 //   * L_xx is written as whole rows in 16-byte pieces (its zeros included): full lines to HBM instead of the generic
 //     kernel's scattered 8-byte entries; L_x, L_u and -- unless DYN_ONLY, see tiles.hpp -- the agents' A, B, L_uu blocks
 //     follow;
@@ -40,7 +40,11 @@ struct TilesWaveCfg {
     static constexpr int NS = ModelDef<MODEL>::NS, NC = ModelDef<MODEL>::NC;
     static constexpr int n = KA * NS, m = KA * NC, NP = KA * (KA - 1) / 2, NP1 = NP > 0 ? NP : 1;
     static constexpr int widest = NP1 > KA ? NP1 : KA;
-    static constexpr int RPG = widest >= 64 ? 1 : (64 / widest > 8 ? 8 : 64 / widest);   // records per group
+    // records per group = per wavefront: enough to fill the lanes of the pair derivatives for one or two agents; from
+    // six pairs on, three records measured best (cfg2: K1 0.246 -> 0.230 ms per bench step against six, 0.241 with two,
+    // 0.244 with four) -- more wavefronts in flight beat fuller lanes
+    static constexpr int RPG_CAP = widest >= 6 ? 3 : 8;
+    static constexpr int RPG = widest >= 64 ? 1 : (64 / widest > RPG_CAP ? RPG_CAP : 64 / widest);
     // per record: e = x - xf [n], u [m], pair gradients [NP1][3], pair Hessians [NP1][9], diagonal sums [KA][9], (A, B blocks)
     static constexpr int oE = 0, oU = oE + n, oG = oU + m, oH = oG + NP1 * 3, oD = oH + NP1 * 9, oA = oD + KA * 9;
     static constexpr int oB = oA + (DYN_ONLY ? 0 : KA * NS * NS);
