@@ -19,6 +19,10 @@ Manifest:
   g4_solves_*.npz    full ilqrSolver.solve incl. decision trace
   g5_dispatch.npz    define_inter_graph_threshold, split_graph, solve_distributed
   g6_scenarios.npz   np.random.seed(s); random_setup(...)
+  g7_callers.npz     solve_rhc (centralized and distributed branch, with the logging rows), selfish_warmstart,
+                     solve_subproblem
+  g8_hetero_*.npz    the zero-padded human model (12 states / 4 controls) mixed with Quadcopter12D: a shim class
+                     built from reference calls (the reference itself cannot mix 12- and 6-state agents)
 
 Run:  python tests/golden/make_golden.py
 """
@@ -70,6 +74,33 @@ MODEL_CLASSES = [
     ("Quadcopter12D", dp.QuadcopterDynamics12D),
 ]
 G = 9.80665
+
+
+class HumanDynamics6DPadded12(dp.DynamicalModel):
+    """BASELINE config 5's "zero-padded" human: HumanDynamics6D carried in a 12-state / 4-control slot so that it
+    can be stacked with QuadcopterDynamics12D (MultiDynamicalModel needs uniform dims, dynamics.py:165-170).
+    Built from reference calls only: the first 6 states / 3 controls are the reference's HumanDynamics6D, the
+    padded states never move (A = 1 on their diagonal, B = 0) and the padded control does nothing."""
+
+    def __init__(self, dt, id=None):
+        super().__init__(12, 4, dt, id)
+        self.human = dp.HumanDynamics6D(dt, self.id)
+
+    def __call__(self, x, u):
+        return np.r_[self.human(np.ascontiguousarray(x[:6]), np.ascontiguousarray(u[:3])), x[6:]]
+
+    def f(self, x, u):
+        return np.r_[self.human.f(np.ascontiguousarray(x[:6]), np.ascontiguousarray(u[:3])), np.zeros(6)]
+
+    def linearize(self, x, u):
+        Ah, Bh = self.human.linearize(np.ascontiguousarray(x[:6]), np.ascontiguousarray(u[:3]))
+        A = np.eye(12); A[:6, :6] = Ah
+        B = np.zeros((12, 4)); B[:6, :3] = Bh
+        return A, B
+
+
+MODEL_ENUM = {c: dp.Model[n].value for n, c in MODEL_CLASSES}
+MODEL_ENUM[HumanDynamics6DPadded12] = 8      # the build's own enum value for the padded model
 
 
 # --------------------------------------------------------------------------- G1
@@ -197,15 +228,22 @@ def build_problem(model_classes, x0, xf, radius, dt, n_dims, ids=None):
     else:
         Q = np.eye(n_s); R = np.eye(n_c)
     Qf = 1000.0 * np.eye(n_s)
+    Qs, Rs, Qfs = [Q.copy() for _ in range(k)], [R.copy() for _ in range(k)], [Qf.copy() for _ in range(k)]
+    for i, c in enumerate(model_classes):
+        if c is HumanDynamics6DPadded12:
+            # the human's weights of examples.py:89-93 (R entry 1e-9 for its unused third control), and the same
+            # 1e-9 for the padded fourth control so that Q_uu stays non-singular; padded states carry no weight
+            Qs[i] = np.diag([1.0, 1, 1, 0, 0, 0] + [0.0] * 6)
+            Rs[i] = np.diag([1.0, 1, 1e-9, 1e-9])
     xf = np.asarray(xf).reshape(-1)
-    refs = [dp.ReferenceCost(xf[i * n_s:(i + 1) * n_s], Q.copy(), R.copy(), Qf.copy(), id_)
+    refs = [dp.ReferenceCost(xf[i * n_s:(i + 1) * n_s], Qs[i], Rs[i], Qfs[i], id_)
             for i, id_ in enumerate(ids)]
     prox = dp.ProximityCost([n_s] * k, radius, list(n_dims))
     prob = dp.ilqrProblem(dp.MultiDynamicalModel(models), dp.GameCost(refs, prox))
-    meta = dict(x0=np.asarray(x0).reshape(-1), xf=xf, Q=np.array([Q] * k), R=np.array([R] * k),
-                Qf=np.array([Qf] * k), radius=np.array(radius), dt=np.array(dt),
+    meta = dict(x0=np.asarray(x0).reshape(-1), xf=xf, Q=np.array(Qs), R=np.array(Rs),
+                Qf=np.array(Qfs), radius=np.array(radius), dt=np.array(dt),
                 n_dims=np.array(n_dims), k=np.array(k), n_s=np.array(n_s), n_c=np.array(n_c),
-                model=np.array([dp.Model[{c: n for n, c in MODEL_CLASSES}[mc]].value for mc in model_classes]),
+                model=np.array([MODEL_ENUM[mc] for mc in model_classes]),
                 ids=np.array(ids))
     return prob, meta
 
@@ -218,6 +256,8 @@ def warm_U(model_classes, T):
             cols.append(np.tile([G, 0, 0], (T, 1)))
         elif c is dp.QuadcopterDynamics12D:
             cols.append(np.tile([0, 0, 0, G * 63.0 / 2000.0], (T, 1)))
+        elif c is HumanDynamics6DPadded12:
+            cols.append(np.zeros((T, 4)))
         else:
             cols.append(np.zeros((T, c(0.1).n_u)))
     return np.hstack(cols)
@@ -427,11 +467,143 @@ def g6_scenarios():
     np.savez_compressed(OUT / "g6_scenarios.npz", **out)
 
 
+# --------------------------------------------------------------------------- G7
+class _Rows(__import__("logging").Handler):
+    def __init__(self):
+        super().__init__()
+        self.rows = []
+
+    def emit(self, record):
+        self.rows.append(record.getMessage())
+
+
+def g7_callers():
+    """The callers either side of the solve: solve_rhc (distributed.py:106-221), ilqrProblem.selfish_warmstart
+    (problem.py:66-91), solve_subproblem (problem.py:97-105)."""
+    import logging
+    out = {}
+    DI, UNI = dp.DoubleIntDynamics4D, dp.UnicycleDynamics4D
+    log = logging.getLogger(); log.setLevel(logging.INFO)
+    for tag, cls, k, N, seed, centralized, kw in (
+            ("rhc_c", DI, 3, 15, 4, True, dict(step_size=5, dist_converge=0.5, t_diverge=3.0)),
+            # (J_converge cannot be pinned: the reference raises NameError there -- n_agents / n_states are only bound
+            #  in the dist_converge branch, distributed.py:134-144 vs :131,189)
+            ("rhc_c2", DI, 5, 20, 11, True, dict(step_size=1, dist_converge=1.5, t_diverge=0.6)),
+            ("rhc_d", UNI, 6, 15, 1, False, dict(step_size=4, dist_converge=0.4, t_diverge=2.0))):
+        prob, meta = analysis_problem(cls, k, seed)
+        np.random.seed(1000 + seed)
+        U_warm = np.random.rand(N, k * int(meta["n_c"])) * 0.01       # what solve_rhc is about to draw (:152)
+        np.random.seed(1000 + seed)
+        h = _Rows(); log.addHandler(h)
+        args = () if centralized else (0.5, [])                      # radius, ignore_ids=[] (quirk Q9)
+        with redirect_stdout(io.StringIO()):
+            Xf, Uf, Jf = dp.solve_rhc(prob, meta["x0"], N, *args, centralized=centralized, i_trial=7, **kw)
+        log.removeHandler(h)
+        for k_, v in meta.items():
+            out[f"{tag}_{k_}"] = v
+        out.update({f"{tag}_N": np.array(N), f"{tag}_np_seed": np.array(1000 + seed), f"{tag}_U_warm": U_warm,
+                    f"{tag}_X_full": Xf, f"{tag}_U_full": Uf, f"{tag}_J_full": np.array(Jf),
+                    f"{tag}_rows": np.array(h.rows), f"{tag}_centralized": np.array(centralized)})
+        for k_, v in kw.items():
+            out[f"{tag}_kw_{k_}"] = np.array(v)
+    # selfish_warmstart
+    for tag, cls, k, N, seed in (("ws_uni", UNI, 3, 20, 5), ("ws_di", DI, 4, 25, 9)):
+        prob, meta = analysis_problem(cls, k, seed)
+        with redirect_stdout(io.StringIO()):
+            Uw = prob.selfish_warmstart(meta["x0"], N)
+        for k_, v in meta.items():
+            out[f"{tag}_{k_}"] = v
+        out.update({f"{tag}_N": np.array(N), f"{tag}_U_warm": Uw})
+    # solve_subproblem on the sub-problems of a proximity graph
+    prob, meta = analysis_problem(UNI, 5, 3)
+    ids = [int(i) for i in meta["ids"]]
+    T = 30
+    U0 = np.zeros((T, 10))
+    graph = dp.define_inter_graph_threshold(meta["x0"].reshape(1, -1), 0.5, prob.game_cost.x_dims, ids)
+    subs = prob.split(graph)
+    x0s = dp.split_graph(meta["x0"].reshape(1, -1), prob.game_cost.x_dims, graph)
+    U0s = dp.split_graph(U0, prob.game_cost.u_dims, graph)
+    for k_, v in meta.items():
+        out[f"sub_{k_}"] = v
+    out["sub_T"] = np.array(T); out["sub_adj"] = graph_to_arrays(graph, ids)
+    for i, id_ in enumerate(ids):
+        Xi, Ui, rid = dp.problem.solve_subproblem((subs[i], x0s[i], U0s[i], id_, False))
+        assert rid == id_
+        out[f"sub_X_{i}"] = Xi; out[f"sub_U_{i}"] = Ui
+    np.savez_compressed(OUT / "g7_callers.npz", **out)
+
+
+# --------------------------------------------------------------------------- G8
+def g8_hetero():
+    """BASELINE config 5's heterogeneous team (QuadcopterDynamics12D + the zero-padded human)."""
+    Q12, HP = dp.QuadcopterDynamics12D, HumanDynamics6DPadded12
+    # the padded model alone, like G1
+    out = {}
+    rng = np.random.default_rng(1008)
+    m = HP(0.1, 500)
+    xs, us, dts, fs, its, As, Bs = [], [], [], [], [], [], []
+    for i in range(8):
+        x = np.r_[rng.uniform(-2, 2, 6), np.zeros(6)]; u = rng.uniform(-1, 1, 4)
+        if i >= 4:
+            x[6:] = rng.uniform(-1, 1, 6)      # the padding is carried through untouched whatever it holds
+        dt = (0.05, 0.1)[i % 2]
+        m = HP(dt, 500)
+        A, B = m.linearize(x, u)
+        xs.append(x); us.append(u); dts.append(dt); fs.append(m.f(x, u)); its.append(m(x, u)); As.append(A); Bs.append(B)
+    out.update(HumanPad12D_x=np.array(xs), HumanPad12D_u=np.array(us), HumanPad12D_dt=np.array(dts),
+               HumanPad12D_f=np.array(fs), HumanPad12D_integrate=np.array(its), HumanPad12D_A=np.array(As),
+               HumanPad12D_B=np.array(Bs))
+    np.savez_compressed(OUT / "g8_hetero_model.npz", **out)
+
+    # k = 3: passes (G3 form, with tiles) and a traced solve (G4 form)
+    mcs = [Q12, Q12, HP]
+    np.random.seed(21)
+    x0, xf = dp.random_setup(3, 12, is_rotation=False, rel_dist=3, var=1.5, n_d=3, random=True, energy=3.0)
+    g3_case("hetero_k3", mcs, 20, 21, [3, 3, 2], x0=x0.reshape(-1), xf=xf.reshape(-1), warm_iters=2)
+    (OUT / "g3_passes_hetero_k3.npz").rename(OUT / "g8_hetero_k3_passes.npz")
+    prob, meta = build_problem(mcs, x0.reshape(-1), xf.reshape(-1), 0.5, 0.1, [3, 3, 2])
+    U0 = warm_U(mcs, 20)
+    r = traced_solve(prob, meta["x0"], U0, 20, n_lqr_iter=12); r.pop("K_last"); r.pop("d_last")
+    np.savez_compressed(OUT / "g8_hetero_k3_solve.npz", **{**meta, **r, "U0": U0, "T": np.array(20)})
+
+    # cfg5 at its stated size: 20 agents (14 quadcopters + 6 humans), T = 150, n_x = 240, n_u = 80.  One backward pass and
+    # the ten forward passes at an operating point one iLQR iteration away from the hover rollout; the gains are 23 MB,
+    # so the fixture keeps K at three steps, all of d, every J and the accepted candidate's trajectory at every tenth step.
+    k, T = 20, 150
+    mcs = [Q12] * 14 + [HP] * 6
+    nd = [3] * 14 + [2] * 6
+    np.random.seed(55)
+    # energy 100 (5 per agent): with analysis.py's 10 the twenty agents start within 0.5 of each other and every
+    # line-search candidate of the reference's first iteration overflows (J = nan)
+    x0, xf = dp.random_setup(k, 12, is_rotation=False, rel_dist=k, var=k / 2, n_d=3, random=True, energy=100.0)
+    prob, meta = build_problem(mcs, x0.reshape(-1), xf.reshape(-1), 0.5, 0.1, nd)
+    U0 = warm_U(mcs, T)
+    s = dp.ilqrSolver(prob, T)
+    Xr, Jr = s._rollout(meta["x0"].reshape(-1, 1), U0)
+    X, U, _ = s.solve(meta["x0"].copy(), U0.copy(), n_lqr_iter=1, verbose=False)
+    mu = s.μ
+    K, d = s._backward_pass(X, U)
+    alphas = 1.1 ** (-np.arange(10, dtype=np.float32) ** 2)
+    _, J_star = s._rollout(meta["x0"].reshape(-1, 1), U)
+    Js, X0f, acc = [], None, -1
+    for i, a in enumerate(alphas):
+        Xn, Un, Jn = s._forward_pass(X, U, K, d, a)
+        Js.append(Jn)
+        if acc < 0 and Jn < J_star:     # the candidate the line search accepts (control.py:183)
+            X0f, U0f, acc = Xn, Un, i
+    keep = np.array([0, 75, 149])
+    out = dict(meta)
+    out.update(T=np.array(T), U0=U0, X_roll_every10=Xr[::10], J_roll=np.array(Jr), X=X, U=U, mu=np.array(mu),
+               K_steps=keep, K_kept=K[keep], d=d, alphas=alphas.astype(np.float64), J_fwd=np.array(Js),
+               J_star=np.array(J_star), acc=np.array(acc), X_fwd_acc_every10=X0f[::10], U_fwd_acc_every10=U0f[::10])
+    np.savez_compressed(OUT / "g8_hetero_k20.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         print("generating", w, flush=True)
         {"g1": g1_models, "g2": g2_costs, "g3": g3_passes, "g4": g4_solves,
-         "g5": g5_dispatch, "g6": g6_scenarios}[w]()
+         "g5": g5_dispatch, "g6": g6_scenarios, "g7": g7_callers, "g8": g8_hetero}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f"{f.name:40s} {f.stat().st_size/1024:8.1f} KiB")
