@@ -32,8 +32,8 @@
 
 /* ------------------------------------------------------------------ models */
 
-static const int MODEL_NS[ORACLE_N_MODELS] = {4, 6, 3, 4, 6, 6, 6, 12}; /* dynamics.py:205-250 */
-static const int MODEL_NC[ORACLE_N_MODELS] = {2, 3, 2, 2, 3, 3, 3, 4};
+static const int MODEL_NS[ORACLE_N_MODELS] = {4, 6, 3, 4, 6, 6, 6, 12, 12}; /* dynamics.py:205-250; 8: padded human */
+static const int MODEL_NC[ORACLE_N_MODELS] = {2, 3, 2, 2, 3, 3, 3, 4, 4};
 
 int oracle_model_dims(int model, int *n_s, int *n_c)
 {
@@ -87,6 +87,16 @@ int oracle_model_f(int model, const double *x, const double *u, double *o)
         o[9] = Q12_TX * u[0] - Q12_CX * wy * wz;
         o[10] = Q12_TY * u[1] + Q12_CY * wx * wz;
         o[11] = Q12_TZ * u[2] - Q12_CZ * wx * wy;
+        return 0;
+    }
+    case ORACLE_HUMAN_PAD_12D: {
+        /* BASELINE config 5's zero-padded human (not a reference model: the reference cannot stack 12- and 6-state
+         * agents, dynamics.py:165-170): HumanDynamics6D (cpp:308-329) in the first 6 states / 3 controls, the
+         * padded states do not move, the padded control does nothing.  Pinned by tests/golden/g8_hetero_*.npz,
+         * which a shim class made of reference calls produced (tests/golden/make_golden.py). */
+        int i;
+        o[0] = x[3] * cos(u[0]); o[1] = x[3] * sin(u[0]); o[2] = 0.0; o[3] = u[1]; o[4] = 0.0; o[5] = 0.0;
+        for (i = 6; i < 12; ++i) o[i] = 0.0;
         return 0;
     }
     default:
@@ -153,6 +163,7 @@ int oracle_model_linearize(int model, const double *x, const double *u, double d
         break;
     }
     case ORACLE_HUMAN_6D:
+    case ORACLE_HUMAN_PAD_12D: /* same entries in the leading 6 x 6 / 6 x 3 corner; the padding's A_c, B_c are zero */
         AA(0, 3) = cos(u[0]); AA(1, 3) = sin(u[0]);
         BB(0, 0) = -x[3] * sin(u[0]); BB(1, 0) = x[3] * cos(u[0]); BB(3, 1) = 1;
         break;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-/* Model enum values: bbdynamicswrap.pyx:8-16 (declaration order, 0..7). */
+/* Model enum values: bbdynamicswrap.pyx:8-16 (declaration order, 0..7); 8 is this build's padded human. */
 enum {
     ORACLE_DOUBLE_INT_4D = 0,
     ORACLE_DOUBLE_INT_6D = 1,
@@ -31,7 +31,8 @@ enum {
     ORACLE_HUMAN_6D = 5,
     ORACLE_HUMAN_LIN_6D = 6,
     ORACLE_QUADCOPTER_12D = 7,
-    ORACLE_N_MODELS = 8
+    ORACLE_HUMAN_PAD_12D = 8, /* not a reference model: HumanDynamics6D zero-padded to 12 states / 4 controls (cfg5) */
+    ORACLE_N_MODELS = 9
 };
 
 /* One centralised (sub)problem: k agents with uniform per-agent dims

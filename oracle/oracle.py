@@ -81,7 +81,7 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 6: (6, 3), 7: (12, 4)}
+MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 6: (6, 3), 7: (12, 4), 8: (12, 4)}
 
 
 def model_f(model, x, u, ref=False):
@@ -291,3 +291,54 @@ def solve_distributed(prob, X, U, radius, n_lqr_iter=50, tol=1e-3):
         U_dec[:, i * nc:(i + 1) * nc] = r["U"][:, pos * nc:(pos + 1) * nc]
     _, J_full = prob.rollout(X[0], U_dec)
     return X_dec, U_dec, J_full, graph
+
+
+def selfish_warmstart(prob, x0, N):
+    """problem.py:66-91: every agent solves alone from U = 0 with the solver's defaults; U_warm stacks the controls."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+    cols = []
+    for i in range(prob.k):
+        sub = prob.with_T(N).subproblem([i])
+        r = sub.solve(x0[i * prob.n_s:(i + 1) * prob.n_s], np.zeros((N, prob.n_c)))
+        cols.append(r["U"])
+    return np.concatenate(cols, axis=1)
+
+
+def solve_rhc(prob, x0, N, U_warm, radius=None, centralized=True, n_d=2, step_size=1, dist_converge=None,
+              t_diverge=None, n_lqr_iter=50, tol=1e-3):
+    """distributed.py:106-221 (dist_converge form; the J_converge form raises NameError in the reference).
+    U_warm is the random warm start the reference draws at :152.  Returns X_full, U_full, J_full and the per-round
+    log fields [(t, J, converged, subgraphs as index lists, distance_left)] the CSV rows are printed from."""
+    k, ns = prob.k, prob.n_s
+    prob = prob.with_T(N)
+    xf = prob.xf
+
+    def left(x):
+        return np.linalg.norm((x - xf).reshape(k, ns)[:, :n_d], axis=1)
+
+    xi = np.asarray(x0, dtype=np.float64).reshape(1, -1)
+    X, U = xi.copy(), np.array(U_warm, dtype=np.float64)
+    t, J, converged = 0, np.inf, True
+    X_full = np.zeros((0, prob.n_x)); U_full = np.zeros((0, prob.n_u))
+    rounds = []
+    while np.any(left(xi.reshape(-1)) > dist_converge):
+        if centralized:
+            r = prob.solve(xi.reshape(-1), U, n_lqr_iter, tol)
+            X, U, J = r["X"], r["U"], r["J"]
+            graphs = [list(range(k))] * k
+        else:
+            X, U, J, g = solve_distributed(prob, X, U, radius, n_lqr_iter, tol)
+            graphs = [g[i] for i in range(k)]
+        xi = X[step_size]
+        X_full = np.r_[X_full, X[:step_size]]; U_full = np.r_[U_full, U[:step_size]]
+        X = np.r_[X[step_size:], np.tile(X[-1], (step_size, 1))]
+        U = np.r_[U[step_size:], np.zeros((step_size, prob.n_u))]
+        rounds.append((t, J, converged, graphs, left(xi).tolist()))
+        if t_diverge and t >= t_diverge:
+            converged = False
+            break
+        t += step_size * prob.dt
+    if not X_full.size and not U_full.size:
+        X_full = np.asarray(x0, dtype=np.float64).copy(); U_full = np.zeros((1, prob.n_u))
+    _, J_full = prob.with_T(U_full.shape[0]).rollout(np.asarray(x0, dtype=np.float64).reshape(-1), U_full)
+    return X_full, U_full, J_full, rounds, converged

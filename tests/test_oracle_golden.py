@@ -10,10 +10,10 @@ TOL_PASS = 1e-10   # single pass: summation order differs from BLAS, nothing els
 TOL_SOLVE = 1e-6   # full solve: 1e-13 perturbations grow ~1e5..1e6x through the iterations (hard part 1)
 
 
-def problem_from(z, prefix=""):
+def problem_from(z, prefix="", T=None):
     g = lambda k: z[prefix + k]
     return orc.Problem(g("model"), g("n_dims"), g("xf"), g("Q"), g("R"), g("Qf"), float(g("radius")), float(g("dt")),
-                       int(g("T")))
+                       int(g("T")) if T is None else int(T))
 
 
 @pytest.mark.parametrize("name", MODEL_NAMES)
@@ -196,3 +196,101 @@ def test_solve_batch_matches_single(golden):
     for i, s in enumerate(seeds):
         assert relerr(r["X"][i], z[f"s{s}_X"]) < TOL_SOLVE
         assert r["n_bwd"][i] == len(z[f"s{s}_mu_trace"])
+
+
+# ---------------------------------------------------------------- G8: the padded human model of BASELINE config 5
+def test_padded_human_model_vs_reference_shim(golden):
+    z = golden("g8_hetero_model")
+    for i in range(len(z["HumanPad12D_x"])):
+        x, u, dt = z["HumanPad12D_x"][i], z["HumanPad12D_u"][i], float(z["HumanPad12D_dt"][i])
+        assert relerr(orc.model_f(8, x, u), z["HumanPad12D_f"][i]) < 1e-15
+        np.testing.assert_array_equal(orc.model_integrate(8, x, u, dt)[6:], x[6:])       # the padding never moves
+        assert relerr(orc.model_integrate(8, x, u, dt), z["HumanPad12D_integrate"][i]) < 1e-14
+        A, B = orc.model_linearize(8, x, u, dt)
+        assert relerr(A, z["HumanPad12D_A"][i]) < 1e-15 and relerr(B, z["HumanPad12D_B"][i]) < 1e-15
+
+
+def test_hetero_k3_passes_and_solve(golden):
+    z = golden("g8_hetero_k3_passes")
+    p = problem_from(z)
+    X, J = p.rollout(z["x0"], z["U0"])
+    assert relerr(X, z["X_roll"]) < 1e-12 and abs(J - z["J_roll"]) < 1e-11 * abs(z["J_roll"])
+    K, d = p.backward_pass(z["X"], z["U"], float(z["mu"]))
+    assert relerr(K, z["K"]) < TOL_PASS and relerr(d, z["d"]) < TOL_PASS
+    for a in range(10):
+        Xn, Un, Jn = p.forward_pass(z["X"], z["U"], z["K"], z["d"], z["alphas"][a])
+        assert relerr(Xn, z["X_fwd"][a]) < TOL_PASS and abs(Jn - z["J_fwd"][a]) < 1e-10 * abs(z["J_fwd"][a])
+    z = golden("g8_hetero_k3_solve")
+    p = problem_from(z)
+    r = p.solve(z["x0"], z["U0"], n_lqr_iter=12)
+    check_solve(r, z, "")
+
+
+def test_hetero_k20_cfg5_size_pass(golden):
+    """cfg5 at its stated size (20 agents, n_x = 240, n_u = 80, T = 150): one backward pass and the ten forward passes."""
+    z = golden("g8_hetero_k20")
+    p = problem_from(z)
+    X, J = p.rollout(z["x0"], z["U0"])
+    assert relerr(X[::10], z["X_roll_every10"]) < 1e-11 and abs(J - z["J_roll"]) < 1e-11 * abs(z["J_roll"])
+    K, d = p.backward_pass(z["X"], z["U"], float(z["mu"]))
+    assert relerr(K[z["K_steps"]], z["K_kept"]) < 1e-7 and relerr(d, z["d"]) < 1e-7
+    acc = int(z["acc"])
+    for a in range(10):
+        Xn, Un, Jn = p.forward_pass(z["X"], z["U"], K, d, z["alphas"][a])
+        if np.isnan(z["J_fwd"][a]):
+            assert not (Jn < float(z["J_star"]))                      # rejected either way (control.py:183)
+        else:
+            assert abs(Jn - z["J_fwd"][a]) < 1e-6 * abs(z["J_fwd"][a])
+        if a == acc:
+            assert relerr(Xn[::10], z["X_fwd_acc_every10"]) < 1e-6 and relerr(Un[::10], z["U_fwd_acc_every10"]) < 1e-6
+
+
+# ---------------------------------------------------------------- G7: the callers either side of the solve
+def parse_row(row):
+    import ast, csv
+    f = next(csv.reader([row]))
+    return dict(model=f[0], n_agents=int(f[1]), i_trial=f[2], centralized=f[3], last=f[4], t=float(f[5]), J=float(f[6]),
+                N=int(f[7]), dt=float(f[8]), converged=f[9], ids=f[10], times=f[11],
+                subgraphs=eval(f[12], {"np": np}), left=ast.literal_eval(f[13]))
+
+
+@pytest.mark.parametrize("tag", ["rhc_c", "rhc_c2", "rhc_d"])
+def test_rhc_vs_reference(golden, tag):
+    z = golden("g7_callers")
+    p = problem_from(z, tag + "_", T=z[tag + "_N"])
+    kw = dict(step_size=int(z[tag + "_kw_step_size"]), dist_converge=float(z[tag + "_kw_dist_converge"]),
+              t_diverge=float(z[tag + "_kw_t_diverge"]))
+    Xf, Uf, Jf, rounds, conv = orc.solve_rhc(p, z[tag + "_x0"], int(z[tag + "_N"]), z[tag + "_U_warm"], radius=0.5,
+                                             centralized=bool(z[tag + "_centralized"]), **kw)
+    assert Xf.shape == z[tag + "_X_full"].shape
+    assert relerr(Xf, z[tag + "_X_full"]) < TOL_SOLVE and relerr(Uf, z[tag + "_U_full"]) < TOL_SOLVE
+    assert abs(Jf - z[tag + "_J_full"]) < TOL_SOLVE * abs(z[tag + "_J_full"])
+    rows = [parse_row(r) for r in z[tag + "_rows"]]
+    assert len(rows) == len(rounds) + 1
+    ids = [int(i) for i in z[tag + "_ids"]]
+    for row, (t, J, c, graphs, left) in zip(rows, rounds):
+        assert abs(row["t"] - t) < 1e-12 and abs(row["J"] - J) < TOL_SOLVE * abs(J) and row["converged"] == str(c)
+        assert [[int(v) for v in g] for g in row["subgraphs"]] == [[ids[i] for i in g] for g in graphs]
+        assert np.allclose(row["left"], left, rtol=1e-6, atol=1e-9)
+    assert rows[-1]["converged"] == str(conv) and rows[-1]["last"] == "True"
+
+
+@pytest.mark.parametrize("tag", ["ws_uni", "ws_di"])
+def test_selfish_warmstart_vs_reference(golden, tag):
+    z = golden("g7_callers")
+    p = problem_from(z, tag + "_", T=z[tag + "_N"])
+    Uw = orc.selfish_warmstart(p, z[tag + "_x0"], int(z[tag + "_N"]))
+    assert relerr(Uw, z[tag + "_U_warm"]) < TOL_SOLVE
+
+
+def test_solve_subproblem_vs_reference(golden):
+    z = golden("g7_callers")
+    p = problem_from(z, "sub_")
+    k, ns, nc, T = p.k, p.n_s, p.n_c, int(z["sub_T"])
+    for i in range(k):
+        idx = [int(j) for j in np.nonzero(z["sub_adj"][i])[0]]
+        sub = p.with_T(T).subproblem(idx)
+        r = sub.solve(np.concatenate([z["sub_x0"][a * ns:(a + 1) * ns] for a in idx]), np.zeros((T, nc * len(idx))))
+        pos = idx.index(i)
+        assert relerr(r["X"][:, pos * ns:(pos + 1) * ns], z[f"sub_X_{i}"]) < TOL_SOLVE
+        assert relerr(r["U"][:, pos * nc:(pos + 1) * nc], z[f"sub_U_{i}"]) < TOL_SOLVE
