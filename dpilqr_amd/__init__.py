@@ -13,7 +13,7 @@ from .dispatch import pairwise_graph, solve_problem_list, solve_scenarios_distri
 from .distributed import (define_inter_graph_threshold, solve_centralized, solve_distributed, solve_rhc,  # noqa: F401
                           solve_rhc_scenarios)
 from .dynamics import (CarDynamics3D, CppModel, DoubleIntDynamics4D, DoubleIntDynamics6D, DynamicalModel,  # noqa: F401
-                       HumanDynamics6D, HumanDynamicsLin6D, MultiDynamicalModel, QuadcopterDynamics6D,
+                       HumanDynamics6D, HumanDynamics6DPadded12, HumanDynamicsLin6D, MultiDynamicalModel, QuadcopterDynamics6D,
                        QuadcopterDynamics12D, UnicycleDynamics4D)
 from .problem import _reset_ids, ilqrProblem, solve_subproblem  # noqa: F401
 from .util import (Point, compute_energy, compute_pairwise_distance, compute_pairwise_distance_nd, distance_to_goal,  # noqa: F401

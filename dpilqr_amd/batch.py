@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from .device import device, empty, ptr, stream_handle, to_dev, zeros
 
-MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 6: (6, 3), 7: (12, 4)}
+MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 6: (6, 3), 7: (12, 4), 8: (12, 4)}
 
 
 def _shared_or_batched(a, B, per_item_shape, dtype):

@@ -24,10 +24,12 @@ class Model(Enum):
     Human6D = 5
     HumanLin6D = 6
     Quadcopter12D = 7
+    HumanPad12D = 8      # this library's own: HumanDynamics6D zero-padded to 12 states / 4 controls (dpilqr_hip.h)
 
 
 MODEL_DIMS = {Model.DoubleInt4D: (4, 2), Model.DoubleInt6D: (6, 3), Model.Car3D: (3, 2), Model.Unicycle4D: (4, 2),
-              Model.Quadcopter6D: (6, 3), Model.Human6D: (6, 3), Model.HumanLin6D: (6, 3), Model.Quadcopter12D: (12, 4)}
+              Model.Quadcopter6D: (6, 3), Model.Human6D: (6, 3), Model.HumanLin6D: (6, 3), Model.Quadcopter12D: (12, 4),
+              Model.HumanPad12D: (12, 4)}
 
 
 def _check(model, x, u):

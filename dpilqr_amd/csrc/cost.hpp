@@ -15,42 +15,44 @@ namespace dpilqr {
 // index of pair (i<j) in itertools.combinations(range(k),2) order (util.py:56, cost.py:143-144)
 __host__ __device__ inline int pair_index(int i, int j, int k) { return i * (2 * k - i - 1) / 2 + (j - i - 1); }
 
-// One pair of ProximityCost.__call__ (cost.py:117-133): fmin(0, |a-b| - r)^2 over the first nd coordinates
-__device__ inline double pair_cost(const double* a, const double* b, int nd, double radius) {
-    double s = 0.0;
+// One pair of ProximityCost.__call__ (cost.py:117-133): fmin(0, |a-b| - r)^2 over the first nd coordinates.
+// R: the arithmetic type (double; float in the fp32 arm of BASELINE config 5's tolerance study)
+template <typename R>
+__device__ inline R pair_cost(const R* a, const R* b, int nd, R radius) {
+    R s = 0.0;
     for (int c = 0; c < nd; ++c) {
-        const double df = a[c] - b[c];
+        const R df = a[c] - b[c];
         s += df * df;
     }
-    // far pairs contribute exactly 0: skip the fp64 square root when d^2 is safely beyond r^2
-    // (fmin(0, d - r) = 0 whenever d > r; the 1e-12 margin covers the rounding of r*r and of sqrt)
-    if (s > radius * radius * (1.0 + 1e-12)) return 0.0;
-    const double m = fmin(0.0, sqrt(s) - radius);
+    // far pairs contribute exactly 0: skip the square root when d^2 is safely beyond r^2
+    // (fmin(0, d - r) = 0 whenever d > r; the margin covers the rounding of r*r and of sqrt)
+    if (s > radius * radius * (R(1.0) + R(sizeof(R) == 8 ? 1e-12 : 1e-5))) return R(0.0);
+    const R m = fmin(R(0.0), sqrt(s) - radius);
     return m * m;
 }
 
 // quadraticize_distance (cost.py:269-315): g[3], H[9]; entries at or beyond nd are zero.
-__device__ inline void pair_quadraticize(const double* pa, const double* pb, int nd, double radius, double* g,
-                                         double* H) {
-    double a[3] = {0.0, 0.0, 0.0}, b[3] = {0.0, 0.0, 0.0};
+template <typename R>
+__device__ inline void pair_quadraticize(const R* pa, const R* pb, int nd, R radius, R* g, R* H) {
+    R a[3] = {0.0, 0.0, 0.0}, b[3] = {0.0, 0.0, 0.0};
     for (int c = 0; c < 3; ++c)
         if (c < nd) { a[c] = pa[c]; b[c] = pb[c]; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) g[c] = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) H[c] = 0.0;
-    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-    const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+    const R dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    const R dist = sqrt(dx * dx + dy * dy + dz * dz);
     if (dist > radius) return;  // active iff not (distance > radius): quirk Q7
-    const double gs = 2 * (dist - radius) / dist;
-    const double dd[3] = {dx, dy, dz};
+    const R gs = 2 * (dist - radius) / dist;
+    const R dd[3] = {dx, dy, dz};
     // the cross terms use the distance recomputed as |a|^2 + |b|^2 - 2 a.b (cost.py:293-303)
-    const double h2a = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
-    const double h2b = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
-    const double dalt = sqrt((h2a + h2b) - 2 * (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]));
-    const double cross = 2 * radius / (dalt * dalt * dalt);
-    const double d3 = dist * dist * dist;
-    double HH[9];
+    const R h2a = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    const R h2b = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+    const R dalt = sqrt((h2a + h2b) - 2 * (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]));
+    const R cross = 2 * radius / (dalt * dalt * dalt);
+    const R d3 = dist * dist * dist;
+    R HH[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) HH[c] = 0.0;
 #pragma unroll
@@ -67,28 +69,28 @@ __device__ inline void pair_quadraticize(const double* pa, const double* pb, int
     }
 }
 
-// ReferenceCost.__call__ (cost.py:79-83) for one agent: ((e @ M) @ e) [+ ((u @ R) @ u)]
-template <int NS, int NC>
-__device__ inline double ref_cost(const double* x, const double* u, const double* xf, const double* M,
-                                  const double* R, bool terminal) {
-    double e[NS];
+// ReferenceCost.__call__ (cost.py:79-83) for one agent: ((e @ M) @ e) [+ ((u @ R) @ u)].  The weights and the goal
+// come from the descriptor (fp64) and are rounded to the arithmetic type on use.
+template <int NS, int NC, typename R>
+__device__ inline R ref_cost(const R* x, const R* u, const double* xf, const double* M, const double* Rm, bool terminal) {
+    R e[NS];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) e[i] = x[i] - xf[i];
-    double c = 0.0;
+    for (int i = 0; i < NS; ++i) e[i] = x[i] - R(xf[i]);
+    R c = 0.0;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        double v = 0.0;
+        R v = 0.0;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) v += e[i] * M[i * NS + j];
+        for (int i = 0; i < NS; ++i) v += e[i] * R(M[i * NS + j]);
         c += v * e[j];
     }
     if (terminal) return c;
-    double cu = 0.0;
+    R cu = 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        double v = 0.0;
+        R v = 0.0;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) v += u[i] * R[i * NC + j];
+        for (int i = 0; i < NC; ++i) v += u[i] * R(Rm[i * NC + j]);
         cu += v * u[j];
     }
     return c + cu;

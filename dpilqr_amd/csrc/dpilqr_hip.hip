@@ -13,21 +13,13 @@
 #include <vector>
 
 #include "dpilqr_hip.h"
-#include "forward.hpp"
-#include "models.hpp"
-#include "riccati.hpp"
-#include "riccati_mfma.hpp"
-#include "forward_wave.hpp"
-#include "riccati_wg.hpp"
-#include "tiles_wave.hpp"
-#include "riccati_tiled.hpp"
-#include "tiles.hpp"
+#include "launch.hpp"
+#include "models.hpp"    // model_ns / model_nc (host-visible)
+#include "tiles.hpp"     // TileLayout (host-visible)
 
-using namespace dpilqr;
+namespace dpilqr {
 
-namespace {
-
-thread_local char g_err[512] = "";
+static thread_local char g_err[512] = "";
 
 int32_t fail(int32_t code, const char* fmt, ...) {
     va_list ap;
@@ -36,14 +28,27 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+const char* last_error() { return g_err; }
 
-#define HIP_TRY(expr)                                                                                 \
-    do {                                                                                              \
-        hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess) return fail(DPILQR_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+// compute units of the current device (256 on MI355X), remembered per device
+int device_cus() {
+    static int cus_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus_of[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus_of[dev] = n;
+    }
+    return cus_of[dev];
+}
 
-constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+}  // namespace dpilqr
+
+using namespace dpilqr;
+
+namespace {
+
 constexpr int kMaxAgents = 64;
 
 int family_nc(int ns) { return ns == 3 ? 2 : ns == 4 ? 2 : ns == 6 ? 3 : ns == 12 ? 4 : -1; }
@@ -60,293 +65,6 @@ int32_t check_desc(const dpilqr_batch_desc* d) {
 }
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-// compute units of the current device (256 on MI355X): the sweep deals its items over rounds of this many workgroups
-int device_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return n;
-    }();
-    return cus;
-}
-
-// hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
-inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
-inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
-
-template <typename Kern>
-int32_t allow_lds(Kern kern, size_t bytes) {
-    if (bytes > (size_t)kMaxLds) return fail(DPILQR_EUNSUPPORTED, "needs %zu B of LDS per workgroup (> %d)", bytes, kMaxLds);
-    if (bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return DPILQR_OK;
-}
-
-// run `body` with the (NS,NC) family as compile-time constants
-#define DISPATCH_FAMILY(ns, BODY)                                                         \
-    switch (ns) {                                                                         \
-    case 3:  { constexpr int NS = 3,  NC = 2; BODY } break;                               \
-    case 4:  { constexpr int NS = 4,  NC = 2; BODY } break;                               \
-    case 6:  { constexpr int NS = 6,  NC = 3; BODY } break;                               \
-    case 12: { constexpr int NS = 12, NC = 4; BODY } break;                               \
-    default: return fail(DPILQR_EINVAL, "unsupported per-agent state dim %d", (int)(ns)); \
-    }
-
-int riccati_threads(int n) { return n <= 24 ? 64 : (n <= 36 ? 128 : 256); }
-
-int forward_threads(int k, int ngrp) {
-    const int t = ((k * ngrp + 63) / 64) * 64;
-    return t;
-}
-
-int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
-                          const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, bool dyn_only,
-                          hipStream_t st) {
-    if (grid_items <= 0) return DPILQR_OK;
-    static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
-    if (force_dense) sparse = false;
-    if (!sparse) dyn_only = false;
-    // the solve loop's producer for a batch of one linear model whose (X, U)-independent entries are already in place:
-    // kernels compiled per (model, agents), tiles_wave.hpp.  (Measured: for the other cases -- A, B to be written too,
-    // or more than 6 agents -- the generic producer's sparse stores are the faster ones.)
-    static const bool no_wave = getenv("DPILQR_TILES_GENERIC") != nullptr;   // A/B switch
-    if (sparse && dyn_only && !no_wave && hint_model(D) >= 0) {
-        const int model = hint_model(D);
-        // rows of L_xx beyond the proximity cost's dimensions hold w_ref (Q + Q^T) only: with one Q, Q_f for the batch they
-        // were placed with A, B, L_uu and are skipped as well
-        const int und = hint_n_dims(D);
-        const int xx_rows = (D.Q_bstride == 0 && D.Qf_bstride == 0 && und >= 1 && und < D.n_s) ? und : D.n_s;
-#define DPILQR_TRY_TW(MODEL, KA, LINEAR)                                                                            \
-    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
-        constexpr int rpg = TilesWaveCfg<MODEL, KA, false>::RPG;                                                    \
-        const int n_groups = (D.T + 1 + rpg - 1) / rpg;                                                             \
-        const int gpw = 1;   /* one wavefront per group of records: measured against 2, 3, 5, 9 groups per wavefront */ \
-        const dim3 grid_w((n_groups + gpw - 1) / gpw, grid_items);                                                  \
-        const size_t lds_w = sizeof(double) * TilesWaveCfg<MODEL, KA, true>::total;                                 \
-        hipLaunchKernelGGL((k_make_tiles_wave<MODEL, KA, true>), grid_w, dim3(64), lds_w, st, D, X, U, tiles, items, \
-                           n_items, gpw, xx_rows);                                                                  \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return DPILQR_OK;                                                                                           \
-    }
-#define DPILQR_TW_6(MODEL, LINEAR) DPILQR_TRY_TW(MODEL, 1, LINEAR) DPILQR_TRY_TW(MODEL, 2, LINEAR)                  \
-        DPILQR_TRY_TW(MODEL, 3, LINEAR) DPILQR_TRY_TW(MODEL, 4, LINEAR) DPILQR_TRY_TW(MODEL, 5, LINEAR)             \
-        DPILQR_TRY_TW(MODEL, 6, LINEAR)
-        DPILQR_TW_6(kDoubleInt4D, true)
-#undef DPILQR_TW_6
-#undef DPILQR_TRY_TW
-    }
-    const int ts = make_tiles_steps(D.k, D.n_s, D.n_c);
-    const size_t lds = make_tiles_lds_bytes(D.k, D.n_s, D.n_c, ts);
-    dim3 grid((D.T + 1 + ts - 1) / ts, grid_items);
-    DISPATCH_FAMILY(D.n_s, {
-        int32_t rc = allow_lds(k_make_tiles<NS, NC, false>, lds);
-        if (rc) return rc;
-        if (sparse) {
-            if ((rc = allow_lds(k_make_tiles<NS, NC, true>, lds))) return rc;
-            hipLaunchKernelGGL((k_make_tiles<NS, NC, true>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts,
-                               dyn_only ? 1 : 0);
-        } else {
-            hipLaunchKernelGGL((k_make_tiles<NS, NC, false>), grid, dim3(64), lds, st, D, X, U, tiles, items, n_items, ts, 0);
-        }
-    })
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
-}
-
-// compile-time-sized sweeps (one wavefront per sub-problem); everything else takes the generic kernel
-#define DPILQR_TILED_SIZES(X) X(4, 2) X(8, 4) X(12, 6) X(16, 8) X(20, 10)
-
-thread_local int g_sweep_waves = 0;   // wavefronts per workgroup of the last launch_riccati (0: not the wavefront sweep)
-
-int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
-                       int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
-                       int gains_by_item, int block_ns, int block_nc, hipStream_t st) {
-    g_sweep_waves = 0;
-    if (grid_items <= 0) return DPILQR_OK;
-    // block_ns > 0: the caller guarantees that [A|B] is block diagonal with block_ns x (block_ns + block_nc) blocks
-    // (tiles made by k_make_tiles from a MultiDynamicalModel); 0: arbitrary dense tiles (the plugin boundary).
-    static const bool no_bd = getenv("DPILQR_RICCATI_DENSE") != nullptr;   // A/B switch
-    const bool bd = !no_bd && block_ns == 4 && block_nc == 2 && n == 4 * (m / 2) && m % 2 == 0;
-    // sweep selection: matrix-pipe kernel where instantiated, else the vector-pipe tiled kernel, else the generic one
-    // (DPILQR_RICCATI=mfma|tiled|generic pins one for A/B measurements)
-    static const char* pick_env = getenv("DPILQR_RICCATI");
-    static const int pick = getenv("DPILQR_FORCE_GENERIC_RICCATI") ? 2
-                            : (!pick_env ? 0 : (!strcmp(pick_env, "tiled") ? 1 : (!strcmp(pick_env, "generic") ? 2 : 0)));
-    if (pick == 0) {
-#define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
-    if (n == NN && m == MM) {                                                                                      \
-        static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
-        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;            \
-        /* wavefronts per workgroup = per CU: 4 (one per SIMD), 8, or 12 when the launch has the items for them */  \
-        const int wv = (bd && grid_items > 2048 && max_wv >= 12 && MfmaCfg<NN, MM>::total * 8 * 12 <= kMaxLds) ? 12 \
-                       : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
-        g_sweep_waves = wv;                                                                                        \
-        const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
-        auto kern = wv == 12 ? k_riccati_mfma<NN, MM, 12, 4, 2>                                                    \
-                    : wv == 8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)           \
-                              : (bd ? k_riccati_mfma<NN, MM, 4, 4, 2> : k_riccati_mfma<NN, MM, 4, 0, 0>);          \
-        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
-        if (rc_t) return rc_t;                                                                                     \
-        /* whole rounds of one workgroup per CU; the kernel deals the live items over them (riccati_mfma.hpp) */    \
-        const int cus = device_cus();                                                                              \
-        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d,                      \
-                           singular, items, n_items, gains_by_item, cus);                                          \
-        HIP_TRY(hipGetLastError());                                                                                \
-        return DPILQR_OK;                                                                                          \
-    }
-        DPILQR_TILED_SIZES(DPILQR_TRY_MFMA)
-#undef DPILQR_TRY_MFMA
-    }
-    // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
-    static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
-    if (pick == 0 && !no_wg && block_ns > 0) {
-#define DPILQR_TRY_WG(KK, NS_, NC_)                                                                                 \
-    if (block_ns == NS_ && block_nc == NC_ && n == KK * NS_ && m == KK * NC_) {                                     \
-        using WC = WgCfg<KK * NS_, KK * NC_, NS_, NC_>;                                                             \
-        static_assert(WC::supported, "workgroup sweep not available for this size");                                \
-        const size_t lds_w = sizeof(double) * WC::total;                                                            \
-        int32_t rc_w = allow_lds(k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>, lds_w);                                \
-        if (rc_w) return rc_w;                                                                                      \
-        hipLaunchKernelGGL((k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>), dim3(grid_items), dim3(kWgThreads), lds_w, \
-                           st, B, T, tiles, mu, K, d, singular, items, n_items, gains_by_item);                     \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return DPILQR_OK;                                                                                           \
-    }
-        // four-state models (DoubleInt4D, Unicycle4D), 6..15 agents; six-state models (DoubleInt6D, Quadcopter6D,
-        // Human6D, HumanLin6D), 2..10 agents
-        DPILQR_TRY_WG(6, 4, 2) DPILQR_TRY_WG(7, 4, 2) DPILQR_TRY_WG(8, 4, 2) DPILQR_TRY_WG(9, 4, 2) DPILQR_TRY_WG(10, 4, 2)
-        DPILQR_TRY_WG(11, 4, 2) DPILQR_TRY_WG(12, 4, 2) DPILQR_TRY_WG(13, 4, 2) DPILQR_TRY_WG(14, 4, 2) DPILQR_TRY_WG(15, 4, 2)
-        DPILQR_TRY_WG(2, 6, 3) DPILQR_TRY_WG(3, 6, 3) DPILQR_TRY_WG(4, 6, 3) DPILQR_TRY_WG(5, 6, 3) DPILQR_TRY_WG(6, 6, 3)
-        DPILQR_TRY_WG(7, 6, 3) DPILQR_TRY_WG(8, 6, 3) DPILQR_TRY_WG(9, 6, 3) DPILQR_TRY_WG(10, 6, 3)
-        // Quadcopter12D, 2..5 agents
-        DPILQR_TRY_WG(2, 12, 4) DPILQR_TRY_WG(3, 12, 4) DPILQR_TRY_WG(4, 12, 4) DPILQR_TRY_WG(5, 12, 4)
-#undef DPILQR_TRY_WG
-    }
-    if (pick <= 1) {
-#define DPILQR_TRY_TILED(NN, MM)                                                                                   \
-    if (n == NN && m == MM) {                                                                                      \
-        static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
-        const size_t lds_t = sizeof(double) * TiledCfg<NN, MM>::total * kTiledWaves;                              \
-        int32_t rc_t = allow_lds(k_riccati_tiled<NN, MM>, lds_t);                                                  \
-        if (rc_t) return rc_t;                                                                                     \
-        hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3((grid_items + kTiledWaves - 1) / kTiledWaves),          \
-                           dim3(64 * kTiledWaves), lds_t, st, B, T, tiles, mu, K, d, singular, items, n_items,     \
-                           gains_by_item);                                                                         \
-        HIP_TRY(hipGetLastError());                                                                                \
-        return DPILQR_OK;                                                                                          \
-    }
-        DPILQR_TILED_SIZES(DPILQR_TRY_TILED)
-#undef DPILQR_TRY_TILED
-    }
-    const size_t lds = riccati_lds_bytes(n, m);
-    int32_t rc = allow_lds(k_riccati_generic, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_riccati_generic, dim3(grid_items), dim3(riccati_threads(n)), lds, st, B, T, n, m, tiles, mu, K,
-                       d, singular, items, n_items, gains_by_item);
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
-}
-
-static bool no_wave_ro() { static const bool v = getenv("DPILQR_FORWARD_GENERIC") != nullptr; return v; }
-
-int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
-                       const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
-                       const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
-                       hipStream_t st) {
-    if (grid_items <= 0) return DPILQR_OK;
-    const int n = D.k * D.n_s, m = D.k * D.n_c;
-    int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
-    if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
-    const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
-    if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
-        return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
-    if (!no_wave_ro() && mode == kModeRollout && hint_model(D) >= 0 && !items) {
-        const int model = hint_model(D);
-#define DPILQR_TRY_RO(MODEL, KA)                                                                                    \
-    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
-        using WR = WaveRolloutLds<MODEL, KA>;                                                                       \
-        const int per_wg = 4 * WR::IPW;                                                                             \
-        hipLaunchKernelGGL((k_rollout_wave<MODEL, KA>), dim3((grid_items + per_wg - 1) / per_wg), dim3(256),        \
-                           sizeof(double) * WR::total * 4, st, D, x0, U, X, Jc);                                    \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return DPILQR_OK;                                                                                           \
-    }
-#define DPILQR_RO_10(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)                \
-        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6) DPILQR_TRY_RO(MODEL, 7)             \
-        DPILQR_TRY_RO(MODEL, 8) DPILQR_TRY_RO(MODEL, 9) DPILQR_TRY_RO(MODEL, 10)
-#define DPILQR_RO_15(MODEL) DPILQR_RO_10(MODEL) DPILQR_TRY_RO(MODEL, 11) DPILQR_TRY_RO(MODEL, 12)                   \
-        DPILQR_TRY_RO(MODEL, 13) DPILQR_TRY_RO(MODEL, 14) DPILQR_TRY_RO(MODEL, 15)
-        DPILQR_RO_15(kDoubleInt4D)
-        DPILQR_RO_15(kUnicycle4D)
-        DPILQR_RO_10(kQuadcopter6D)
-#define DPILQR_RO_6(MODEL) DPILQR_TRY_RO(MODEL, 1) DPILQR_TRY_RO(MODEL, 2) DPILQR_TRY_RO(MODEL, 3)                 \
-        DPILQR_TRY_RO(MODEL, 4) DPILQR_TRY_RO(MODEL, 5) DPILQR_TRY_RO(MODEL, 6)
-        DPILQR_RO_6(kDoubleInt6D)
-        DPILQR_RO_6(kCar3D)
-        DPILQR_RO_6(kHuman6D)
-        DPILQR_RO_6(kHumanLin6D)
-        DPILQR_TRY_RO(kQuadcopter12D, 1) DPILQR_TRY_RO(kQuadcopter12D, 2) DPILQR_TRY_RO(kQuadcopter12D, 3)
-        DPILQR_TRY_RO(kQuadcopter12D, 4) DPILQR_TRY_RO(kQuadcopter12D, 5)
-#undef DPILQR_RO_6
-#undef DPILQR_RO_15
-#undef DPILQR_RO_10
-#undef DPILQR_TRY_RO
-    }
-    // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
-    // compiled for (model, agents), see forward_wave.hpp
-    static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch
-    if (!no_wave && mode == kModeLineSearch && hint_model(D) >= 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
-        const int model = hint_model(D);
-#define DPILQR_TRY_WAVE(MODEL, KA)                                                                                  \
-    if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
-        using WF = WaveFwdLds<MODEL, KA>;                                                                           \
-        const size_t lds_w = sizeof(double) * WF::total * WF::IPB;                                                  \
-        int32_t rc_w = allow_lds(k_linesearch_wave<MODEL, KA>, lds_w);                                              \
-        if (rc_w) return rc_w;                                                                                      \
-        hipLaunchKernelGGL((k_linesearch_wave<MODEL, KA>), dim3((grid_items + WF::IPB - 1) / WF::IPB),              \
-                           dim3(64 * WF::NW * WF::IPB), lds_w, st, D, X, U, K, d, alphas, Xc, Uc, S, items, n_items); \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return DPILQR_OK;                                                                                           \
-    }
-#define DPILQR_WAVE_10(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)        \
-        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6) DPILQR_TRY_WAVE(MODEL, 7)     \
-        DPILQR_TRY_WAVE(MODEL, 8) DPILQR_TRY_WAVE(MODEL, 9) DPILQR_TRY_WAVE(MODEL, 10)
-#define DPILQR_WAVE_15(MODEL) DPILQR_WAVE_10(MODEL) DPILQR_TRY_WAVE(MODEL, 11) DPILQR_TRY_WAVE(MODEL, 12)           \
-        DPILQR_TRY_WAVE(MODEL, 13) DPILQR_TRY_WAVE(MODEL, 14) DPILQR_TRY_WAVE(MODEL, 15)
-        DPILQR_WAVE_15(kDoubleInt4D)
-        DPILQR_WAVE_15(kUnicycle4D)
-        DPILQR_WAVE_10(kQuadcopter6D)
-        // the remaining models, up to six agents (one wavefront per sub-problem)
-#define DPILQR_WAVE_6(MODEL) DPILQR_TRY_WAVE(MODEL, 1) DPILQR_TRY_WAVE(MODEL, 2) DPILQR_TRY_WAVE(MODEL, 3)         \
-        DPILQR_TRY_WAVE(MODEL, 4) DPILQR_TRY_WAVE(MODEL, 5) DPILQR_TRY_WAVE(MODEL, 6)
-        DPILQR_WAVE_6(kDoubleInt6D)
-        DPILQR_WAVE_6(kCar3D)
-        DPILQR_WAVE_6(kHuman6D)
-        DPILQR_WAVE_6(kHumanLin6D)
-        DPILQR_TRY_WAVE(kQuadcopter12D, 1) DPILQR_TRY_WAVE(kQuadcopter12D, 2) DPILQR_TRY_WAVE(kQuadcopter12D, 3)
-        DPILQR_TRY_WAVE(kQuadcopter12D, 4) DPILQR_TRY_WAVE(kQuadcopter12D, 5)
-#undef DPILQR_WAVE_6
-#undef DPILQR_WAVE_15
-#undef DPILQR_WAVE_10
-#undef DPILQR_TRY_WAVE
-    }
-    // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp
-    static const bool no_pack = getenv("DPILQR_FORWARD_NO_PACK") != nullptr;   // diagnostic switch
-    const int ipb = (!no_pack && threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;
-    const size_t lds = lds_item * ipb;
-    threads *= ipb;
-    DISPATCH_FAMILY(D.n_s, {
-        int32_t rc = allow_lds(k_forward<NS, NC>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_forward<NS, NC>), dim3((grid_items + ipb - 1) / ipb), dim3(threads), lds, st, D, mode, x0, X, U,
-                           K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, ipb, (int)(lds_item / sizeof(double)));
-    })
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
-}
 
 // float32-rounded table of control.py:162 (quirk Q1), bit patterns of 1.1 ** (-arange(10, f32) ** 2)
 void alpha_table(double* a) {
@@ -512,7 +230,7 @@ thread_local Profiler g_prof;
 extern "C" {
 
 int32_t dpilqr_abi_version(void) { return DPILQR_ABI_VERSION; }
-const char* dpilqr_last_error(void) { return g_err; }
+const char* dpilqr_last_error(void) { return last_error(); }
 
 int32_t dpilqr_device_info(int32_t dev, int32_t* n_cu, int32_t* lds_bytes, char* arch, int32_t arch_len) {
     int count = 0;
@@ -539,14 +257,7 @@ static int32_t model_op(int op, int32_t n, int32_t ns, const int32_t* model, con
                         double* o1, double* o2, void* stream) {
     if (n < 0 || !model || !x || !u || !o1 || (op == 2 && !o2)) return fail(DPILQR_EINVAL, "model op: bad argument");
     if (n == 0) return DPILQR_OK;
-    const dim3 grid((n + 63) / 64), block(64);
-    DISPATCH_FAMILY(ns, {
-        if (op == 0) hipLaunchKernelGGL((k_model_op<NS, NC, 0>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
-        else if (op == 1) hipLaunchKernelGGL((k_model_op<NS, NC, 1>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
-        else hipLaunchKernelGGL((k_model_op<NS, NC, 2>), grid, block, 0, as_stream(stream), n, model, x, u, dt, o1, o2);
-    })
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
+    return launch_model_op(op, n, ns, model, x, u, dt, o1, o2, as_stream(stream));
 }
 
 int32_t dpilqr_model_f(int32_t n, int32_t family_ns, const int32_t* model, const double* x, const double* u,
@@ -567,25 +278,13 @@ int32_t dpilqr_cost_eval(const dpilqr_batch_desc* desc, int32_t n_pts, const dou
     int32_t rc = check_desc(desc);
     if (rc) return rc;
     if (n_pts < 0 || !x || !u || !cost) return fail(DPILQR_EINVAL, "cost_eval: bad argument");
-    const int64_t total = (int64_t)desc->B * n_pts;
-    if (total == 0) return DPILQR_OK;
-    const dim3 grid((unsigned)((total + 63) / 64)), block(64);
-    DISPATCH_FAMILY(desc->n_s, {
-        hipLaunchKernelGGL((k_cost_eval<NS, NC>), grid, block, 0, as_stream(stream), *desc, n_pts, x, u, terminal, cost);
-    })
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
+    if ((int64_t)desc->B * n_pts == 0) return DPILQR_OK;
+    return launch_cost_eval(*desc, n_pts, x, u, terminal, cost, as_stream(stream));
 }
 
 int32_t dpilqr_tile_layout(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t row_strides[7], int64_t* stride) {
     if (n_x < 1 || n_u < 1 || !offsets || !row_strides || !stride) return fail(DPILQR_EINVAL, "tile_layout: bad argument");
-    const TileLayout L(n_x, n_u);
-    offsets[0] = L.oA; offsets[1] = L.oB; offsets[2] = L.oLxx; offsets[3] = L.oLux; offsets[4] = L.oLuu;
-    offsets[5] = L.oLx; offsets[6] = L.oLu;
-    row_strides[0] = L.ldAB; row_strides[1] = L.ldAB; row_strides[2] = n_x; row_strides[3] = L.ldUG; row_strides[4] = L.ldUG;
-    row_strides[5] = 1; row_strides[6] = 1;
-    *stride = L.stride;
-    return DPILQR_OK;
+    return tile_layout_host(n_x, n_u, offsets, row_strides, stride);
 }
 
 int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u) {
@@ -800,9 +499,8 @@ int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, doub
 }
 
 int32_t dpilqr_debug_stamps(void* buf) {
-    void* p = buf;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)));
-    return DPILQR_OK;
+    int32_t rc = set_stamp_buffer_riccati(buf);
+    return rc ? rc : set_stamp_buffer_forward(buf);
 }
 
 int32_t dpilqr_profile_enable(int32_t enable) {
@@ -834,12 +532,7 @@ int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, cons
                               int32_t* adj, void* stream) {
     if (S < 0 || N < 1 || k < 1 || n_s < 2 || !X || !radius || !adj) return fail(DPILQR_EINVAL, "pairwise_graph: bad argument");
     if (S == 0) return DPILQR_OK;
-    hipStream_t st = as_stream(stream);
-    HIP_TRY(hipMemsetAsync(adj, 0, sizeof(int32_t) * (size_t)S * k * k, st));
-    const int64_t total = (int64_t)S * (k * (k - 1) / 2 + k);
-    hipLaunchKernelGGL(k_pairwise_graph, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, S, N, k, n_s, X, radius, adj);
-    HIP_TRY(hipGetLastError());
-    return DPILQR_OK;
+    return launch_pairwise_graph(S, N, k, n_s, X, radius, adj, as_stream(stream));
 }
 
 }  // extern "C"

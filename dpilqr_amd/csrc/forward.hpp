@@ -15,27 +15,9 @@
 
 #include "cost.hpp"
 #include "models.hpp"
+#include "solve_state.hpp"
 
 namespace dpilqr {
-
-enum ForwardMode : int { kModeRollout = 0, kModeCandidates = 1, kModeLineSearch = 2 };
-
-struct SolveState {  // per-item solver state, device arrays of length B
-    double* mu;
-    double* delta;
-    double* J_star;
-    double* J_last;
-    int32_t* status;
-    int32_t* n_bwd;
-    int32_t* n_fwd;
-    double* trace;            // [B][n_lqr_iter][5] or null
-    const int32_t* singular;  // [B] or null
-    int32_t* next_count;      // number of items pushed onto next_items so far
-    int32_t* next_items;      // active list of the next iteration
-    int32_t n_lqr_iter;
-    int32_t gains_by_item;    // K, d indexed by item id (caller asked for them) instead of list position
-    double tol;
-};
 
 struct ForwardLds {
     int Kt, dt, dx, xs, cref, cpair, J, ctl, total;
@@ -419,7 +401,7 @@ __global__ void k_model_op(int n_agents, const int32_t* __restrict__ model, cons
 }
 
 // define_inter_graph_threshold (distributed.py:224-247): thread per (scenario, pair)
-__global__ void k_pairwise_graph(int S, int N, int k, int n_s, const double* __restrict__ X,
+static __global__ void k_pairwise_graph(int S, int N, int k, int n_s, const double* __restrict__ X,
                                  const double* __restrict__ radius, int32_t* __restrict__ adj) {
     const int npairs = k * (k - 1) / 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

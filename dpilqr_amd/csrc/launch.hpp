@@ -1,0 +1,79 @@
+// launch.hpp -- host-side declarations shared by the translation units of libdpilqr_hip.so.
+//
+// The library is built from several .hip files so that they compile in parallel (one file with every kernel
+// instantiation took over two minutes): tu_tiles.hip (K1), tu_riccati.hip (K2), tu_forward.hip (K3, rollouts, the small
+// batched entry points), tu_big.hip (the sweep for n_x > 60 and the fp32 arm) and dpilqr_hip.hip (the C ABI and the
+// solve loop).  No device code crosses a file boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "dpilqr_hip.h"
+#include "solve_state.hpp"
+
+namespace dpilqr {
+
+int32_t fail(int32_t code, const char* fmt, ...);   // records the calling thread's error message, returns `code`
+const char* last_error();
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return ::dpilqr::fail(DPILQR_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+
+template <typename Kern>
+inline int32_t allow_lds(Kern kern, size_t bytes) {
+    if (bytes > (size_t)kMaxLds) return fail(DPILQR_EUNSUPPORTED, "needs %zu B of LDS per workgroup (> %d)", bytes, kMaxLds);
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DPILQR_OK;
+}
+
+// run `body` with the (NS,NC) family as compile-time constants
+#define DISPATCH_FAMILY(ns, BODY)                                                         \
+    switch (ns) {                                                                         \
+    case 3:  { constexpr int NS = 3,  NC = 2; BODY } break;                               \
+    case 4:  { constexpr int NS = 4,  NC = 2; BODY } break;                               \
+    case 6:  { constexpr int NS = 6,  NC = 3; BODY } break;                               \
+    case 12: { constexpr int NS = 12, NC = 4; BODY } break;                               \
+    default: return ::dpilqr::fail(DPILQR_EINVAL, "unsupported per-agent state dim %d", (int)(ns)); \
+    }
+
+// compute units of the current device (256 on MI355X): the sweep deals its items over rounds of this many workgroups
+int device_cus();
+
+// hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
+inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
+inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
+
+// ---- tu_tiles.hip
+int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
+                          const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, bool dyn_only,
+                          hipStream_t st);
+int32_t tile_layout_host(int32_t n_x, int32_t n_u, int64_t offsets[7], int64_t row_strides[7], int64_t* stride);
+
+// ---- tu_riccati.hip
+extern thread_local int g_sweep_waves;   // wavefronts per workgroup of the last launch_riccati (0: not the wavefront sweep)
+int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
+                       int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
+                       int gains_by_item, int block_ns, int block_nc, hipStream_t st);
+int32_t set_stamp_buffer_riccati(void* device_buffer);
+
+// ---- tu_forward.hip
+int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
+                       const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
+                       const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
+                       hipStream_t st);
+int32_t set_stamp_buffer_forward(void* device_buffer);
+int32_t launch_model_op(int op, int32_t n, int32_t ns, const int32_t* model, const double* x, const double* u, double dt,
+                        double* o1, double* o2, hipStream_t st);
+int32_t launch_cost_eval(const dpilqr_batch_desc& D, int32_t n_pts, const double* x, const double* u, int32_t terminal,
+                         double* cost, hipStream_t st);
+int32_t launch_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X, const double* radius,
+                              int32_t* adj, hipStream_t st);
+
+}  // namespace dpilqr

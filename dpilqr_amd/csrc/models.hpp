@@ -22,36 +22,41 @@ constexpr int kMaxNc = 4;
 // Model enum, identical values to bbdynamicswrap.pyx:8-16
 enum Model : int {
     kDoubleInt4D = 0, kDoubleInt6D = 1, kCar3D = 2, kUnicycle4D = 3,
-    kQuadcopter6D = 4, kHuman6D = 5, kHumanLin6D = 6, kQuadcopter12D = 7, kNumModels = 8
+    kQuadcopter6D = 4, kHuman6D = 5, kHumanLin6D = 6, kQuadcopter12D = 7,
+    kHumanPad12D = 8,   // this library's own: HumanDynamics6D zero-padded to 12 states / 4 controls (dpilqr_hip.h)
+    kNumModels = 9
 };
 
 __host__ __device__ inline int model_ns(int m) {
-    constexpr int t[kNumModels] = {4, 6, 3, 4, 6, 6, 6, 12};
+    constexpr int t[kNumModels] = {4, 6, 3, 4, 6, 6, 6, 12, 12};
     return (m >= 0 && m < kNumModels) ? t[m] : -1;
 }
 __host__ __device__ inline int model_nc(int m) {
-    constexpr int t[kNumModels] = {2, 3, 2, 2, 3, 3, 3, 4};
+    constexpr int t[kNumModels] = {2, 3, 2, 2, 3, 3, 3, 4, 4};
     return (m >= 0 && m < kNumModels) ? t[m] : -1;
 }
+
+__device__ __forceinline__ void sincos_r(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void sincos_r(float x, float* s, float* c) { sincosf(x, s, c); }
 
 template <int M> struct ModelDef;
 
 template <> struct ModelDef<kDoubleInt4D> {  // x=[px,py,vx,vy] u=[ax,ay]
     static constexpr int NS = 4, NC = 2;
-    __device__ static void f(const double* x, const double* u, double* o) {
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         o[0] = x[2]; o[1] = x[3]; o[2] = u[0]; o[3] = u[1];
     }
-    __device__ static void jac(const double*, const double*, double* A, double* B) {
+    template <typename R> __device__ static void jac(const R*, const R*, R* A, R* B) {
         A[0 * 4 + 2] = 1.0; A[1 * 4 + 3] = 1.0; B[2 * 2 + 0] = 1.0; B[3 * 2 + 1] = 1.0;
     }
 };
 
 template <> struct ModelDef<kDoubleInt6D> {  // x=[p(3),v(3)] u=[a(3)]
     static constexpr int NS = 6, NC = 3;
-    __device__ static void f(const double* x, const double* u, double* o) {
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         o[0] = x[3]; o[1] = x[4]; o[2] = x[5]; o[3] = u[0]; o[4] = u[1]; o[5] = u[2];
     }
-    __device__ static void jac(const double*, const double*, double* A, double* B) {
+    template <typename R> __device__ static void jac(const R*, const R*, R* A, R* B) {
         A[0 * 6 + 3] = 1.0; A[1 * 6 + 4] = 1.0; A[2 * 6 + 5] = 1.0;
         B[3 * 3 + 0] = 1.0; B[4 * 3 + 1] = 1.0; B[5 * 3 + 2] = 1.0;
     }
@@ -59,13 +64,13 @@ template <> struct ModelDef<kDoubleInt6D> {  // x=[p(3),v(3)] u=[a(3)]
 
 template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
     static constexpr int NS = 3, NC = 2;
-    __device__ static void f(const double* x, const double* u, double* o) {
-        double sn, cs;
-        sincos(x[2], &sn, &cs);
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        R sn, cs;
+        sincos_r(x[2], &sn, &cs);
         o[0] = u[0] * cs; o[1] = u[0] * sn; o[2] = u[1];
     }
-    __device__ static void jac(const double* x, const double* u, double* A, double* B) {
-        const double s = sin(x[2]), c = cos(x[2]);
+    template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+        const R s = sin(x[2]), c = cos(x[2]);
         A[0 * 3 + 2] = -u[0] * s; A[1 * 3 + 2] = u[0] * c;
         B[0 * 2 + 0] = c; B[1 * 2 + 0] = s; B[2 * 2 + 1] = 1.0;
     }
@@ -73,13 +78,13 @@ template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
 
 template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
     static constexpr int NS = 4, NC = 2;
-    __device__ static void f(const double* x, const double* u, double* o) {
-        double sn, cs;
-        sincos(x[3], &sn, &cs);   // one argument reduction for both (same values as sin(), cos())
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        R sn, cs;
+        sincos_r(x[3], &sn, &cs);   // one argument reduction for both (same values as sin(), cos())
         o[0] = x[2] * cs; o[1] = x[2] * sn; o[2] = u[0]; o[3] = u[1];
     }
-    __device__ static void jac(const double* x, const double*, double* A, double* B) {
-        const double s = sin(x[3]), c = cos(x[3]);
+    template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
+        const R s = sin(x[3]), c = cos(x[3]);
         A[0 * 4 + 2] = c; A[0 * 4 + 3] = -x[2] * s;
         A[1 * 4 + 2] = s; A[1 * 4 + 3] = x[2] * c;
         B[2 * 2 + 0] = 1.0; B[3 * 2 + 1] = 1.0;
@@ -88,26 +93,26 @@ template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
 
 template <> struct ModelDef<kQuadcopter6D> {  // x=[p(3),v(3)] u=[tau,phi,theta]
     static constexpr int NS = 6, NC = 3;
-    __device__ static void f(const double* x, const double* u, double* o) {
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         o[0] = x[3]; o[1] = x[4]; o[2] = x[5];
-        o[3] = kGrav * tan(u[2]); o[4] = -kGrav * tan(u[1]); o[5] = u[0] - kGrav;
+        o[3] = R(kGrav) * tan(u[2]); o[4] = -R(kGrav) * tan(u[1]); o[5] = u[0] - R(kGrav);
     }
-    __device__ static void jac(const double*, const double* u, double* A, double* B) {
-        const double t2 = tan(u[2]), t1 = tan(u[1]);
+    template <typename R> __device__ static void jac(const R*, const R* u, R* A, R* B) {
+        const R t2 = tan(u[2]), t1 = tan(u[1]);
         A[0 * 6 + 3] = 1.0; A[1 * 6 + 4] = 1.0; A[2 * 6 + 5] = 1.0;
-        B[3 * 3 + 2] = kGrav * (t2 * t2) + kGrav;
-        B[4 * 3 + 1] = -kGrav * (t1 * t1) - kGrav;
+        B[3 * 3 + 2] = R(kGrav) * (t2 * t2) + R(kGrav);
+        B[4 * 3 + 1] = -R(kGrav) * (t1 * t1) - R(kGrav);
         B[5 * 3 + 0] = 1.0;
     }
 };
 
 template <> struct ModelDef<kHuman6D> {  // x=[px,py,pz,v,0,0] u=[heading,accel,-]
     static constexpr int NS = 6, NC = 3;
-    __device__ static void f(const double* x, const double* u, double* o) {
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         o[0] = x[3] * cos(u[0]); o[1] = x[3] * sin(u[0]); o[2] = 0.0; o[3] = u[1]; o[4] = 0.0; o[5] = 0.0;
     }
-    __device__ static void jac(const double* x, const double* u, double* A, double* B) {
-        const double s = sin(u[0]), c = cos(u[0]);
+    template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+        const R s = sin(u[0]), c = cos(u[0]);
         A[0 * 6 + 3] = c; A[1 * 6 + 3] = s;
         B[0 * 3 + 0] = -x[3] * s; B[1 * 3 + 0] = x[3] * c; B[3 * 3 + 1] = 1.0;
     }
@@ -115,12 +120,12 @@ template <> struct ModelDef<kHuman6D> {  // x=[px,py,pz,v,0,0] u=[heading,accel,
 
 template <> struct ModelDef<kHumanLin6D> {  // planar double integrator at constant height
     static constexpr int NS = 6, NC = 3;
-    __device__ static void f(const double* x, const double* u, double* o) {
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         o[0] = x[3]; o[1] = x[4]; o[2] = 0.0; o[3] = u[0]; o[4] = u[1]; o[5] = 0.0;
     }
     // The reference discretises the DoubleInt6D Jacobians and THEN zeroes A[2][5], B[5][2]
     // (cpp:408-415); dropping the two continuous entries before discretising gives the same matrices.
-    __device__ static void jac(const double*, const double*, double* A, double* B) {
+    template <typename R> __device__ static void jac(const R*, const R*, R* A, R* B) {
         A[0 * 6 + 3] = 1.0; A[1 * 6 + 4] = 1.0;
         B[3 * 3 + 0] = 1.0; B[4 * 3 + 1] = 1.0;
     }
@@ -137,28 +142,28 @@ template <> struct ModelDef<kQuadcopter12D> {
     static constexpr double kCx = 85899976080679.0 / 175721491136944.0;
     static constexpr double kCy = 95876456000597.0 / 185697971056862.0;
     static constexpr double kCz = 9976479919918.0 / 271597947137541.0;
-    __device__ static void f(const double* x, const double* u, double* o) {
-        const double sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
-        const double sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
-        const double vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        const R sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
+        const R sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
+        const R vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
         o[0] = vx * cps * cth + vy * (sph * sth * cps - sps * cph) + vz * (sph * sps + sth * cph * cps);
         o[1] = vx * sps * cth + vy * (sph * sps * sth + cph * cps) + vz * (-sph * cps + sps * sth * cph);
         o[2] = -vx * sth + vy * sph * cth + vz * cph * cth;
         o[3] = wy * sph / cth + wz * cph / cth;
         o[4] = wy * cph - wz * sph;
         o[5] = wx + wy * sph * tth + wz * cph * tth;
-        o[6] = vy * wz - vz * wy + kGrav * sth;
-        o[7] = -vx * wz + vz * wx - kGrav * sph * cth;
-        o[8] = kFz * u[3] + vx * wy - vy * wx - kGrav * cph * cth;
-        o[9] = kTx * u[0] - kCx * wy * wz;
-        o[10] = kTy * u[1] + kCy * wx * wz;
-        o[11] = kTz * u[2] - kCz * wx * wy;
+        o[6] = vy * wz - vz * wy + R(kGrav) * sth;
+        o[7] = -vx * wz + vz * wx - R(kGrav) * sph * cth;
+        o[8] = R(kFz) * u[3] + vx * wy - vy * wx - R(kGrav) * cph * cth;
+        o[9] = R(kTx) * u[0] - R(kCx) * wy * wz;
+        o[10] = R(kTy) * u[1] + R(kCy) * wx * wz;
+        o[11] = R(kTz) * u[2] - R(kCz) * wx * wy;
     }
-    __device__ static void jac(const double* x, const double*, double* A, double* B) {
-        const double sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
-        const double sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
-        const double c2 = cth * cth, sec2 = tth * tth + 1;
-        const double vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
+    template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
+        const R sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
+        const R sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
+        const R c2 = cth * cth, sec2 = tth * tth + 1;
+        const R vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
 #define A_(r, c) A[(r) * 12 + (c)]
         A_(0, 3) = -vx * sps * cth + vy * (-sph * sps * sth - cph * cps) + vz * (sph * cps - sps * sth * cph);
         A_(0, 4) = -vx * sth * cps + vy * sph * cps * cth + vz * cph * cps * cth;
@@ -189,16 +194,33 @@ template <> struct ModelDef<kQuadcopter12D> {
         A_(5, 9) = 1.0;
         A_(5, 10) = sph * tth;
         A_(5, 11) = cph * tth;
-        A_(6, 4) = kGrav * cth; A_(6, 7) = wz; A_(6, 8) = -wy; A_(6, 10) = -vz; A_(6, 11) = vy;
-        A_(7, 4) = kGrav * sph * sth; A_(7, 5) = -kGrav * cph * cth;
+        A_(6, 4) = R(kGrav) * cth; A_(6, 7) = wz; A_(6, 8) = -wy; A_(6, 10) = -vz; A_(6, 11) = vy;
+        A_(7, 4) = R(kGrav) * sph * sth; A_(7, 5) = -R(kGrav) * cph * cth;
         A_(7, 6) = -wz; A_(7, 8) = wx; A_(7, 9) = vz; A_(7, 11) = -vx;
-        A_(8, 4) = kGrav * sth * cph; A_(8, 5) = kGrav * sph * cth;
+        A_(8, 4) = R(kGrav) * sth * cph; A_(8, 5) = R(kGrav) * sph * cth;
         A_(8, 6) = wy; A_(8, 7) = -wx; A_(8, 9) = -vy; A_(8, 10) = vx;
-        A_(9, 10) = -kCx * wz; A_(9, 11) = -kCx * wy;
-        A_(10, 9) = kCy * wz; A_(10, 11) = kCy * wx;
-        A_(11, 9) = -kCz * wy; A_(11, 10) = -kCz * wx;
+        A_(9, 10) = -R(kCx) * wz; A_(9, 11) = -R(kCx) * wy;
+        A_(10, 9) = R(kCy) * wz; A_(10, 11) = R(kCy) * wx;
+        A_(11, 9) = -R(kCz) * wy; A_(11, 10) = -R(kCz) * wx;
 #undef A_
-        B[8 * 4 + 3] = kFz; B[9 * 4 + 0] = kTx; B[10 * 4 + 1] = kTy; B[11 * 4 + 2] = kTz;
+        B[8 * 4 + 3] = R(kFz); B[9 * 4 + 0] = R(kTx); B[10 * 4 + 1] = R(kTy); B[11 * 4 + 2] = R(kTz);
+    }
+};
+
+template <> struct ModelDef<kHumanPad12D> {  // x=[px,py,pz,v,0,0 | 6 padded states] u=[heading,accel,-,-]
+    // HumanDynamics6D in a 12-state / 4-control slot (BASELINE config 5's "zero-padded state").  The padded states
+    // have x_dot = 0, so RK4 leaves them bit-for-bit where they are and the Euler Jacobians give A = 1 on their
+    // diagonal and B = 0 -- what a block-diagonal embedding of the six-state model means.
+    static constexpr int NS = 12, NC = 4;
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        o[0] = x[3] * cos(u[0]); o[1] = x[3] * sin(u[0]); o[2] = 0.0; o[3] = u[1];
+#pragma unroll
+        for (int i = 4; i < 12; ++i) o[i] = 0.0;
+    }
+    template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+        const R s = sin(u[0]), c = cos(u[0]);
+        A[0 * 12 + 3] = c; A[1 * 12 + 3] = s;
+        B[0 * 4 + 0] = -x[3] * s; B[1 * 4 + 0] = x[3] * c; B[3 * 4 + 1] = 1.0;
     }
 };
 
@@ -242,14 +264,20 @@ __device__ __forceinline__ double div6(double x) {
     div6_vec<1>(v);
     return v[0];
 }
+// the fp32 arm (BASELINE config 5's tolerance study) divides: a single-precision division is a short sequence
+template <int N>
+__device__ __forceinline__ void div6_vec(float* v) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] / 6.0f;
+}
 
 // classical RK4 with 5 fixed sub-steps, zero-order-hold u (bbdynamics.cpp:39-93)
-template <int M>
-__device__ inline void integrate(const double* x, const double* u, double dt, double* xn) {
+template <int M, typename R>
+__device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
     using D = ModelDef<M>;
     constexpr int NS = D::NS;
-    const double dh = dt / 5;
-    double k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
+    const R dh = dt / 5;
+    R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) xn[i] = x[i];
 #pragma unroll 1
@@ -258,16 +286,16 @@ __device__ inline void integrate(const double* x, const double* u, double dt, do
         for (int i = 0; i < NS; ++i) xa[i] = xn[i];
         D::f(xa, u, k0);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / 2.0) * k0[i];
+        for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k0[i];
         D::f(xb, u, k1);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / 2.0) * k1[i];
+        for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k1[i];
         D::f(xb, u, k2);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
         D::f(xb, u, k3);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + 2.0 * k1[i] + 2.0 * k2[i] + k3[i]);
+        for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
         div6_vec<NS>(xb);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xn[i] += xb[i];
@@ -275,8 +303,8 @@ __device__ inline void integrate(const double* x, const double* u, double dt, do
 }
 
 // forward-Euler discretised Jacobians: A = I + dt*A_c, B = dt*B_c (cpp:95-106)
-template <int M>
-__device__ inline void linearize(const double* x, const double* u, double dt, double* A, double* B) {
+template <int M, typename R>
+__device__ inline void linearize(const R* x, const R* u, R dt, R* A, R* B) {
     using D = ModelDef<M>;
     constexpr int NS = D::NS, NC = D::NC;
 #pragma unroll
@@ -287,42 +315,43 @@ __device__ inline void linearize(const double* x, const double* u, double dt, do
 #pragma unroll
     for (int i = 0; i < NS * NS; ++i) {
         A[i] *= dt;
-        if (i % (NS + 1) == 0) A[i] += 1.0;
+        if (i % (NS + 1) == 0) A[i] += R(1.0);
     }
 #pragma unroll
     for (int i = 0; i < NS * NC; ++i) B[i] *= dt;
 }
 
 // ---- runtime dispatch restricted to the models of one (NS,NC) family; arrays sized by the family
-template <int NS>
-__device__ inline void f_rt(int model, const double* x, const double* u, double* o);
-template <int NS>
-__device__ inline void integrate_rt(int model, const double* x, const double* u, double dt, double* xn);
-template <int NS>
-__device__ inline void linearize_rt(int model, const double* x, const double* u, double dt, double* A, double* B);
-
-#define DPILQR_FAMILY(NSV, ...)                                                                         \
-    template <> __device__ inline void f_rt<NSV>(int model, const double* x, const double* u, double* o) { \
-        switch (model) { __VA_ARGS__(DPILQR_CASE_F) default: break; }                                    \
-    }                                                                                                   \
-    template <> __device__ inline void integrate_rt<NSV>(int model, const double* x, const double* u,     \
-                                                          double dt, double* xn) {                      \
-        switch (model) { __VA_ARGS__(DPILQR_CASE_I) default: break; }                                    \
-    }                                                                                                   \
-    template <> __device__ inline void linearize_rt<NSV>(int model, const double* x, const double* u,     \
-                                                          double dt, double* A, double* B) {            \
-        switch (model) { __VA_ARGS__(DPILQR_CASE_L) default: break; }                                    \
-    }
+template <int NS> struct Family;
+#define DPILQR_FAMILY(NSV, ...)                                                                          \
+    template <> struct Family<NSV> {                                                                     \
+        template <typename R> __device__ static void f(int model, const R* x, const R* u, R* o) {        \
+            switch (model) { __VA_ARGS__(DPILQR_CASE_F) default: break; }                                \
+        }                                                                                                \
+        template <typename R> __device__ static void integrate(int model, const R* x, const R* u, R dt, R* xn) { \
+            switch (model) { __VA_ARGS__(DPILQR_CASE_I) default: break; }                                \
+        }                                                                                                \
+        template <typename R> __device__ static void linearize(int model, const R* x, const R* u, R dt, R* A, R* B) { \
+            switch (model) { __VA_ARGS__(DPILQR_CASE_L) default: break; }                                \
+        }                                                                                                \
+    };
 #define DPILQR_CASE_F(M) case M: ModelDef<M>::f(x, u, o); break;
-#define DPILQR_CASE_I(M) case M: integrate<M>(x, u, dt, xn); break;
-#define DPILQR_CASE_L(M) case M: linearize<M>(x, u, dt, A, B); break;
+#define DPILQR_CASE_I(M) case M: ::dpilqr::integrate<M>(x, u, dt, xn); break;
+#define DPILQR_CASE_L(M) case M: ::dpilqr::linearize<M>(x, u, dt, A, B); break;
 #define DPILQR_FAM3(X) X(kCar3D)
 #define DPILQR_FAM4(X) X(kDoubleInt4D) X(kUnicycle4D)
 #define DPILQR_FAM6(X) X(kDoubleInt6D) X(kQuadcopter6D) X(kHuman6D) X(kHumanLin6D)
-#define DPILQR_FAM12(X) X(kQuadcopter12D)
+#define DPILQR_FAM12(X) X(kQuadcopter12D) X(kHumanPad12D)
 DPILQR_FAMILY(3, DPILQR_FAM3)
 DPILQR_FAMILY(4, DPILQR_FAM4)
 DPILQR_FAMILY(6, DPILQR_FAM6)
 DPILQR_FAMILY(12, DPILQR_FAM12)
+
+template <int NS, typename R>
+__device__ inline void f_rt(int model, const R* x, const R* u, R* o) { Family<NS>::f(model, x, u, o); }
+template <int NS, typename R>
+__device__ inline void integrate_rt(int model, const R* x, const R* u, R dt, R* xn) { Family<NS>::integrate(model, x, u, dt, xn); }
+template <int NS, typename R>
+__device__ inline void linearize_rt(int model, const R* x, const R* u, R dt, R* A, R* B) { Family<NS>::linearize(model, x, u, dt, A, B); }
 
 }  // namespace dpilqr

@@ -46,7 +46,7 @@ struct RiccatiLds {
 
 inline size_t riccati_lds_bytes(int n, int m) { return sizeof(double) * (size_t)RiccatiLds(n, m).total; }
 
-__global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, int m, const double* __restrict__ tiles,
+static __global__ __launch_bounds__(256) void k_riccati_generic(int B, int T, int n, int m, const double* __restrict__ tiles,
                                   const double* __restrict__ mu_arr, double* __restrict__ Kout,
                                   double* __restrict__ dout, int32_t* __restrict__ singular,
                                   const int32_t* __restrict__ items, const int32_t* __restrict__ n_items,

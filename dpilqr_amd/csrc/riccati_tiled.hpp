@@ -55,7 +55,7 @@ __device__ __forceinline__ void store_f64_nt(double* p, double v) {
 
 // Diagnostic stamps (dpilqr_debug_stamps): when a buffer is registered, lane 0 of every sweep workgroup
 // records {start, end} of s_memrealtime (100 MHz) and its XCC / CU / SIMD ids.  Never read by any kernel.
-__device__ unsigned long long* g_stamp_buf = nullptr;
+static __device__ unsigned long long* g_stamp_buf = nullptr;   // one copy per translation unit (launch.hpp)
 
 constexpr int round_up(int x, int q) { return (x + q - 1) / q * q; }
 

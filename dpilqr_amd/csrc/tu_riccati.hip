@@ -1,0 +1,119 @@
+// tu_riccati.hip -- K2, the Riccati sweeps for n_x <= 60 (riccati_mfma.hpp, riccati_wg.hpp, riccati_tiled.hpp,
+// riccati.hpp), and their launcher.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "launch.hpp"
+#include "riccati.hpp"
+#include "riccati_mfma.hpp"
+#include "riccati_tiled.hpp"
+#include "riccati_wg.hpp"
+
+namespace dpilqr {
+
+static int riccati_threads(int n) { return n <= 24 ? 64 : (n <= 36 ? 128 : 256); }
+
+// compile-time-sized sweeps (one wavefront per sub-problem); everything else takes the generic kernel
+#define DPILQR_TILED_SIZES(X) X(4, 2) X(8, 4) X(12, 6) X(16, 8) X(20, 10)
+
+thread_local int g_sweep_waves = 0;
+
+int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
+                       int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
+                       int gains_by_item, int block_ns, int block_nc, hipStream_t st) {
+    g_sweep_waves = 0;
+    if (grid_items <= 0) return DPILQR_OK;
+    // block_ns > 0: the caller guarantees that [A|B] is block diagonal with block_ns x (block_ns + block_nc) blocks
+    // (tiles made by k_make_tiles from a MultiDynamicalModel); 0: arbitrary dense tiles (the plugin boundary).
+    static const bool no_bd = getenv("DPILQR_RICCATI_DENSE") != nullptr;   // A/B switch
+    const bool bd = !no_bd && block_ns == 4 && block_nc == 2 && n == 4 * (m / 2) && m % 2 == 0;
+    // sweep selection: matrix-pipe kernel where instantiated, else the vector-pipe tiled kernel, else the generic one
+    // (DPILQR_RICCATI=mfma|tiled|generic pins one for A/B measurements)
+    static const char* pick_env = getenv("DPILQR_RICCATI");
+    static const int pick = getenv("DPILQR_FORCE_GENERIC_RICCATI") ? 2
+                            : (!pick_env ? 0 : (!strcmp(pick_env, "tiled") ? 1 : (!strcmp(pick_env, "generic") ? 2 : 0)));
+    if (pick == 0) {
+#define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
+    if (n == NN && m == MM) {                                                                                      \
+        static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
+        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;            \
+        /* wavefronts per workgroup = per CU: 4 (one per SIMD), 8, or 12 when the launch has the items for them */  \
+        const int wv = (bd && grid_items > 2048 && max_wv >= 12 && MfmaCfg<NN, MM>::total * 8 * 12 <= kMaxLds) ? 12 \
+                       : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
+        g_sweep_waves = wv;                                                                                        \
+        const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
+        auto kern = wv == 12 ? k_riccati_mfma<NN, MM, 12, 4, 2>                                                    \
+                    : wv == 8 ? (bd ? k_riccati_mfma<NN, MM, 8, 4, 2> : k_riccati_mfma<NN, MM, 8, 0, 0>)           \
+                              : (bd ? k_riccati_mfma<NN, MM, 4, 4, 2> : k_riccati_mfma<NN, MM, 4, 0, 0>);          \
+        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
+        if (rc_t) return rc_t;                                                                                     \
+        /* whole rounds of one workgroup per CU; the kernel deals the live items over them (riccati_mfma.hpp) */    \
+        const int cus = device_cus();                                                                              \
+        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d,                      \
+                           singular, items, n_items, gains_by_item, cus);                                          \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+        DPILQR_TILED_SIZES(DPILQR_TRY_MFMA)
+#undef DPILQR_TRY_MFMA
+    }
+    // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
+    static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
+    if (pick == 0 && !no_wg && block_ns > 0) {
+#define DPILQR_TRY_WG(KK, NS_, NC_)                                                                                 \
+    if (block_ns == NS_ && block_nc == NC_ && n == KK * NS_ && m == KK * NC_) {                                     \
+        using WC = WgCfg<KK * NS_, KK * NC_, NS_, NC_>;                                                             \
+        static_assert(WC::supported, "workgroup sweep not available for this size");                                \
+        const size_t lds_w = sizeof(double) * WC::total;                                                            \
+        int32_t rc_w = allow_lds(k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>, lds_w);                                \
+        if (rc_w) return rc_w;                                                                                      \
+        hipLaunchKernelGGL((k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>), dim3(grid_items), dim3(kWgThreads), lds_w, \
+                           st, B, T, tiles, mu, K, d, singular, items, n_items, gains_by_item);                     \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+        // four-state models (DoubleInt4D, Unicycle4D), 6..15 agents; six-state models (DoubleInt6D, Quadcopter6D,
+        // Human6D, HumanLin6D), 2..10 agents
+        DPILQR_TRY_WG(6, 4, 2) DPILQR_TRY_WG(7, 4, 2) DPILQR_TRY_WG(8, 4, 2) DPILQR_TRY_WG(9, 4, 2) DPILQR_TRY_WG(10, 4, 2)
+        DPILQR_TRY_WG(11, 4, 2) DPILQR_TRY_WG(12, 4, 2) DPILQR_TRY_WG(13, 4, 2) DPILQR_TRY_WG(14, 4, 2) DPILQR_TRY_WG(15, 4, 2)
+        DPILQR_TRY_WG(2, 6, 3) DPILQR_TRY_WG(3, 6, 3) DPILQR_TRY_WG(4, 6, 3) DPILQR_TRY_WG(5, 6, 3) DPILQR_TRY_WG(6, 6, 3)
+        DPILQR_TRY_WG(7, 6, 3) DPILQR_TRY_WG(8, 6, 3) DPILQR_TRY_WG(9, 6, 3) DPILQR_TRY_WG(10, 6, 3)
+        // Quadcopter12D, 2..5 agents
+        DPILQR_TRY_WG(2, 12, 4) DPILQR_TRY_WG(3, 12, 4) DPILQR_TRY_WG(4, 12, 4) DPILQR_TRY_WG(5, 12, 4)
+#undef DPILQR_TRY_WG
+    }
+    if (pick <= 1) {
+#define DPILQR_TRY_TILED(NN, MM)                                                                                   \
+    if (n == NN && m == MM) {                                                                                      \
+        static_assert(TiledCfg<NN, MM>::supported, "tiled sweep not available for this size");                     \
+        const size_t lds_t = sizeof(double) * TiledCfg<NN, MM>::total * kTiledWaves;                              \
+        int32_t rc_t = allow_lds(k_riccati_tiled<NN, MM>, lds_t);                                                  \
+        if (rc_t) return rc_t;                                                                                     \
+        hipLaunchKernelGGL((k_riccati_tiled<NN, MM>), dim3((grid_items + kTiledWaves - 1) / kTiledWaves),          \
+                           dim3(64 * kTiledWaves), lds_t, st, B, T, tiles, mu, K, d, singular, items, n_items,     \
+                           gains_by_item);                                                                         \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+        DPILQR_TILED_SIZES(DPILQR_TRY_TILED)
+#undef DPILQR_TRY_TILED
+    }
+    const size_t lds = riccati_lds_bytes(n, m);
+    int32_t rc = allow_lds(k_riccati_generic, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_riccati_generic, dim3(grid_items), dim3(riccati_threads(n)), lds, st, B, T, n, m, tiles, mu, K,
+                       d, singular, items, n_items, gains_by_item);
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
+int32_t set_stamp_buffer_riccati(void* buf) {
+    void* p = buf;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)));
+    return DPILQR_OK;
+}
+
+}  // namespace dpilqr

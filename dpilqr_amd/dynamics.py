@@ -81,13 +81,18 @@ QuadcopterDynamics6D = _device_model("QuadcopterDynamics6D", Model.Quadcopter6D)
 QuadcopterDynamics12D = _device_model("QuadcopterDynamics12D", Model.Quadcopter12D)
 HumanDynamics6D = _device_model("HumanDynamics6D", Model.Human6D)
 HumanDynamicsLin6D = _device_model("HumanDynamicsLin6D", Model.HumanLin6D)
+# Not in the reference: BASELINE config 5's "zero-padded" human, so that humans can be stacked with
+# QuadcopterDynamics12D (a MultiDynamicalModel needs uniform dims, dynamics.py:165-170).  First 6 states / 3 controls:
+# HumanDynamics6D; the other 6 states never move, the fourth control does nothing.
+HumanDynamics6DPadded12 = _device_model("HumanDynamics6DPadded12", Model.HumanPad12D)
 
 DEVICE_MODEL_CLASSES = (DoubleIntDynamics4D, DoubleIntDynamics6D, CarDynamics3D, UnicycleDynamics4D,
-                        QuadcopterDynamics6D, QuadcopterDynamics12D, HumanDynamics6D, HumanDynamicsLin6D)
+                        QuadcopterDynamics6D, QuadcopterDynamics12D, HumanDynamics6D, HumanDynamicsLin6D,
+                        HumanDynamics6DPadded12)
 
 
 def is_device_model(m):
-    """True when `m` is one of the eight recognised models with none of its methods overridden."""
+    """True when `m` is one of the recognised models with none of its methods overridden."""
     return type(m) in DEVICE_MODEL_CLASSES
 
 

@@ -51,6 +51,12 @@ extern "C" {
 #define DPILQR_MODEL_HUMAN_6D 5
 #define DPILQR_MODEL_HUMAN_LIN_6D 6
 #define DPILQR_MODEL_QUADCOPTER_12D 7
+/* Not a reference model.  BASELINE config 5 mixes QuadcopterDynamics12D (12 states / 4 controls) with HumanDynamics6D
+ * (6 / 3) "zero-padded": the reference cannot stack agents of different dims (dynamics.py:165-170, util.py:229-236), so
+ * this library defines the padded human itself -- HumanDynamics6D (bbdynamics.cpp:308-391) in the first 6 states and 3
+ * controls, six padded states that never move (A = 1 on their diagonal, B = 0) and a fourth control that does nothing
+ * (give it a small positive R entry, as scripts/examples.py:93 does for the human's unused third control). */
+#define DPILQR_MODEL_HUMAN_PAD_12D 8
 
 /* per-item solve status (written by dpilqr_solve_batch) */
 #define DPILQR_STATUS_ACTIVE 0
