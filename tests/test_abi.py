@@ -46,7 +46,8 @@ def test_host_only_entry_points(lib):
     assert np.array_equal(np.array(a, dtype=np.float32), (1.1 ** (-np.arange(10, dtype=np.float32) ** 2)))
     ns, nc = C.c_int32(), C.c_int32()
     assert lib.load().dpilqr_model_dims(7, C.byref(ns), C.byref(nc)) == 0 and (ns.value, nc.value) == (12, 4)
-    assert lib.load().dpilqr_model_dims(8, C.byref(ns), C.byref(nc)) == lib.EINVAL
+    assert lib.load().dpilqr_model_dims(8, C.byref(ns), C.byref(nc)) == 0 and (ns.value, nc.value) == (12, 4)   # padded human
+    assert lib.load().dpilqr_model_dims(9, C.byref(ns), C.byref(nc)) == lib.EINVAL
 
 
 def test_errors_are_codes_not_crashes(lib):
