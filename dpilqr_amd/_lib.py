@@ -53,7 +53,17 @@ SIGNATURES = {
     "dpilqr_forward_pass": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dpilqr_alphas": (i32, [C.POINTER(f64 * N_ALPHA)]),
     "dpilqr_solve_workspace_bytes": (i64, [_DP, i32, i32]),
-    "dpilqr_solve_batch": (i32, [_DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_solver_create": (i32, [C.POINTER(vp)]),
+    "dpilqr_solver_destroy": (i32, [vp]),
+    "dpilqr_solve_batch": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_solve_enqueue": (i32, [_DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "dpilqr_solve_iterations_bound": (i64, [_DP, i32, i32]),
+    "dpilqr_rollout_f32": (i32, [_DP, vp, vp, vp, vp, vp]),
+    "dpilqr_backward_pass_workspace_bytes": (i64, [_DP, i32]),
+    "dpilqr_backward_pass_f32": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_forward_pass_f32": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "dpilqr_solve_workspace_bytes_f32": (i64, [_DP, i32, i32]),
+    "dpilqr_solve_batch_f32": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_debug_stamps": (i32, [vp]),
     "dpilqr_profile_enable": (i32, [i32]),
     "dpilqr_profile_read": (i32, [C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
@@ -76,7 +86,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dpilqr_abi_version() != 1:
+        if lib.dpilqr_abi_version() != 2:
             raise ImportError("libdpilqr_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -127,6 +137,26 @@ def profile_read_sweep(waves, reset=True):
     ms, ln, it = f64(), i64(), i64()
     check(load().dpilqr_profile_read_sweep(int(waves), C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
     return dict(ms=ms.value, launches=ln.value, items=it.value)
+
+
+import threading
+
+_solvers = threading.local()
+
+
+def solver():
+    """The calling thread's dpilqr_solver for the current device (the synchronous solve's pinned mailbox and events):
+    created once, explicitly, so that no solve allocates behind the caller's back."""
+    import torch
+    dev = torch.cuda.current_device()
+    table = getattr(_solvers, "table", None)
+    if table is None:
+        table = _solvers.table = {}
+    if dev not in table:
+        h = vp()
+        check(load().dpilqr_solver_create(C.byref(h)))
+        table[dev] = h
+    return table[dev]
 
 
 _device_ok = None

@@ -10,6 +10,7 @@ Python objects on the hot path:
     ilqrSolver.solve           control.py:150-225  -> ProblemBatch.solve
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -130,18 +131,27 @@ class ProblemBatch:
     def tiles_buffer(self):
         return empty((self.B, self.T + 1, self.tile_stride))
 
-    def _in(self, a, shape):
-        t = to_dev(a)
+    # ------------------------------------------------------------------ passes
+    # dtype=torch.float32 selects the fp32 arm of BASELINE config 5's tolerance study (the *_f32 entry points): the
+    # same passes with trajectories, gains and every intermediate in float; costs and the solver state stay double.
+    @property
+    def fused_sweep(self):
+        """Clusters with n_x > 60 take the large-cluster path: linearize / quadraticize are evaluated inside the sweep,
+        no tile records exist (one would be 1.28 MB at n_x = 240)."""
+        return self.n_x > 60
+
+    def _in(self, a, shape, dtype=torch.float64):
+        t = to_dev(a, dtype)
         if tuple(t.shape) != tuple(shape):
             t = t.reshape(shape)
         return t.contiguous()
 
-    # ------------------------------------------------------------------ passes
-    def rollout(self, x0, U):
+    def rollout(self, x0, U, dtype=torch.float64):
         """control.py:80-93 for every item: returns X (B,T+1,n_x), J (B,) device tensors."""
-        x0 = self._in(x0, (self.B, self.n_x)); U = self._in(U, (self.B, self.T, self.n_u))
-        X = empty((self.B, self.T + 1, self.n_x)); J = empty((self.B,))
-        _lib.check(self._lib.dpilqr_rollout(self._d, ptr(x0), ptr(U), ptr(X), ptr(J), stream_handle()))
+        x0 = self._in(x0, (self.B, self.n_x), dtype); U = self._in(U, (self.B, self.T, self.n_u), dtype)
+        X = empty((self.B, self.T + 1, self.n_x), dtype); J = empty((self.B,))
+        fn = self._lib.dpilqr_rollout if dtype == torch.float64 else self._lib.dpilqr_rollout_f32
+        _lib.check(fn(self._d, ptr(x0), ptr(U), ptr(X), ptr(J), stream_handle()))
         return X, J
 
     def make_tiles(self, X, U, tiles=None):
@@ -163,19 +173,30 @@ class ProblemBatch:
             out[key] = a[:, :, 0, :] if key in ("Lx", "Lu") else a
         return out
 
-    def backward_pass(self, X, U, mu, tiles=None):
+    def backward_pass(self, X, U, mu, tiles=None, dtype=torch.float64):
         """control.py:116-148: K (B,T,n_u,n_x), d (B,T,n_u)."""
-        tiles = self.make_tiles(X, U, tiles)
-        return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu, blocks=(self.n_s, self.n_c))
+        if dtype == torch.float64 and not self.fused_sweep and "DPILQR_FORCE_BIG" not in os.environ:
+            tiles = self.make_tiles(X, U, tiles)
+            return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu, blocks=(self.n_s, self.n_c))
+        B, T, n, m = self.B, self.T, self.n_x, self.n_u
+        X = self._in(X, (B, T + 1, n), dtype); U = self._in(U, (B, T, m), dtype)
+        mu_t = to_dev(np.broadcast_to(np.asarray(mu, dtype=np.float64), (B,))) if not isinstance(mu, torch.Tensor) else mu
+        K = empty((B, T, m, n), dtype); d = empty((B, T, m), dtype)
+        nbytes = self._lib.dpilqr_backward_pass_workspace_bytes(self._d, 8 if dtype == torch.float64 else 4)
+        _lib.check(nbytes)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
+        fn = self._lib.dpilqr_backward_pass if dtype == torch.float64 else self._lib.dpilqr_backward_pass_f32
+        _lib.check(fn(self._d, ptr(X), ptr(U), ptr(mu_t), ptr(K), ptr(d), ptr(ws), stream_handle()))
+        return K, d
 
-    def forward_pass(self, X, U, K, d, alphas):
+    def forward_pass(self, X, U, K, d, alphas, dtype=torch.float64):
         """control.py:95-114 for all alphas: Xn (B,A,T+1,n_x), Un (B,A,T,n_u), Jn (B,A)."""
-        X = self._in(X, (self.B, self.T + 1, self.n_x)); U = self._in(U, (self.B, self.T, self.n_u))
-        K = self._in(K, (self.B, self.T, self.n_u, self.n_x)); d = self._in(d, (self.B, self.T, self.n_u))
+        X = self._in(X, (self.B, self.T + 1, self.n_x), dtype); U = self._in(U, (self.B, self.T, self.n_u), dtype)
+        K = self._in(K, (self.B, self.T, self.n_u, self.n_x), dtype); d = self._in(d, (self.B, self.T, self.n_u), dtype)
         al = to_dev(np.asarray(alphas, dtype=np.float64)); A = int(al.numel())
-        Xn = empty((self.B, A, self.T + 1, self.n_x)); Un = empty((self.B, A, self.T, self.n_u)); Jn = empty((self.B, A))
-        _lib.check(self._lib.dpilqr_forward_pass(self._d, ptr(X), ptr(U), ptr(K), ptr(d), ptr(al), A, ptr(Xn),
-                                                 ptr(Un), ptr(Jn), stream_handle()))
+        Xn = empty((self.B, A, self.T + 1, self.n_x), dtype); Un = empty((self.B, A, self.T, self.n_u), dtype); Jn = empty((self.B, A))
+        fn = self._lib.dpilqr_forward_pass if dtype == torch.float64 else self._lib.dpilqr_forward_pass_f32
+        _lib.check(fn(self._d, ptr(X), ptr(U), ptr(K), ptr(d), ptr(al), A, ptr(Xn), ptr(Un), ptr(Jn), stream_handle()))
         return Xn, Un, Jn
 
     def cost(self, x, u, terminal=False):
@@ -189,22 +210,26 @@ class ProblemBatch:
         return out
 
     # ------------------------------------------------------------------ whole solve
-    def workspace_bytes(self, window, gains_in_ws):
-        nbytes = self._lib.dpilqr_solve_workspace_bytes(self._d, int(window), int(bool(gains_in_ws)))
+    def workspace_bytes(self, window, gains_in_ws, dtype=torch.float64):
+        fn = self._lib.dpilqr_solve_workspace_bytes if dtype == torch.float64 else self._lib.dpilqr_solve_workspace_bytes_f32
+        nbytes = fn(self._d, int(window), int(bool(gains_in_ws)))
         _lib.check(nbytes)
         return int(nbytes)
 
-    def default_window(self):
+    def default_window(self, dtype=torch.float64):
         """Items in flight when the caller does not say: 6144 (two rounds of three sweep wavefronts per SIMD on an
         MI355X) for small clusters, fewer where the per-item buffers are large -- a 10-quadcopter item owns 8.8 MB of
         tile records, gains and line-search candidates, and several cluster sizes are solved concurrently
         (dispatch.py) -- so that one solve's workspace stays near 12 GB; never below 1024 (four rounds of the
-        workgroup-per-item sweep)."""
+        workgroup-per-item sweep), except on the large-cluster path (one workgroup per item: 256 = one per CU)."""
         T, n, m = self.T, self.n_x, self.n_u
+        if self.fused_sweep or dtype != torch.float64:
+            per_item = self.workspace_bytes(2, True, dtype) - self.workspace_bytes(1, True, dtype)
+            return int(min(self.B, 6144, max(256, (12 << 30) // max(per_item, 1))))
         per_item = 8 * ((T + 1) * self.tile_stride + T * m * (n + 1) + 10 * ((T + 1) * n + T * m))
         return int(min(self.B, 6144, max(1024, (12 << 30) // per_item)))
 
-    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None):
+    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64):
         """ilqrSolver.solve (control.py:150-225) for all B items.
 
         window: most items in flight at once (default: default_window()); finished items are retired on the device and
@@ -212,27 +237,55 @@ class ProblemBatch:
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
-        window = self.default_window() if window is None else int(window)
-        x0 = self._in(x0, (B, n))
-        U = self._in(U0, (B, T, m)).clone()
-        X = empty((B, T + 1, n)); J = empty((B,))
+        window = self.default_window(dtype) if window is None else int(window)
+        x0 = self._in(x0, (B, n), dtype)
+        U = self._in(U0, (B, T, m), dtype).clone()
+        X = empty((B, T + 1, n), dtype); J = empty((B,))
         status = empty((B,), torch.int32); n_bwd = empty((B,), torch.int32); n_fwd = empty((B,), torch.int32)
         tr = torch.full((B, max(n_lqr_iter, 1), 5), float("nan"), dtype=torch.float64, device=device()) if trace else None
-        K = empty((B, T, m, n)) if gains else None
-        d = empty((B, T, m)) if gains else None
-        ws = _workspace_pool.acquire(self.workspace_bytes(window, not gains))
+        K = empty((B, T, m, n), dtype) if gains else None
+        d = empty((B, T, m), dtype) if gains else None
+        ws = _workspace_pool.acquire(self.workspace_bytes(window, not gains, dtype))
+        fn = self._lib.dpilqr_solve_batch if dtype == torch.float64 else self._lib.dpilqr_solve_batch_f32
+        ok = False
         try:
-            _lib.check(self._lib.dpilqr_solve_batch(self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws),
-                                                    ws.numel(), ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd),
-                                                    ptr(tr), ptr(K), ptr(d), stream_handle()))
+            _lib.check(fn(_lib.solver(), self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws), ws.numel(),
+                          ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd), ptr(tr), ptr(K), ptr(d), stream_handle()))
+            ok = True
         finally:
-            _workspace_pool.release(ws)   # solve_batch has synchronised its stream: the buffer is idle
+            if ok:
+                _workspace_pool.release(ws)   # solve_batch has synchronised its stream: the buffer is idle
+            # a failed solve's buffer is dropped, not pooled: the allocator frees it in stream order
         out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
         if trace:
             out["trace"] = tr
         if gains:
             out["K"], out["d"] = K, d
         return out
+
+    def solve_enqueue(self, x0, U0, n_global_iter, n_lqr_iter=50, tol=1e-3, window=None, state=None):
+        """The same solve as pure enqueue on torch's current stream (dpilqr_solve_enqueue): nothing is waited for.
+        Returns (results dict, state); pass `state` back to continue with another n_global_iter iterations.  An item is
+        finished when its status is no longer 0 (STATUS_ACTIVE)."""
+        B, T, n, m = self.B, self.T, self.n_x, self.n_u
+        if state is None:
+            window = self.default_window() if window is None else int(window)
+            x0 = self._in(x0, (B, n)); U = self._in(U0, (B, T, m)).clone()
+            r = dict(X=empty((B, T + 1, n)), U=U, J=empty((B,)), status=empty((B,), torch.int32),
+                     n_bwd=empty((B,), torch.int32), n_fwd=empty((B,), torch.int32))
+            ws = torch.empty(self.workspace_bytes(window, True), dtype=torch.uint8, device=device())
+            state = dict(r=r, ws=ws, x0=x0, window=window, resume=0)
+        r, ws = state["r"], state["ws"]
+        _lib.check(self._lib.dpilqr_solve_enqueue(self._d, ptr(state["x0"]), ptr(r["U"]), int(n_lqr_iter), float(tol),
+                                                  state["window"], ptr(ws), ws.numel(), ptr(r["X"]), ptr(r["J"]),
+                                                  ptr(r["status"]), ptr(r["n_bwd"]), ptr(r["n_fwd"]), None, None, None,
+                                                  int(n_global_iter), state["resume"], stream_handle()))
+        state["resume"] = 1
+        return r, state
+
+    def iterations_bound(self, n_lqr_iter=50, window=None):
+        window = self.default_window() if window is None else int(window)
+        return int(self._lib.dpilqr_solve_iterations_bound(self._d, window, int(n_lqr_iter)))
 
 
 def backward_pass_tiles(tiles, B, T, n_x, n_u, mu, singular=None, blocks=None):

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "dpilqr_hip.h"
@@ -102,7 +103,7 @@ __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int3
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
     if (threadIdx.x == 0) {
         *count = base + n_new; *admitted = first + n_new; *next_count = 0;
-        mail[0] = base + n_new; mail[1] = first + n_new;   // pinned host memory: the host reads it after the event
+        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; }   // pinned host memory: the host reads it after the event
     }
 }
 
@@ -118,21 +119,28 @@ __global__ void k_finish_status(int B, int32_t* status) {  // n_lqr_iter == 0: n
 
 constexpr int kCountRing = 4;
 
+// Shape of a solve: which kernels serve it and how large an element is.
+struct SolveShape {
+    bool big;        // the fused workgroup-per-item sweep of tu_big.hip (n_x > 60, or the fp32 arm): no tile records
+    size_t elem;     // bytes per element of the trajectories / gains (8: fp64, 4: fp32)
+};
+
 struct SolveWorkspace {
-    // W = window = most sub-problems in flight at once: the big per-iteration buffers (tile records, gains,
-    // line-search candidates) are indexed by position in the active list and sized by W, not by B.
+    // W = window = most sub-problems in flight at once: the big per-iteration buffers (tile records or sweep scratch,
+    // gains, line-search candidates) are indexed by position in the active list and sized by W, not by B.
     size_t tiles, K, d, Xc, Uc, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
-    SolveWorkspace(const dpilqr_batch_desc& D, int W, bool gains_in_ws) {
-        const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T, Wn = W;
+    SolveWorkspace(const dpilqr_batch_desc& D, int W, bool gains_in_ws, SolveShape sh) {
+        const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T, Wn = W, e = sh.elem;
         const TileLayout L((int)n, (int)m);
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         size_t o = 0;
-        tiles = o;    o = al(o + sizeof(double) * Wn * (T + 1) * L.stride);
-        K = o;        o = al(o + (gains_in_ws ? sizeof(double) * Wn * T * m * n : 0));
-        d = o;        o = al(o + (gains_in_ws ? sizeof(double) * Wn * T * m : 0));
+        tiles = o;    o = al(o + (sh.big ? e * Wn * (size_t)riccati_big_scratch_elems((int)n, (int)m)
+                                         : sizeof(double) * Wn * (T + 1) * L.stride));
+        K = o;        o = al(o + (gains_in_ws ? e * Wn * T * m * n : 0));
+        d = o;        o = al(o + (gains_in_ws ? e * Wn * T * m : 0));
         // line-search candidates: every alpha's trajectory, so that accepting one is a copy, not a re-roll
-        Xc = o;       o = al(o + sizeof(double) * Wn * DPILQR_N_ALPHA * (T + 1) * n);
-        Uc = o;       o = al(o + sizeof(double) * Wn * DPILQR_N_ALPHA * T * m);
+        Xc = o;       o = al(o + e * Wn * DPILQR_N_ALPHA * (T + 1) * n);
+        Uc = o;       o = al(o + e * Wn * DPILQR_N_ALPHA * T * m);
         mu = o;       o = al(o + sizeof(double) * B);
         delta = o;    o = al(o + sizeof(double) * B);
         J_star = o;   o = al(o + sizeof(double) * B);
@@ -154,19 +162,6 @@ int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || w
 // does not leave the GPU idle.  The price is kHostLag empty iterations (a dozen tiny launches) at the end of a solve.
 constexpr int kHostLag = 3, kMailRing = kHostLag + 1;
 
-struct Mailbox {  // pinned host words the admission kernel posts the active-list counters into
-    int32_t* host = nullptr;
-    int32_t* dev = nullptr;   // the same words as the device sees them
-    std::vector<int32_t> hist;  // exact active-list length of every global iteration of the last solve
-    hipEvent_t ev[kMailRing] = {};
-    ~Mailbox() {
-        if (host) (void)hipHostFree(host);
-        for (auto& e : ev)
-            if (e) (void)hipEventDestroy(e);
-    }
-};
-thread_local Mailbox g_mail;
-
 // opt-in per-kernel timing (dpilqr_profile_*): event pairs recorded on the solve's own stream
 struct Profiler {
     bool on = false;
@@ -182,6 +177,9 @@ struct Profiler {
     struct Rec { int cls, iter; size_t e0; int tag; };
     std::vector<Rec> recs;
     size_t used = 0;
+    ~Profiler() {
+        for (auto& e : pool) (void)hipEventDestroy(e);
+    }
     hipEvent_t next() {
         if (used == pool.size()) {
             hipEvent_t e;
@@ -203,9 +201,10 @@ struct Profiler {
         if (e) (void)hipEventRecord(e, st);
         recs.back().tag = tag;
     }
+    void drop() { recs.clear(); used = 0; }   // a failed solve: forget the half-recorded pairs
     // after the stream has been synchronised; active[it] = items processed by iteration it
     void collect(const std::vector<int32_t>& active, int B) {
-        if (!on) return;
+        if (!on) { drop(); return; }
         for (const Rec& r : recs) {
             float t = 0.f;
             if (r.e0 + 1 < pool.size() && hipEventElapsedTime(&t, pool[r.e0], pool[r.e0 + 1]) == hipSuccess) {
@@ -219,11 +218,278 @@ struct Profiler {
                 }
             }
         }
-        recs.clear();
-        used = 0;
+        drop();
     }
 };
-thread_local Profiler g_prof;
+
+}  // namespace
+
+// Host-side state of the synchronous solve (dpilqr_solver_create): the pinned mailbox the admission kernel posts the
+// active-list counters into, the events that tell the host when a post has landed, and the optional profiler.  Bound
+// to the device that was current when it was created.
+struct dpilqr_solver {
+    int device = -1;
+    int32_t* host = nullptr;
+    int32_t* dev = nullptr;      // the same words as the device sees them
+    std::vector<int32_t> hist;   // exact active-list length of every global iteration of the last solve
+    hipEvent_t ev[kMailRing] = {};
+    Profiler prof;
+    int32_t init() {
+        HIP_TRY(hipGetDevice(&device));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(int32_t) * 2 * kMailRing, hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0));
+        for (auto& e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return DPILQR_OK;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
+        for (auto& e : ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+    }
+    ~dpilqr_solver() { release(); }
+};
+
+namespace {
+
+// dpilqr_solve_batch(solver = NULL): one default solver per host thread, created on first use, re-created when the
+// thread has moved to another device
+thread_local dpilqr_solver g_default_solver;
+
+int32_t default_solver(dpilqr_solver** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_default_solver.host && g_default_solver.device != dev) g_default_solver.release();
+    if (!g_default_solver.host) {
+        int32_t rc = g_default_solver.init();
+        if (rc) return rc;
+    }
+    *out = &g_default_solver;
+    return DPILQR_OK;
+}
+
+// At the end of an enqueue-only call: bring the double-buffered active list and the counter ring back to the state a
+// call starting at iteration 0 expects (survivors in list 0, their count in counts[0], the other counters zero).
+__global__ void k_normalise_lists(int32_t* lists, int32_t* counts, int window, int it_end) {
+    const int src = it_end & 1, cs = it_end % kCountRing;
+    __shared__ int n_sh;
+    if (threadIdx.x == 0) n_sh = counts[cs];
+    __syncthreads();
+    const int n = n_sh;
+    if (src == 1)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) lists[i] = lists[window + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < kCountRing; ++c) counts[c] = 0;
+        counts[0] = n;
+    }
+}
+
+// per arithmetic type: the launchers of a solve
+template <typename R> struct Passes;
+template <> struct Passes<double> {
+    static int32_t forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
+                           const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
+                           const SolveState& S, const int32_t* items, const int32_t* n_items, int grid, hipStream_t st) {
+        return launch_forward(D, mode, x0, X, U, K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, grid, st);
+    }
+    static int32_t sweep_big(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
+                             int32_t* sing, const int32_t* items, const int32_t* n_items, int grid, int by_item, void* scratch,
+                             hipStream_t st) {
+        return launch_riccati_big_f64(D, X, U, mu, K, d, sing, items, n_items, grid, by_item, scratch, st);
+    }
+};
+template <> struct Passes<float> {
+    static int32_t forward(const dpilqr_batch_desc& D, int mode, const float* x0, float* X, float* U, const float* K,
+                           const float* d, const double* alphas, int ngrp, float* Xc, float* Uc, double* Jc,
+                           const SolveState& S, const int32_t* items, const int32_t* n_items, int grid, hipStream_t st) {
+        return launch_forward_big_f32(D, mode, x0, X, U, K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, grid, st);
+    }
+    static int32_t sweep_big(const dpilqr_batch_desc& D, const float* X, const float* U, const double* mu, float* K, float* d,
+                             int32_t* sing, const int32_t* items, const int32_t* n_items, int grid, int by_item, void* scratch,
+                             hipStream_t st) {
+        return launch_riccati_big_f32(D, X, U, mu, K, d, sing, items, n_items, grid, by_item, scratch, st);
+    }
+};
+
+template <typename R>
+SolveShape shape_of(const dpilqr_batch_desc& D) {
+    return SolveShape{sizeof(R) == 4 || uses_big_path(D.k * D.n_s), sizeof(R)};
+}
+
+// ilqrSolver.solve for every item of the batch.  solver != NULL: the synchronous, adaptive form (the host follows the
+// device's counters a few iterations late and stops launching when everything has finished).  solver == NULL: the
+// enqueue-only form -- exactly n_global_iter iterations of launches, no host read, no synchronisation.
+template <typename R>
+int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R* x0, R* U, int32_t n_lqr_iter, double tol,
+                   int32_t window, void* workspace, int64_t workspace_bytes, R* X, double* J, int32_t* status,
+                   int32_t* n_bwd, int32_t* n_fwd, double* trace, R* K_out, R* d_out, int32_t n_global_iter,
+                   int32_t resume, hipStream_t st) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;   // an empty batch: nothing to read or write
+    if (!x0 || !U || !X || !J || !status || !n_bwd || !n_fwd || !workspace)
+        return fail(DPILQR_EINVAL, "solve_batch: NULL pointer");
+    if ((K_out == nullptr) != (d_out == nullptr)) return fail(DPILQR_EINVAL, "solve_batch: K_out and d_out go together");
+    if (n_lqr_iter < 0 || n_lqr_iter > kMaxLqrIter) return fail(DPILQR_EINVAL, "solve_batch: n_lqr_iter=%d", n_lqr_iter);
+    if (!solver && n_global_iter < 0) return fail(DPILQR_EINVAL, "solve_enqueue: n_global_iter=%d", n_global_iter);
+    const dpilqr_batch_desc& D = *desc;
+    const int Wn = window_of(D, window);
+    const bool gains_by_item = K_out != nullptr;
+    const SolveShape sh = shape_of<R>(D);
+    const SolveWorkspace W(D, Wn, !gains_by_item, sh);
+    if (workspace_bytes < (int64_t)W.total)
+        return fail(DPILQR_EWORKSPACE, "solve_batch: workspace %lld B < required %zu B", (long long)workspace_bytes, W.total);
+    if (solver) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != solver->device)
+            return fail(DPILQR_EINVAL, "solve_batch: the solver belongs to device %d, the current device is %d", solver->device, dev);
+    }
+    char* ws = static_cast<char*>(workspace);
+    double* tiles = reinterpret_cast<double*>(ws + W.tiles);       // tile records, or the big sweep's scratch
+    R* K = gains_by_item ? K_out : reinterpret_cast<R*>(ws + W.K);
+    R* d = gains_by_item ? d_out : reinterpret_cast<R*>(ws + W.d);
+    double* alphas = reinterpret_cast<double*>(ws + W.alphas);
+    R* Xc = reinterpret_cast<R*>(ws + W.Xc);
+    R* Uc = reinterpret_cast<R*>(ws + W.Uc);
+    int32_t* lists = reinterpret_cast<int32_t*>(ws + W.lists);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + W.counts);
+    int32_t* singular = reinterpret_cast<int32_t*>(ws + W.singular);
+    SolveState S{};
+    S.mu = reinterpret_cast<double*>(ws + W.mu);
+    S.delta = reinterpret_cast<double*>(ws + W.delta);
+    S.J_star = reinterpret_cast<double*>(ws + W.J_star);
+    S.J_last = reinterpret_cast<double*>(ws + W.J_last);
+    S.status = status; S.n_bwd = n_bwd; S.n_fwd = n_fwd; S.trace = trace; S.singular = singular;
+    S.n_lqr_iter = n_lqr_iter; S.tol = tol; S.gains_by_item = gains_by_item ? 1 : 0;
+    const int n = D.k * D.n_s, m = D.k * D.n_c;
+    Profiler none;
+    Profiler& prof = solver ? solver->prof : none;
+    if (solver) solver->hist.clear();
+    // every failure after the first launch leaves kernels queued that still use the workspace: wait for them before
+    // the caller gets its buffers back, and forget the profiler's half-recorded event pairs
+    auto bail = [&](int32_t code) {
+        (void)hipStreamSynchronize(st);
+        prof.drop();
+        return code;
+    };
+
+    int32_t* admitted_dev = counts + kCountRing;
+    static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
+    const int um = hint_model(D);
+    // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every item
+    const bool static_part = !sh.big && !no_static && D.R_bstride == 0 &&
+                             (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
+    if (!resume) {
+        double a[DPILQR_N_ALPHA];
+        alpha_table(a);
+        const int init_n = D.B > kCountRing + 1 ? D.B : kCountRing + 1;
+        hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
+                           singular, counts, kCountRing + 1, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+        HIP_TRY(hipGetLastError());
+        // X, J* <- rollout(x0, U) for every item up front (control.py:164)
+        prof.begin(3, -1, st);
+        rc = Passes<R>::forward(D, kModeRollout, x0, X, U, nullptr, nullptr, nullptr, 1, nullptr, nullptr, S.J_star, S, nullptr,
+                                nullptr, D.B, st);
+        if (rc) return bail(rc);
+        prof.end(st);
+        hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_star, S.J_last);
+        if (n_lqr_iter > 0) {
+            // tile records: the producer of the loop writes only structurally non-zero entries, so the zeros are put in
+            // place once; the big sweep's scratch: its padding is zero and never written
+            if (hipMemsetAsync(tiles, 0, W.K - W.tiles, st) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipMemsetAsync failed"));
+            // the static part is written once into all Wn slots here (with items 0..Wn-1 as stand-ins; their (X, U)
+            // dependent entries are overwritten by each iteration's producer launch) and skipped afterwards
+            if (static_part) {
+                if constexpr (sizeof(R) == 8) {
+                    if ((rc = launch_make_tiles(D, X, U, tiles, nullptr, nullptr, Wn, true, false, st))) return bail(rc);
+                }
+            }
+        }
+    }
+
+    // Iteration loop with continuous admission.  At most Wn sub-problems are in flight; one global iteration = one
+    // backward pass + one line search for every active item.  Items that finish are retired by the line-search kernel
+    // (it pushes only the survivors onto the next list) and k_admit refills their places from the not-yet-started items,
+    // so every launch stays at Wn items although the items need very different numbers of iterations.  The active set
+    // lives on the device; the host launches Wn-wide grids (surplus workgroups exit at once).
+    size_t n_iterations = 0;
+    auto enqueue_iteration = [&](int it, int upper) -> int32_t {
+        int32_t* cur = lists + (size_t)(it & 1) * Wn;
+        int32_t* cur_n = counts + (it % kCountRing);
+        int32_t* nxt_n = counts + ((it + 1) % kCountRing);
+        int32_t* mail = solver ? solver->dev + 2 * (it % kMailRing) : nullptr;
+        hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail);
+        if (solver) HIP_TRY(hipEventRecord(solver->ev[it % kMailRing], st));
+        S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
+        S.next_count = nxt_n;
+        int32_t r = DPILQR_OK;
+        if (!sh.big) {
+            if constexpr (sizeof(R) == 8) {
+                prof.begin(0, it, st);
+                if ((r = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, static_part, st))) return r;
+                prof.end(st);
+                prof.begin(1, it, st);
+                if ((r = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, D.n_s,
+                                        D.n_c, st)))
+                    return r;
+                prof.end(st, g_sweep_waves);
+            }
+        } else {
+            prof.begin(1, it, st);
+            if ((r = Passes<R>::sweep_big(D, X, U, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, tiles, st))) return r;
+            prof.end(st, 0);
+        }
+        prof.begin(2, it, st);
+        if ((r = Passes<R>::forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr, S, cur, cur_n,
+                                    upper, st)))
+            return r;
+        prof.end(st);
+        return DPILQR_OK;
+    };
+
+    if (n_lqr_iter > 0 && solver) {
+        // the host reads {active, admitted} kHostLag iterations late -- that many iterations of launches are always
+        // queued while it waits -- to learn when everything has been started and nothing is left active
+        int upper = Wn;
+        for (int it = 0; it < kMaxGlobalIter; ++it) {
+            n_iterations = (size_t)it + 1;
+            if ((rc = enqueue_iteration(it, upper))) return bail(rc);
+            bool done = false;
+            if (it >= kHostLag) {  // {active, admitted} of iteration it - kHostLag
+                const int slot = (it - kHostLag) % kMailRing;
+                if (hipEventSynchronize(solver->ev[slot]) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipEventSynchronize failed"));
+                const int32_t act = solver->host[2 * slot], adm = solver->host[2 * slot + 1];
+                solver->hist.push_back(act);
+                // everything started and the list already empty back then: the iterations since were no-ops
+                done = (adm >= D.B && act == 0);
+                // once everything is admitted the list can only shrink: tighten the grid
+                upper = (adm >= D.B) ? std::min(Wn, std::max(act, 1)) : Wn;
+            }
+            if (done) break;
+            if (it + 1 == kMaxGlobalIter) return bail(fail(DPILQR_EUNSUPPORTED, "solve_batch: more than %d global iterations", kMaxGlobalIter));
+        }
+    } else if (n_lqr_iter > 0) {
+        for (int it = 0; it < n_global_iter; ++it)
+            if ((rc = enqueue_iteration(it, Wn))) return rc;
+        if (n_global_iter > 0)
+            hipLaunchKernelGGL(k_normalise_lists, dim3(1), dim3(256), 0, st, lists, counts, Wn, n_global_iter);
+    }
+    hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_last, J);
+    if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
+    HIP_TRY(hipGetLastError());
+    if (!solver) return DPILQR_OK;       // enqueue-only: everything is on the stream, nothing was waited for
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipStreamSynchronize failed"));
+    if (n_lqr_iter > 0) {
+        // the last iterations' exact lengths were posted but not yet consumed
+        for (size_t j = solver->hist.size(); j < n_iterations; ++j) solver->hist.push_back(solver->host[2 * (j % kMailRing)]);
+    }
+    prof.collect(solver->hist, D.B);
+    return DPILQR_OK;
+}
 
 }  // namespace
 
@@ -333,15 +599,62 @@ int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int
                           as_stream(stream));
 }
 
+int64_t dpilqr_backward_pass_workspace_bytes(const dpilqr_batch_desc* desc, int32_t elem_bytes) {
+    if (!desc || desc->B < 0 || desc->k < 1 || desc->T < 1 || (elem_bytes != 4 && elem_bytes != 8))
+        return fail(DPILQR_EINVAL, "backward_pass_workspace_bytes: bad argument");
+    const int n = desc->k * desc->n_s, m = desc->k * desc->n_c;
+    if (elem_bytes == 4 || uses_big_path(n)) return (int64_t)elem_bytes * desc->B * riccati_big_scratch_elems(n, m);
+    return (int64_t)sizeof(double) * desc->B * (desc->T + 1) * TileLayout(n, m).stride;
+}
+
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
                              double* K, double* d, double* tiles_workspace, void* stream) {
     int32_t rc = check_desc(desc);
     if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
     if (!X || !U || !mu || !K || !d || !tiles_workspace) return fail(DPILQR_EINVAL, "backward_pass: NULL pointer");
+    const int n = desc->k * desc->n_s, m = desc->k * desc->n_c;
+    if (uses_big_path(n)) {   // large clusters: the fused sweep (no tile records); the workspace is its scratch
+        HIP_TRY(hipMemsetAsync(tiles_workspace, 0, sizeof(double) * desc->B * (size_t)riccati_big_scratch_elems(n, m), as_stream(stream)));
+        return launch_riccati_big_f64(*desc, X, U, mu, K, d, nullptr, nullptr, nullptr, desc->B, 0, tiles_workspace, as_stream(stream));
+    }
     rc = launch_make_tiles(*desc, X, U, tiles_workspace, nullptr, nullptr, desc->B, false, false, as_stream(stream));
     if (rc) return rc;
-    return launch_riccati(desc->B, desc->T, desc->k * desc->n_s, desc->k * desc->n_c, tiles_workspace, mu, K, d, nullptr,
-                          nullptr, nullptr, desc->B, 0, desc->n_s, desc->n_c, as_stream(stream));
+    return launch_riccati(desc->B, desc->T, n, m, tiles_workspace, mu, K, d, nullptr, nullptr, nullptr, desc->B, 0, desc->n_s,
+                          desc->n_c, as_stream(stream));
+}
+
+int32_t dpilqr_backward_pass_f32(const dpilqr_batch_desc* desc, const float* X, const float* U, const double* mu, float* K,
+                                 float* d, void* workspace, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
+    if (!X || !U || !mu || !K || !d || !workspace) return fail(DPILQR_EINVAL, "backward_pass_f32: NULL pointer");
+    const int n = desc->k * desc->n_s, m = desc->k * desc->n_c;
+    HIP_TRY(hipMemsetAsync(workspace, 0, sizeof(float) * desc->B * (size_t)riccati_big_scratch_elems(n, m), as_stream(stream)));
+    return launch_riccati_big_f32(*desc, X, U, mu, K, d, nullptr, nullptr, nullptr, desc->B, 0, workspace, as_stream(stream));
+}
+
+int32_t dpilqr_rollout_f32(const dpilqr_batch_desc* desc, const float* x0, const float* U, float* X, double* J, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
+    if (!x0 || !U || !X || !J) return fail(DPILQR_EINVAL, "rollout_f32: NULL pointer");
+    SolveState S{};
+    return launch_forward_big_f32(*desc, kModeRollout, x0, X, const_cast<float*>(U), nullptr, nullptr, nullptr, 1, nullptr, nullptr,
+                                  J, S, nullptr, nullptr, desc->B, as_stream(stream));
+}
+
+int32_t dpilqr_forward_pass_f32(const dpilqr_batch_desc* desc, const float* X, const float* U, const float* K, const float* d,
+                                const double* alphas, int32_t n_alpha, float* Xn, float* Un, double* Jn, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
+    if (!X || !U || !K || !d || !alphas || !Xn || !Un || !Jn) return fail(DPILQR_EINVAL, "forward_pass_f32: NULL pointer");
+    if (n_alpha < 1) return fail(DPILQR_EINVAL, "forward_pass_f32: n_alpha=%d", n_alpha);
+    SolveState S{};
+    return launch_forward_big_f32(*desc, kModeCandidates, nullptr, const_cast<float*>(X), const_cast<float*>(U), K, d, alphas,
+                                  n_alpha, Xn, Un, Jn, S, nullptr, nullptr, desc->B, as_stream(stream));
 }
 
 int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,
@@ -364,138 +677,62 @@ int32_t dpilqr_alphas(double* alphas_host) {
 
 int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace) {
     if (!desc || desc->B < 0 || desc->k < 1 || desc->T < 1) return fail(DPILQR_EINVAL, "solve_workspace_bytes: bad desc");
-    return (int64_t)SolveWorkspace(*desc, window_of(*desc, window), gains_in_workspace != 0).total;
+    return (int64_t)SolveWorkspace(*desc, window_of(*desc, window), gains_in_workspace != 0, shape_of<double>(*desc)).total;
+}
+int64_t dpilqr_solve_workspace_bytes_f32(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace) {
+    if (!desc || desc->B < 0 || desc->k < 1 || desc->T < 1) return fail(DPILQR_EINVAL, "solve_workspace_bytes_f32: bad desc");
+    return (int64_t)SolveWorkspace(*desc, window_of(*desc, window), gains_in_workspace != 0, shape_of<float>(*desc)).total;
 }
 
-int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
-                           int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
-                           int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out,
-                           void* stream) {
-    int32_t rc = check_desc(desc);
-    if (rc) return rc;
-    if (desc->B == 0) return DPILQR_OK;   // an empty batch: nothing to read or write
-    if (!x0 || !U || !X || !J || !status || !n_bwd || !n_fwd || !workspace)
-        return fail(DPILQR_EINVAL, "solve_batch: NULL pointer");
-    if ((K_out == nullptr) != (d_out == nullptr)) return fail(DPILQR_EINVAL, "solve_batch: K_out and d_out go together");
-    if (n_lqr_iter < 0 || n_lqr_iter > kMaxLqrIter) return fail(DPILQR_EINVAL, "solve_batch: n_lqr_iter=%d", n_lqr_iter);
-    const dpilqr_batch_desc& D = *desc;
-    const int Wn = window_of(D, window);
-    const bool gains_by_item = K_out != nullptr;
-    const SolveWorkspace W(D, Wn, !gains_by_item);
-    if (workspace_bytes < (int64_t)W.total)
-        return fail(DPILQR_EWORKSPACE, "solve_batch: workspace %lld B < required %zu B", (long long)workspace_bytes, W.total);
-    if (D.B == 0) return DPILQR_OK;
-    hipStream_t st = as_stream(stream);
-    char* ws = static_cast<char*>(workspace);
-    double* tiles = reinterpret_cast<double*>(ws + W.tiles);
-    double* K = gains_by_item ? K_out : reinterpret_cast<double*>(ws + W.K);
-    double* d = gains_by_item ? d_out : reinterpret_cast<double*>(ws + W.d);
-    double* alphas = reinterpret_cast<double*>(ws + W.alphas);
-    double* Xc = reinterpret_cast<double*>(ws + W.Xc);
-    double* Uc = reinterpret_cast<double*>(ws + W.Uc);
-    int32_t* lists = reinterpret_cast<int32_t*>(ws + W.lists);
-    int32_t* counts = reinterpret_cast<int32_t*>(ws + W.counts);
-    int32_t* singular = reinterpret_cast<int32_t*>(ws + W.singular);
-    SolveState S{};
-    S.mu = reinterpret_cast<double*>(ws + W.mu);
-    S.delta = reinterpret_cast<double*>(ws + W.delta);
-    S.J_star = reinterpret_cast<double*>(ws + W.J_star);
-    S.J_last = reinterpret_cast<double*>(ws + W.J_last);
-    S.status = status; S.n_bwd = n_bwd; S.n_fwd = n_fwd; S.trace = trace; S.singular = singular;
-    S.n_lqr_iter = n_lqr_iter; S.tol = tol; S.gains_by_item = gains_by_item ? 1 : 0;
-    const int n = D.k * D.n_s, m = D.k * D.n_c;
-
-    if (!g_mail.host) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_mail.host), sizeof(int32_t) * 2 * kMailRing, hipHostMallocDefault));
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_mail.dev), g_mail.host, 0));
-        for (auto& e : g_mail.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    g_mail.hist.clear();
-
-    double a[DPILQR_N_ALPHA];
-    alpha_table(a);
-    const int init_n = D.B > kCountRing + 1 ? D.B : kCountRing + 1;
-    hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
-                       singular, counts, kCountRing + 1, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
-    HIP_TRY(hipGetLastError());
-    // X, J* <- rollout(x0, U) for every item up front (control.py:164)
-    g_prof.begin(3, -1, st);
-    rc = launch_forward(D, kModeRollout, x0, X, U, nullptr, nullptr, nullptr, 1, nullptr, nullptr, S.J_star, S, nullptr,
-                        nullptr, D.B, st);
-    if (rc) return rc;
-    g_prof.end(st);
-    hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_star, S.J_last);
-
-    // Iteration loop with continuous admission.  At most Wn sub-problems are in flight; one global
-    // iteration = one backward pass + one line search for every active item.  Items that finish are
-    // retired by the line-search kernel (it pushes only the survivors onto the next list) and k_admit
-    // refills their places from the not-yet-started items, so every launch stays at Wn items although
-    // the items need very different numbers of iterations.  The active set lives on the device; the
-    // host launches Wn-wide grids (surplus workgroups exit at once) and only reads {active, admitted}
-    // one iteration late -- a full iteration of launches is always queued while it waits -- to learn
-    // when everything has been started and nothing is left active.
-    int32_t* admitted_dev = counts + kCountRing;
-    size_t n_iterations = 0;
-    if (n_lqr_iter > 0) {
-        // the tile producer of the loop writes only structurally non-zero entries: put the zeros in place once
-        HIP_TRY(hipMemsetAsync(tiles, 0, W.K - W.tiles, st));
-        // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every
-        // item, so they are written once into all Wn slots here (with items 0..Wn-1 as stand-ins; their (X, U)
-        // dependent entries are overwritten by each iteration's producer launch) and skipped afterwards.
-        static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
-        const int um = hint_model(D);
-        const bool static_part_placed = !no_static && D.R_bstride == 0 &&
-                                        (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
-        if (static_part_placed && (rc = launch_make_tiles(D, X, U, tiles, nullptr, nullptr, Wn, true, false, st))) return rc;
-        int upper = Wn;
-        for (int it = 0; it < kMaxGlobalIter; ++it) {
-            n_iterations = (size_t)it + 1;
-            int32_t* cur = lists + (size_t)(it & 1) * Wn;
-            int32_t* cur_n = counts + (it % kCountRing);
-            int32_t* nxt_n = counts + ((it + 1) % kCountRing);
-            hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn,
-                               g_mail.dev + 2 * (it % kMailRing));
-            HIP_TRY(hipEventRecord(g_mail.ev[it % kMailRing], st));
-            S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
-            S.next_count = nxt_n;
-            g_prof.begin(0, it, st);
-            if ((rc = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, static_part_placed, st))) return rc;
-            g_prof.end(st);
-            g_prof.begin(1, it, st);
-            if ((rc = launch_riccati(D.B, D.T, n, m, tiles, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, D.n_s, D.n_c,
-                                     st)))
-                return rc;
-            g_prof.end(st, g_sweep_waves);
-            g_prof.begin(2, it, st);
-            if ((rc = launch_forward(D, kModeLineSearch, nullptr, X, U, K, d, alphas, DPILQR_N_ALPHA, Xc, Uc, nullptr, S,
-                                     cur, cur_n, upper, st)))
-                return rc;
-            g_prof.end(st);
-            bool done = false;
-            if (it >= kHostLag) {  // {active, admitted} of iteration it - kHostLag
-                const int slot = (it - kHostLag) % kMailRing;
-                HIP_TRY(hipEventSynchronize(g_mail.ev[slot]));
-                const int32_t act = g_mail.host[2 * slot], adm = g_mail.host[2 * slot + 1];
-                g_mail.hist.push_back(act);
-                // everything started and the list already empty back then: the iterations since were no-ops
-                done = (adm >= D.B && act == 0);
-                // once everything is admitted the list can only shrink: tighten the grid
-                upper = (adm >= D.B) ? std::min(Wn, std::max(act, 1)) : Wn;
-            }
-            if (done) break;
-            if (it + 1 == kMaxGlobalIter) return fail(DPILQR_EUNSUPPORTED, "solve_batch: more than %d global iterations", kMaxGlobalIter);
-        }
-    }
-    hipLaunchKernelGGL(k_copy_f64, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, S.J_last, J);
-    if (n_lqr_iter == 0) hipLaunchKernelGGL(k_finish_status, dim3((D.B + 255) / 256), dim3(256), 0, st, D.B, status);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    if (n_lqr_iter > 0) {
-        // the last iterations' exact lengths were posted but not yet consumed
-        for (size_t j = g_mail.hist.size(); j < n_iterations; ++j) g_mail.hist.push_back(g_mail.host[2 * (j % kMailRing)]);
-    }
-    g_prof.collect(g_mail.hist, D.B);
+int32_t dpilqr_solver_create(dpilqr_solver** out) {
+    if (!out) return fail(DPILQR_EINVAL, "solver_create: NULL pointer");
+    dpilqr_solver* s = new (std::nothrow) dpilqr_solver();
+    if (!s) return fail(DPILQR_EHIP, "solver_create: out of host memory");
+    const int32_t rc = s->init();
+    if (rc) { delete s; return rc; }
+    *out = s;
     return DPILQR_OK;
+}
+int32_t dpilqr_solver_destroy(dpilqr_solver* solver) {
+    delete solver;
+    return DPILQR_OK;
+}
+
+int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const double* x0, double* U,
+                           int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                           double* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
+                           double* K_out, double* d_out, void* stream) {
+    if (!solver) {
+        const int32_t rc = default_solver(&solver);
+        if (rc) return rc;
+    }
+    return solve_impl<double>(solver, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+                              n_fwd, trace, K_out, d_out, 0, 0, as_stream(stream));
+}
+int32_t dpilqr_solve_batch_f32(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const float* x0, float* U,
+                               int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                               float* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
+                               float* K_out, float* d_out, void* stream) {
+    if (!solver) {
+        const int32_t rc = default_solver(&solver);
+        if (rc) return rc;
+    }
+    return solve_impl<float>(solver, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+                             n_fwd, trace, K_out, d_out, 0, 0, as_stream(stream));
+}
+int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
+                             int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J, int32_t* status,
+                             int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out,
+                             int32_t n_global_iter, int32_t resume, void* stream) {
+    return solve_impl<double>(nullptr, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+                              n_fwd, trace, K_out, d_out, n_global_iter, resume, as_stream(stream));
+}
+int64_t dpilqr_solve_iterations_bound(const dpilqr_batch_desc* desc, int32_t window, int32_t n_lqr_iter) {
+    if (!desc || desc->B < 0 || n_lqr_iter < 0) return fail(DPILQR_EINVAL, "solve_iterations_bound: bad argument");
+    const int64_t W = window_of(*desc, window);
+    // every global iteration with a non-empty list completes one iLQR iteration of >= 1 item, and an item that is in
+    // flight stays in flight until it finishes: ceil(B / W) generations of at most n_lqr_iter iterations each
+    return ((int64_t)desc->B + W - 1) / W * n_lqr_iter + 1;
 }
 
 int32_t dpilqr_debug_stamps(void* buf) {
@@ -504,6 +741,7 @@ int32_t dpilqr_debug_stamps(void* buf) {
 }
 
 int32_t dpilqr_profile_enable(int32_t enable) {
+    Profiler& g_prof = g_default_solver.prof;
     const int32_t prev = g_prof.on ? 1 : 0;
     g_prof.on = (enable & 1) != 0;
     g_prof.mask = (enable >> 1) & 0xF ? (enable >> 1) & 0xF : 0xF;
@@ -512,6 +750,7 @@ int32_t dpilqr_profile_enable(int32_t enable) {
 
 int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset) {
     if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read: NULL pointer");
+    Profiler& g_prof = g_default_solver.prof;
     for (int c = 0; c < 4; ++c) {
         ms[c] = g_prof.ms[c]; launches[c] = g_prof.launches[c]; items[c] = g_prof.items[c];
         if (reset) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; g_prof.items[c] = 0; }
@@ -523,6 +762,7 @@ int32_t dpilqr_profile_read_sweep(int32_t waves, double* ms, int64_t* launches, 
     if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read_sweep: NULL pointer");
     if (waves != 4 && waves != 8 && waves != 12) return fail(DPILQR_EINVAL, "profile_read_sweep: waves=%d (4, 8 or 12)", waves);
     const int v = waves / 4 - 1;
+    Profiler& g_prof = g_default_solver.prof;
     *ms = g_prof.sweep_ms[v]; *launches = g_prof.sweep_launches[v]; *items = g_prof.sweep_items[v];
     if (reset) { g_prof.sweep_ms[v] = 0; g_prof.sweep_launches[v] = 0; g_prof.sweep_items[v] = 0; }
     return DPILQR_OK;

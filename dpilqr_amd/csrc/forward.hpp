@@ -19,13 +19,15 @@
 
 namespace dpilqr {
 
-struct ForwardLds {
+struct ForwardLds {   // offsets in elements of the arithmetic type
     int Kt, dt, dx, xs, cref, cpair, J, ctl, total;
-    __host__ __device__ ForwardLds(int n, int m, int k, int ngrp) {
+    // kdirect: K[t] is read from global memory row by row instead of being staged (large clusters: K[t] alone is
+    // 154 KB at n_x = 240, n_u = 80)
+    __host__ __device__ ForwardLds(int n, int m, int k, int ngrp, bool kdirect = false) {
         const int npairs = k * (k - 1) / 2;
         int o = 0;
         // everything staged per time step is double-buffered by the parity of t: one barrier per step
-        Kt = o;    o += 2 * m * n;
+        Kt = o;    o += kdirect ? 0 : 2 * m * n;
         dt = o;    o += 2 * m;
         dx = o;    o += 2 * ngrp * n;
         xs = o;    o += 2 * ngrp * n;
@@ -33,10 +35,12 @@ struct ForwardLds {
         cpair = o; o += 2 * ngrp * (npairs > 0 ? npairs : 1);
         J = o;     o += ngrp;
         ctl = o;   o += 2;
-        total = o;
+        total = (o + 1) & ~1;
     }
 };
-inline size_t forward_lds_bytes(int n, int m, int k, int ngrp) { return sizeof(double) * (size_t)ForwardLds(n, m, k, ngrp).total; }
+inline size_t forward_lds_bytes(int n, int m, int k, int ngrp, bool kdirect = false, size_t elem = sizeof(double)) {
+    return elem * (size_t)ForwardLds(n, m, k, ngrp, kdirect).total;
+}
 
 // Workgroup-wide LDS hand-off.  A single-wave workgroup executes its LDS operations in order, so a
 // compiler fence is enough; larger workgroups use a bare s_barrier behind an LDS-only wait (NOT
@@ -51,22 +55,24 @@ constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step: ceil(n
 // One pass over the horizon for the calling thread's (candidate g, agent a).
 //   GAINS : u = U + (K dx + alpha d) (control.py:104-107) ; else u = U (control.py:89)
 //   Xw/Uw : where to write this candidate's trajectory (null = nowhere); never aliases Xold/Uold.
+//   R     : arithmetic type (double; float in the fp32 arm of BASELINE config 5's tolerance study)
 // Everything a step needs from HBM (K[t], d[t], X[t], U[t]) is fetched one step ahead into registers.
 // Returns J on the a == 0 lane of each candidate.
-template <int NS, int NC, bool GAINS>
-__device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int tid, int nth, bool active,
-                               int g, int a, int ngrp, const double* x_init, const double* __restrict__ Xold,
-                               const double* __restrict__ Uold, const double* __restrict__ Kb,
-                               const double* __restrict__ db, double alpha, double* __restrict__ Xw,
-                               double* __restrict__ Uw, double* lds) {
+template <typename R, int NS, int NC, bool GAINS, bool KDIRECT>
+__device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int tid, int nth, bool active,
+                          int g, int a, int ngrp, const R* x_init, const R* __restrict__ Xold,
+                          const R* __restrict__ Uold, const R* __restrict__ Kb,
+                          const R* __restrict__ db, R alpha, R* __restrict__ Xw,
+                          R* __restrict__ Uw, R* lds) {
     const int k = D.k, T = D.T, n = k * NS, m = k * NC;
     const int npairs = k * (k - 1) / 2, np1 = npairs > 0 ? npairs : 1;
-    const ForwardLds O(n, m, k, ngrp);
+    const ForwardLds O(n, m, k, ngrp, KDIRECT);
     const int gg = active ? g : 0;
     const bool single_wave = nth <= 64;
     const int mn = m * n;
+    const R dtr = (R)D.dt, radius = (R)P.radius, w_prox = (R)D.w_prox, w_ref = (R)D.w_ref;
 
-    double x[NS], xold[NS], u[NC], stK[kMaxStage], std_ = 0.0;
+    R x[NS], xold[NS], u[NC], stK[KDIRECT ? 1 : kMaxStage], std_ = 0.0;
     const int model = active ? P.model[a] : 0;
     const double* xf = P.xf + a * NS;
     const double* Qa = P.Q + a * NS * NS;
@@ -75,11 +81,13 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
 
     auto fetch = [&](int t) {  // registers <- HBM for step t
         if (GAINS) {
-            const double* Kt = Kb + (int64_t)t * mn;
+            if constexpr (!KDIRECT) {
+                const R* Kt = Kb + (int64_t)t * mn;
 #pragma unroll
-            for (int q = 0; q < kMaxStage; ++q) {
-                const int e = tid + q * nth;
-                if (e < mn) stK[q] = Kt[e];
+                for (int q = 0; q < kMaxStage; ++q) {
+                    const int e = tid + q * nth;
+                    if (e < mn) stK[q] = Kt[e];
+                }
             }
             if (tid < m) std_ = db[(int64_t)t * m + tid];
         }
@@ -102,20 +110,22 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
         }
     }
     fetch(0);
-    double J = 0.0;
+    R J = 0.0;
 
     for (int t = 0; t < T; ++t) {
         const int par = t & 1;
-        double* sKt = lds + O.Kt + par * mn;
-        double* sdt = lds + O.dt + par * m;
-        double* sdx = lds + O.dx + (par * ngrp + gg) * n;
-        double* sxs = lds + O.xs + (par * ngrp + gg) * n;
-        double ut[NC];
+        R* sKt = lds + O.Kt + par * (KDIRECT ? 0 : mn);
+        R* sdt = lds + O.dt + par * m;
+        R* sdx = lds + O.dx + (par * ngrp + gg) * n;
+        R* sxs = lds + O.xs + (par * ngrp + gg) * n;
+        R ut[NC];
         if (GAINS) {
+            if constexpr (!KDIRECT) {
 #pragma unroll
-            for (int q = 0; q < kMaxStage; ++q) {
-                const int e = tid + q * nth;
-                if (e < mn) sKt[e] = stK[q];
+                for (int q = 0; q < kMaxStage; ++q) {
+                    const int e = tid + q * nth;
+                    if (e < mn) sKt[e] = stK[q];
+                }
             }
             if (tid < m) sdt[tid] = std_;
         }
@@ -131,41 +141,42 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
         if (t + 1 < T) fetch(t + 1);
         lds_handoff(single_wave);
         if (active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), summed in the reference's order
-            const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
-            const double* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
-            double prox = 0.0, ref = 0.0;
+            const R* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
+            const R* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
+            R prox = 0.0, ref = 0.0;
             for (int p = 0; p < npairs; ++p) prox += cp[p];
             for (int i = 0; i < k; ++i) ref += cr[i];
-            J += D.w_prox * prox + D.w_ref * ref;
+            J += w_prox * prox + w_ref * ref;
         }
         if (active) {
             if (GAINS) {  // du = K[t] dx + alpha d[t] (control.py:106), this agent's NC rows, j ascending
-                double sum[NC];
+                R sum[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) sum[c] = 0.0;
-                const double* rows = sKt + (a * NC) * n;
+                // the agent's NC rows of K[t]: staged in LDS, or (large clusters) straight from global memory
+                const R* rows = KDIRECT ? Kb + (int64_t)t * mn + (int64_t)(a * NC) * n : sKt + (a * NC) * n;
                 if ((n & 1) == 0) {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    typedef R v2r __attribute__((ext_vector_type(2)));
 #pragma unroll 2
                     for (int j = 0; j < n; j += 2) {
-                        const v2d dx2 = *reinterpret_cast<const v2d*>(sdx + j);
+                        const v2r dx2 = *reinterpret_cast<const v2r*>(sdx + j);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
+                            const v2r kr = *reinterpret_cast<const v2r*>(rows + c * n + j);
                             sum[c] += kr.x * dx2.x;
                             sum[c] += kr.y * dx2.y;
                         }
                     }
                 } else {
                     for (int j = 0; j < n; ++j) {
-                        const double dxj = sdx[j];
+                        const R dxj = sdx[j];
 #pragma unroll
                         for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double du = sum[c] + alpha * sdt[a * NC + c];
+                    const R du = sum[c] + alpha * sdt[a * NC + c];
                     ut[c] = ut[c] + du;
                 }
             }
@@ -173,14 +184,14 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
             for (int o = a + 1; o < k; ++o) {
                 const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
                 lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
-                    pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
+                    pair_cost(sxs + a * NS, sxs + o * NS, nd, radius);
             }
             if (Uw) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) Uw[(int64_t)t * m + a * NC + c] = ut[c];
             }
-            double xn[NS];
-            integrate_rt<NS>(model, x, ut, D.dt, xn);
+            R xn[NS];
+            integrate_rt<NS>(model, x, ut, dtr, xn);
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = xn[i];
             if (Xw) {
@@ -192,7 +203,7 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
     {
         // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:91,112)
         const int par = T & 1;
-        double* sxs = lds + O.xs + (par * ngrp + gg) * n;
+        R* sxs = lds + O.xs + (par * ngrp + gg) * n;
         if (active) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) sxs[a * NS + i] = x[i];
@@ -200,31 +211,31 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
         lds_handoff(single_wave);
         if (active) {
             if (a == 0 && T > 0) {
-                const double* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
-                const double* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
-                double prox = 0.0, ref = 0.0;
+                const R* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
+                const R* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
+                R prox = 0.0, ref = 0.0;
                 for (int p = 0; p < npairs; ++p) prox += cp[p];
                 for (int i = 0; i < k; ++i) ref += cr[i];
-                J += D.w_prox * prox + D.w_ref * ref;
+                J += w_prox * prox + w_ref * ref;
             }
-            double uz[NC];
+            R uz[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) uz[c] = 0.0;
             lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, uz, xf, Qfa, Ra, true);
             for (int o = a + 1; o < k; ++o) {
                 const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
                 lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
-                    pair_cost(sxs + a * NS, sxs + o * NS, nd, P.radius);
+                    pair_cost(sxs + a * NS, sxs + o * NS, nd, radius);
             }
         }
         lds_handoff(single_wave);
         if (active && a == 0) {
-            const double* cr = lds + O.cref + (par * ngrp + g) * k;
-            const double* cp = lds + O.cpair + (par * ngrp + g) * np1;
-            double prox = 0.0, ref = 0.0;
+            const R* cr = lds + O.cref + (par * ngrp + g) * k;
+            const R* cp = lds + O.cpair + (par * ngrp + g) * np1;
+            R prox = 0.0, ref = 0.0;
             for (int p = 0; p < npairs; ++p) prox += cp[p];
             for (int i = 0; i < k; ++i) ref += cr[i];
-            J += D.w_prox * prox + D.w_ref * ref;
+            J += w_prox * prox + w_ref * ref;
         }
     }
     lds_handoff(single_wave);
@@ -238,10 +249,11 @@ __device__ double horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, 
 // Workgroup layout: `ipb` sub-problems per workgroup.  When a sub-problem's threads fit one wavefront
 // (n_alpha * k <= 64, e.g. cfg2's 50) four of them share a 256-thread workgroup, one wave each with its own
 // LDS slice and no workgroup barrier -- the same SIMD-placement argument as for the sweep (riccati_tiled.hpp).
-template <int NS, int NC>
-__global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mode, const double* __restrict__ x0, double* X,
-                                                  double* U, const double* __restrict__ K, const double* __restrict__ d,
-                                                  const double* __restrict__ alphas, int ngrp, double* Xc, double* Uc,
+// R: arithmetic type; KDIRECT: K[t] is not staged in LDS (large clusters); lds_per_item in elements of R.
+template <typename R, int NS, int NC, bool KDIRECT>
+__global__ __launch_bounds__(256, KDIRECT ? 1 : 2) void k_forward(dpilqr_batch_desc D, int mode, const R* __restrict__ x0, R* X,
+                                                  R* U, const R* __restrict__ K, const R* __restrict__ d,
+                                                  const double* __restrict__ alphas, int ngrp, R* Xc, R* Uc,
                                                   double* Jc, SolveState S, const int32_t* __restrict__ items,
                                                   const int32_t* __restrict__ n_items, int ipb, int lds_per_item) {
     const int nth = (ipb > 1) ? 64 : (int)blockDim.x;
@@ -254,18 +266,18 @@ __global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mod
     const int g = tid / k, a = tid - g * k;
     const ItemParams P = item_params(D, b);
     const bool homog = homogeneous_ndims(P.n_dims, k);
-    extern __shared__ double lds_all[];
-    double* lds = lds_all + (size_t)sub * lds_per_item;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R* lds = reinterpret_cast<R*>(lds_raw) + (size_t)sub * lds_per_item;
     const bool single_wave = nth <= 64;
-    const ForwardLds O(n, m, k, ngrp);
-    double* Xb = X + (int64_t)b * (T + 1) * n;
-    double* Ub = U + (int64_t)b * T * m;
+    const ForwardLds O(n, m, k, ngrp, KDIRECT);
+    R* Xb = X + (int64_t)b * (T + 1) * n;
+    R* Ub = U + (int64_t)b * T * m;
 
     if (mode == kModeRollout) {
         const bool active = (g == 0);
-        const double J = horizon_pass<NS, NC, false>(D, P, homog, tid, nth, active, 0, a, 1, x0 + (int64_t)b * n, nullptr, Ub,
-                                                     nullptr, nullptr, 0.0, Xb, nullptr, lds);
-        if (active && a == 0) Jc[b] = J;
+        const R J = horizon_pass<R, NS, NC, false, KDIRECT>(D, P, homog, tid, nth, active, 0, a, 1, x0 + (int64_t)b * n,
+                                                            nullptr, Ub, nullptr, nullptr, (R)0.0, Xb, nullptr, lds);
+        if (active && a == 0) Jc[b] = (double)J;
         return;
     }
 
@@ -274,18 +286,18 @@ __global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mod
         return;
     }
     const int64_t gslot = (mode == kModeLineSearch && !S.gains_by_item) ? slot : b;
-    const double* Kb = K + gslot * T * m * n;
-    const double* db = d + gslot * T * m;
+    const R* Kb = K + gslot * T * m * n;
+    const R* db = d + gslot * T * m;
     const bool active = (g < ngrp);
-    const double alpha = active ? alphas[g] : 0.0;
+    const R alpha = active ? (R)alphas[g] : (R)0.0;
     // candidate trajectories: slot of this item in the scratch (solve) or the caller's buffers (API)
     const int64_t cslot = (mode == kModeLineSearch) ? slot : b;
-    double* Xw = active ? Xc + (cslot * ngrp + g) * (int64_t)(T + 1) * n : nullptr;
-    double* Uw = active ? Uc + (cslot * ngrp + g) * (int64_t)T * m : nullptr;
-    const double J = horizon_pass<NS, NC, true>(D, P, homog, tid, nth, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha, Xw, Uw,
-                                                lds);
+    R* Xw = active ? Xc + (cslot * ngrp + g) * (int64_t)(T + 1) * n : nullptr;
+    R* Uw = active ? Uc + (cslot * ngrp + g) * (int64_t)T * m : nullptr;
+    const R J = horizon_pass<R, NS, NC, true, KDIRECT>(D, P, homog, tid, nth, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
+                                                       Xw, Uw, lds);
     if (mode == kModeCandidates) {
-        if (active && a == 0) Jc[(int64_t)b * ngrp + g] = J;
+        if (active && a == 0) Jc[(int64_t)b * ngrp + g] = (double)J;
         return;
     }
 
@@ -299,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mod
         const double J_star = S.J_star[b];
         int acc = -1;
         for (int i = 0; i < ngrp; ++i)
-            if (lds[O.J + i] < J_star) { acc = i; break; }  // strict <, NaN rejects (control.py:183)
+            if ((double)lds[O.J + i] < J_star) { acc = i; break; }  // strict <, NaN rejects (control.py:183)
         const int n_eval = (acc >= 0) ? acc + 1 : ngrp;
-        const double J_last = lds[O.J + n_eval - 1];         // last EVALUATED cost (quirk Q2)
+        const double J_last = (double)lds[O.J + n_eval - 1];  // last EVALUATED cost (quirk Q2)
         const double mu_before = S.mu[b];
         int status = DPILQR_STATUS_ACTIVE;
         double J_new = J_star;
@@ -336,8 +348,8 @@ __global__ __launch_bounds__(256, 2) void k_forward(dpilqr_batch_desc D, int mod
     const int acc = ctl[0];
     if (acc < 0) return;
     // accepted: X, U <- the accepted candidate's trajectory (a coalesced copy out of the scratch)
-    const double* Xa = Xc + (cslot * ngrp + acc) * (int64_t)(T + 1) * n;
-    const double* Ua = Uc + (cslot * ngrp + acc) * (int64_t)T * m;
+    const R* Xa = Xc + (cslot * ngrp + acc) * (int64_t)(T + 1) * n;
+    const R* Ua = Uc + (cslot * ngrp + acc) * (int64_t)T * m;
     for (int e = tid; e < (T + 1) * n; e += nth) Xb[e] = Xa[e];
     for (int e = tid; e < T * m; e += nth) Ub[e] = Ua[e];
 }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "dpilqr_hip.h"
 #include "solve_state.hpp"
@@ -75,5 +76,28 @@ int32_t launch_cost_eval(const dpilqr_batch_desc& D, int32_t n_pts, const double
                          double* cost, hipStream_t st);
 int32_t launch_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X, const double* radius,
                               int32_t* adj, hipStream_t st);
+
+
+// ---- tu_big.hip: large clusters (n_x > 60) in fp64, any size in fp32 (BASELINE config 5's tolerance study)
+int64_t riccati_big_scratch_elems(int n, int m);   // per sub-problem in flight, in elements of the arithmetic type
+int32_t launch_riccati_big_f64(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K,
+                               double* d, int32_t* singular, const int32_t* items, const int32_t* n_items,
+                               int grid_items, int gains_by_item, void* scratch, hipStream_t st);
+int32_t launch_riccati_big_f32(const dpilqr_batch_desc& D, const float* X, const float* U, const double* mu, float* K,
+                               float* d, int32_t* singular, const int32_t* items, const int32_t* n_items,
+                               int grid_items, int gains_by_item, void* scratch, hipStream_t st);
+int32_t launch_forward_big_f64(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
+                               const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
+                               const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
+                               hipStream_t st);
+int32_t launch_forward_big_f32(const dpilqr_batch_desc& D, int mode, const float* x0, float* X, float* U, const float* K,
+                               const float* d, const double* alphas, int ngrp, float* Xc, float* Uc, double* Jc,
+                               const SolveState& S, const int32_t* items, const int32_t* n_items, int grid_items,
+                               hipStream_t st);
+// the sweep's choice: clusters beyond the wavefront / workgroup sweeps (n_x > 60) take the fused big kernel
+inline bool uses_big_path(int n_x) {
+    static const bool force = getenv("DPILQR_FORCE_BIG") != nullptr;   // test / A-B switch: every size through tu_big.hip
+    return force || n_x > 60;
+}
 
 }  // namespace dpilqr

@@ -1,0 +1,502 @@
+// riccati_big.hpp -- K2 for large clusters (n_x > 60, BASELINE config 5: 20 twelve-state agents, n_x = 240, n_u = 80)
+// and for the fp32 arm of config 5's tolerance study: the Riccati backward sweep (ilqrSolver._backward_pass,
+// control.py:116-148) with one workgroup per sub-problem, FUSED with the tile producer.
+//
+// At n_x = 240 nothing of the wavefront / workgroup sweeps' design survives: P alone is 460 KB (LDS: 160 KB), a dense
+// tile record would be 1.28 MB per time step (193 MB per sub-problem pass).  So
+//   * the per-step linearisation and quadraticisation (GameCost.quadraticize cost.py:208-239, MultiDynamicalModel.
+//     linearize dynamics.py:173-186) are evaluated inside the sweep, from (X[t], U[t]) and the batch descriptor: no tile
+//     records exist on this path (SURVEY 8(d) "fused variant": the sweep reads 8 (T+1) n_x + 8 T n_u bytes of
+//     trajectory per pass).  Recognised plugin types only -- the same condition as for dpilqr_solve_batch;
+//   * P, V = Q_xx .. P', [Q_ux | Q_u], [K | d], T3^T and Q_uu live in a per-workgroup scratch in global memory
+//     (1.4 MB at n_x = 240: L2 / Infinity-Cache resident while the workgroup sweeps) and LDS holds the per-agent
+//     [A_i | B_i] blocks, the pair derivatives, the symmetrised weights and the LU of Q_uu;
+//   * A, B are block diagonal (uniform_block_diag, util.py:229-236), so A^T P A, B^T (P + mu I) A, B^T (P + mu I) B are
+//     k^2 small block products (S1); the skipped terms are exact zeros, the association is the reference's
+//     ((A^T P) A);
+//   * Q_uu is factorised in LDS with partial pivoting (dgetf2 order, np.linalg.solve control.py:141-142), the
+//     n_x + 1 right-hand sides are then solved one per thread by blocked substitution (S3);
+//   * the dense products K^T Q_uu K, K^T Q_ux (S4, S5) are 16x16x4 MFMA tiles with operands read straight from the
+//     scratch (rows = reduction index, the MFMA operand order), fp64 or fp32.
+// Arithmetic type R: double (the product) or float (the tolerance study); descriptor data are fp64 and rounded on use.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cost.hpp"
+#include "models.hpp"
+
+namespace dpilqr {
+
+constexpr int kBigThreads = 256;
+
+__host__ __device__ constexpr int big_round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+// 16x16x4 matrix-pipe tile: lane (g = lane / 16, c = lane % 16) supplies A = X[l0 + g][i0 + c], B = Y[l0 + g][j0 + c]
+// and owns four elements of D = X^T Y in column j0 + c; their rows differ between the two instructions.
+template <typename R> struct Mfma;
+template <> struct Mfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mac(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int v, int g) { return g + 4 * v; }    // scripts/ubench/mfma_f64.hip
+};
+template <> struct Mfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mac(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int v, int g) { return 4 * g + v; }
+};
+
+// Scratch of one workgroup in global memory, in elements of R.  Every matrix has the same leading dimension ldw (a
+// multiple of 16 >= n + 1, so that a 16-wide operand tile never leaves its row) and the control-indexed ones have mk
+// rows (m rounded up to the 16-row blocks of the substitution); padding is zeroed once by the host and never written.
+struct BigScratch {
+    int n, m, n1, ldw, mk;
+    int64_t oP, oV, oG, oKd, oT3, oQuu, total;
+    __host__ __device__ BigScratch(int n_, int m_) : n(n_), m(m_) {
+        n1 = n + 1;
+        ldw = big_round_up(n1, 16);
+        mk = big_round_up(m, 16);
+        int64_t o = 0;
+        oP = o;   o += (int64_t)n * ldw;
+        oV = o;   o += (int64_t)n * ldw;
+        oG = o;   o += (int64_t)mk * ldw;
+        oKd = o;  o += (int64_t)mk * ldw;
+        oT3 = o;  o += (int64_t)mk * ldw;
+        oQuu = o; o += (int64_t)mk * mk;
+        total = (o + 31) & ~(int64_t)31;
+    }
+};
+
+struct BigLds {   // offsets in elements of R (all even)
+    int AB, QQ, RR, E, U, G3, H, p, LU, inv, perm, ldlu, total;
+    __host__ __device__ BigLds(int k, int ns, int nc) {
+        const int n = k * ns, m = k * nc, np = k * (k - 1) / 2, mk = big_round_up(m, 16);
+        auto ev = [](int x) { return (x + 1) & ~1; };
+        int o = 0;
+        AB = o;  o += ev(k * ns * (ns + nc));   // per agent, row l: [A_i[l][:] | B_i[l][:]]
+        QQ = o;  o += ev(k * ns * ns);          // w_ref (Q + Q^T) per agent (Q_f for the terminal step)
+        RR = o;  o += ev(k * nc * nc);          // w_ref (R + R^T)
+        E = o;   o += ev(n);                    // x - x_f
+        U = o;   o += ev(m);
+        G3 = o;  o += ev(np * 3);               // pair gradients
+        H = o;   o += ev(np * 9);               // pair Hessians
+        p = o;   o += ev(n);
+        ldlu = mk + 2;
+        LU = o;  o += mk * ldlu;
+        inv = o; o += mk;
+        perm = o; o += 2 * mk + 4;              // int32 perm[mk], piv[mk], flags, in R-sized slots (>= 4 bytes each)
+        total = ev(o);
+    }
+};
+
+template <typename R, int NS, int NC>
+__global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D, const R* __restrict__ X,
+                                                             const R* __restrict__ U, const double* __restrict__ mu_arr,
+                                                             R* __restrict__ Kout, R* __restrict__ dout,
+                                                             int32_t* __restrict__ singular,
+                                                             const int32_t* __restrict__ items,
+                                                             const int32_t* __restrict__ n_items, int gains_by_item,
+                                                             R* scratch_all) {
+    typedef typename Mfma<R>::acc_t acc_t;
+    constexpr int NSC = NS + NC;
+    const int slot = blockIdx.x;
+    if (n_items && slot >= *n_items) return;
+    const int b = items ? items[slot] : slot;
+    if (b >= D.B) return;
+    const int64_t gslot = gains_by_item ? b : slot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g16 = lane >> 4, c16 = lane & 15;
+    const int k = D.k, T = D.T, n = k * NS, m = k * NC, npairs = k * (k - 1) / 2;
+    const BigScratch S(n, m);
+    const BigLds O(k, NS, NC);
+    const int n1 = S.n1, ldw = S.ldw, mk = S.mk, ldlu = O.ldlu;
+    const ItemParams P = item_params(D, b);
+    const R mu = (R)mu_arr[b], wr = (R)D.w_ref, wp = (R)D.w_prox, radius = (R)P.radius, dt = (R)D.dt;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R* lds = reinterpret_cast<R*>(lds_raw);
+    R* sAB = lds + O.AB; R* sQQ = lds + O.QQ; R* sRR = lds + O.RR; R* sE = lds + O.E; R* sU = lds + O.U;
+    R* sG3 = lds + O.G3; R* sH = lds + O.H; R* sp = lds + O.p; R* sLU = lds + O.LU; R* sInv = lds + O.inv;
+    int* sPerm = reinterpret_cast<int*>(lds + O.perm);
+    int* sPiv = sPerm + mk;
+    int* sFlag = sPiv + mk;      // [0]: singular, [1]: pivot row of the current column
+
+    R* gP = scratch_all + (int64_t)slot * S.total + S.oP;
+    R* gV = scratch_all + (int64_t)slot * S.total + S.oV;
+    R* gG = scratch_all + (int64_t)slot * S.total + S.oG;
+    R* gKd = scratch_all + (int64_t)slot * S.total + S.oKd;
+    R* gT3 = scratch_all + (int64_t)slot * S.total + S.oT3;
+    R* gQuu = scratch_all + (int64_t)slot * S.total + S.oQuu;
+    const R* Xb = X + (int64_t)b * (T + 1) * n;
+    const R* Ub = U + (int64_t)b * T * m;
+
+    // ---- once per pass: w_ref (R + R^T); the LU buffer's padding is the identity
+    for (int e = tid; e < k * NC * NC; e += kBigThreads) {
+        const int a = e / (NC * NC), r = e - a * NC * NC, li = r / NC, lj = r - li * NC;
+        const double* Rm = P.R + a * NC * NC;
+        sRR[e] = wr * ((R)Rm[li * NC + lj] + (R)Rm[lj * NC + li]);
+    }
+    for (int e = tid; e < mk * ldlu; e += kBigThreads) {
+        const int r = e / ldlu, c = e - r * ldlu;
+        sLU[e] = (r == c && r >= m) ? (R)1.0 : (R)0.0;
+    }
+    if (tid < 2) sFlag[tid] = 0;
+
+    // per-step plugin evaluation at (x, u) of step t: linearisation, x - x_f, pair derivatives, weights
+    auto stage_step = [&](int t, bool terminal) {
+        const R* xt = Xb + (int64_t)t * n;
+        const R* ut = Ub + (int64_t)(terminal ? 0 : t) * m;
+        for (int a = tid; a < k; a += kBigThreads) {
+            R x[NS], u[NC], A[NS * NS], Bm[NS * NC];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) x[i] = xt[a * NS + i];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) u[i] = terminal ? (R)0.0 : ut[a * NC + i];
+            if (!terminal) {
+                linearize_rt<NS>(P.model[a], x, u, dt, A, Bm);
+#pragma unroll
+                for (int l = 0; l < NS; ++l) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) sAB[(a * NS + l) * NSC + i] = A[l * NS + i];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) sAB[(a * NS + l) * NSC + NS + i] = Bm[l * NC + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) sE[a * NS + i] = x[i] - (R)P.xf[a * NS + i];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) sU[a * NC + i] = u[i];
+        }
+        for (int p = tid; p < npairs; p += kBigThreads) {   // pairs in itertools.combinations order
+            int i = 0, rem = p;
+            while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+            const int j = i + 1 + rem;
+            const int nd = min(P.n_dims[i], P.n_dims[j]);  // cost.py:145
+            R gg[3], HH[9];
+            pair_quadraticize(xt + i * NS, xt + j * NS, nd, radius, gg, HH);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sG3[p * 3 + c] = gg[c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sH[p * 9 + c] = HH[c];
+        }
+        if (t == T || t == T - 1) {   // the weights change once: Q_f for the terminal record, Q for all others
+            for (int e = tid; e < k * NS * NS; e += kBigThreads) {
+                const int a = e / (NS * NS), r = e - a * NS * NS, li = r / NS, lj = r - li * NS;
+                const double* M = (terminal ? P.Qf : P.Q) + a * NS * NS;
+                sQQ[e] = wr * ((R)M[li * NS + lj] + (R)M[lj * NS + li]);
+            }
+        }
+    };
+    // L_xx[gi][gj], L_x[gi] of the staged step (cost.py:228-237, 160-169; same association as tiles.hpp)
+    auto lxx = [&](int ai, int li, int aj, int lj) -> R {
+        R v = 0.0;
+        if (ai == aj) v = sQQ[ai * NS * NS + li * NS + lj];
+        if (k > 1 && li < 3 && lj < 3) {
+            R acc = 0.0;
+            if (ai == aj) {
+                for (int o = 0; o < k; ++o) {
+                    if (o == ai) continue;
+                    const int p = (o < ai) ? pair_index(o, ai, k) : pair_index(ai, o, k);
+                    acc += sH[p * 9 + li * 3 + lj];
+                }
+            } else {
+                const int p = (ai < aj) ? pair_index(ai, aj, k) : pair_index(aj, ai, k);
+                acc += -sH[p * 9 + li * 3 + lj];
+            }
+            v += wp * acc;
+        }
+        return v;
+    };
+    auto lx = [&](int a, int lj) -> R {
+        R v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v += sE[a * NS + i] * sQQ[a * NS * NS + i * NS + lj];
+        if (k > 1 && lj < 3) {
+            R acc = 0.0;
+            for (int o = 0; o < k; ++o) {
+                if (o == a) continue;
+                if (o < a) acc += -sG3[pair_index(o, a, k) * 3 + lj];
+                else       acc += sG3[pair_index(a, o, k) * 3 + lj];
+            }
+            v += wp * acc;
+        }
+        return v;
+    };
+
+    // ---- terminal condition: p = l_x(T), P = l_xx(T)   (control.py:125-129)
+    __syncthreads();
+    stage_step(T, true);
+    __syncthreads();
+    for (int e = tid; e < n * n; e += kBigThreads) {
+        const int i = e / n, j = e - i * n;
+        gP[(int64_t)i * ldw + j] = lxx(i / NS, i % NS, j / NS, j % NS);
+    }
+    for (int i = tid; i < n; i += kBigThreads) sp[i] = lx(i / NS, i % NS);
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        stage_step(t, false);
+        __syncthreads();
+
+        // ---- S1: the block products.  Work item (ai, aj, r): row r of [A_ai | B_ai]^T P_(ai,aj) (NS terms), then times
+        // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).
+        for (int w = tid; w < k * k * NSC; w += kBigThreads) {
+            const int blk = w / NSC, r = w - blk * NSC, ai = blk / k, aj = blk - ai * k;
+            R Tr[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) Tr[j] = 0.0;
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                const R ab = sAB[(ai * NS + l) * NSC + r];
+                const R* Prow = gP + (int64_t)(ai * NS + l) * ldw + aj * NS;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) Tr[j] = fma(ab, Prow[j], Tr[j]);
+            }
+            if (r >= NS && ai == aj) {   // B^T (P + mu I) = B^T P + mu B^T   (quirk Q6)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) Tr[j] = fma(mu, sAB[(ai * NS + j) * NSC + r], Tr[j]);
+            }
+            if (r < NS) {
+                R* out = gV + (int64_t)(ai * NS + r) * ldw + aj * NS;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    R s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + c], s);
+                    out[c] = lxx(ai, r, aj, c) + s;
+                }
+            } else {
+                const int a = ai * NC + (r - NS);
+                R* out = gG + (int64_t)a * ldw + aj * NS;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    R s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + c], s);
+                    out[c] = s;                                   // l_ux = 0 (cost.py:93,231)
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    R s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + NS + c], s);
+                    const R q = ((ai == aj) ? sRR[ai * NC * NC + (r - NS) * NC + c] : (R)0.0) + s;
+                    gQuu[(int64_t)a * mk + aj * NC + c] = q;
+                    sLU[a * ldlu + aj * NC + c] = q;
+                }
+            }
+        }
+        // Q_x = l_x + A^T p -> column n of V ; Q_u = l_u + B^T p -> column n of [Q_ux | Q_u]
+        for (int i = tid; i < n + m; i += kBigThreads) {
+            R s = 0.0;
+            if (i < n) {
+                const int a = i / NS, li = i - a * NS;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) s = fma(sAB[(a * NS + l) * NSC + li], sp[a * NS + l], s);
+                gV[(int64_t)i * ldw + n] = lx(a, li) + s;
+            } else {
+                const int ia = i - n, a = ia / NC, lc = ia - a * NC;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) s = fma(sAB[(a * NS + l) * NSC + NS + lc], sp[a * NS + l], s);
+                R lu = 0.0;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) lu += sU[a * NC + q] * sRR[a * NC * NC + q * NC + lc];
+                gG[(int64_t)ia * ldw + n] = lu + s;
+            }
+        }
+        __syncthreads();
+
+        // ---- S3a: LU of Q_uu in LDS, partial pivoting (dgetf2: first row of largest magnitude)
+        for (int kk = 0; kk < m; ++kk) {
+            if (wave == 0) {
+                // wave-wide pivot search: lane-strided scan, then a butterfly that keeps the smaller row on ties
+                R best = -1.0;
+                int piv = kk;
+                for (int r = kk + lane; r < m; r += 64) {
+                    const R v = fabs(sLU[r * ldlu + kk]);
+                    if (v > best) { best = v; piv = r; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const R ob = __shfl_xor(best, off);
+                    const int op = __shfl_xor(piv, off);
+                    if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+                }
+                if (lane == 0) {
+                    sPiv[kk] = piv;
+                    sFlag[1] = piv;
+                    const R pv = sLU[piv * ldlu + kk];
+                    if (!(best > (R)0.0)) sFlag[0] = 1;            // zero (or NaN) pivot: np.linalg.solve would raise
+                    sInv[kk] = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                }
+            }
+            __syncthreads();
+            const int piv = sFlag[1];
+            if (piv != kk) {
+                for (int c = tid; c < m; c += kBigThreads) {
+                    const R a0 = sLU[kk * ldlu + c];
+                    sLU[kk * ldlu + c] = sLU[piv * ldlu + c];
+                    sLU[piv * ldlu + c] = a0;
+                }
+                __syncthreads();
+            }
+            const R inv = sInv[kk];
+            const int rem = m - kk - 1;
+            for (int e = tid; e < rem * rem; e += kBigThreads) {
+                const int r = kk + 1 + e / rem, c = kk + 1 + e % rem;
+                const R l = sLU[r * ldlu + kk] * inv;
+                sLU[r * ldlu + c] = fma(-l, sLU[kk * ldlu + c], sLU[r * ldlu + c]);
+            }
+            __syncthreads();
+        }
+        // multipliers l = a / pivot in place (exactly the values the elimination used); row order of the right-hand sides
+        for (int e = tid; e < m * m; e += kBigThreads) {
+            const int r = e / m, c = e - r * m;
+            if (r > c) sLU[r * ldlu + c] *= sInv[c];
+        }
+        if (tid == 0) {
+            for (int r = 0; r < mk; ++r) sPerm[r] = r;
+            for (int kk = 0; kk < m; ++kk) {
+                const int pv = sPiv[kk];
+                const int a0 = sPerm[kk]; sPerm[kk] = sPerm[pv]; sPerm[pv] = a0;
+            }
+        }
+        __syncthreads();
+
+        // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u]: one right-hand side per thread, substitution in blocks of 16 rows
+        // (solved blocks go through the scratch; a row of 16 threads' values is one coalesced access)
+        const int nb = mk / 16;
+        for (int j = tid; j < n1; j += kBigThreads) {
+            for (int I = 0; I < nb; ++I) {                       // L y = P b
+                R y[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 16 * I + i;
+                    y[i] = (r < m) ? gG[(int64_t)sPerm[r] * ldw + j] : (R)0.0;
+                }
+                for (int J = 0; J < I; ++J) {
+                    R yj[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) yj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const R* Lr = sLU + (16 * I + i) * ldlu + 16 * J;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) y[i] = fma(-Lr[c], yj[c], y[i]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+#pragma unroll
+                    for (int i = c + 1; i < 16; ++i) y[i] = fma(-sLU[(16 * I + i) * ldlu + 16 * I + c], y[c], y[i]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gKd[(int64_t)(16 * I + i) * ldw + j] = y[i];
+            }
+            for (int I = nb - 1; I >= 0; --I) {                  // U x = y ; [K | d] = -x
+                R y[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i] = gKd[(int64_t)(16 * I + i) * ldw + j];
+                for (int J = nb - 1; J > I; --J) {
+                    R xj[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) xj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const R* Ur = sLU + (16 * I + i) * ldlu + 16 * J;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) y[i] = fma(Ur[c], xj[c], y[i]);   // xj holds -x
+                    }
+                }
+#pragma unroll
+                for (int i = 15; i >= 0; --i) {
+                    R s = y[i];
+#pragma unroll
+                    for (int c = i + 1; c < 16; ++c) s = fma(sLU[(16 * I + i) * ldlu + 16 * I + c], y[c], s);
+                    y[i] = -(s / sLU[(16 * I + i) * ldlu + 16 * I + i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int a = 16 * I + i;
+                    if (a < m) {
+                        gKd[(int64_t)a * ldw + j] = y[i];
+                        if (j < n) Kout[((gslot * T + t) * m + a) * (int64_t)n + j] = y[i];
+                        else dout[(gslot * T + t) * m + a] = y[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // restore the LU buffer's identity padding is not needed: rows / columns >= m are never touched
+
+        // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]   (K^T Q_uu, associated as the reference's K.T @ Q_uu @ K)
+        {
+            const int ti_n = (m + 15) / 16, tj_n = (n + 15) / 16, tj2 = (tj_n + 1) / 2;
+            for (int job = wave; job < ti_n * tj2; job += kBigThreads / 64) {
+                const int it = job / tj2, jt0 = 2 * (job - it * tj2);
+                acc_t acc[2];
+                acc[0] = acc_t{0, 0, 0, 0}; acc[1] = acc_t{0, 0, 0, 0};
+                const int jt1 = min(jt0 + 1, tj_n - 1);
+                // second tile clamped to a valid column block when tj_n is odd (its result is then not stored)
+                const R* px = gQuu + (int64_t)g16 * mk + 16 * it + c16;
+                const R* py = gKd + (int64_t)g16 * ldw + 16 * jt0 + c16;
+                {
+                    for (int ks = 0; ks < mk; ks += 4) {
+                        const R a = px[(int64_t)ks * mk];
+                        const R b0 = py[(int64_t)ks * ldw], b1 = py[(int64_t)ks * ldw + 16 * (jt1 - jt0)];
+                        acc[0] = Mfma<R>::mac(a, b0, acc[0]);
+                        acc[1] = Mfma<R>::mac(a, b1, acc[1]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && jt0 + 1 >= tj_n) break;
+                    const int col = 16 * (jt0 + q) + c16;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * it + Mfma<R>::row(v, g16);
+                        if (row < m && col < n) gT3[(int64_t)row * ldw + col] = acc[q][v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- S5: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T   rows < n, columns <= n
+        {
+            const int ti_n = (n + 15) / 16, tj_n = (n1 + 15) / 16;
+            for (int job = wave; job < ti_n * tj_n; job += kBigThreads / 64) {
+                const int it = job / tj_n, jt = job - it * tj_n;
+                acc_t a1 = acc_t{0, 0, 0, 0}, a2 = acc_t{0, 0, 0, 0}, a2t = acc_t{0, 0, 0, 0};
+                const int64_t xo = (int64_t)g16 * ldw + 16 * it + c16, yo = (int64_t)g16 * ldw + 16 * jt + c16;
+                for (int ks = 0; ks < mk; ks += 4) {
+                    const int64_t ro = (int64_t)ks * ldw;
+                    const R t3i = gT3[ro + xo], kdi = gKd[ro + xo], gi = gG[ro + xo];
+                    const R kdj = gKd[ro + yo], gj = gG[ro + yo];
+                    a1 = Mfma<R>::mac(t3i, kdj, a1);
+                    a2 = Mfma<R>::mac(kdi, gj, a2);
+                    a2t = Mfma<R>::mac(gi, kdj, a2t);
+                }
+                const int col = 16 * jt + c16;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * it + Mfma<R>::row(v, g16);
+                    if (row < n && col <= n) {
+                        R* pv = gV + (int64_t)row * ldw + col;
+                        *pv = ((*pv + a1[v]) + a2[v]) + a2t[v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- S6: P <- (V + V^T) / 2 ; p <- V[:, n]
+        for (int e = tid; e < n * n; e += kBigThreads) {
+            const int i = e / n, j = e - i * n;
+            gP[(int64_t)i * ldw + j] = (R)0.5 * (gV[(int64_t)i * ldw + j] + gV[(int64_t)j * ldw + i]);
+        }
+        for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+        __syncthreads();
+    }
+    if (singular && tid == 0 && sFlag[0]) singular[b] = 1;
+}
+
+}  // namespace dpilqr

@@ -26,8 +26,9 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     int threads = forward_threads(D.k, mode == kModeRollout ? 1 : ngrp);
     if (threads > 256) return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * ngrp);
     const size_t lds_item = (forward_lds_bytes(n, m, D.k, ngrp) + 15) & ~(size_t)15;
-    if (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage)
-        return fail(DPILQR_EUNSUPPORTED, "n_u*n_x=%d exceeds the forward pass's per-step staging (%d threads x %d)", m * n, threads, kMaxStage);
+    // large clusters: K[t] does not fit the per-step LDS staging -- the variant that reads it from global memory (tu_big.hip)
+    if (uses_big_path(n) || lds_item > (size_t)kMaxLds || (mode != kModeRollout && (m * n + threads - 1) / threads > kMaxStage))
+        return launch_forward_big_f64(D, mode, x0, X, U, K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, grid_items, st);
     if (!no_wave_ro() && mode == kModeRollout && hint_model(D) >= 0 && !items) {
         const int model = hint_model(D);
 #define DPILQR_TRY_RO(MODEL, KA)                                                                                    \
@@ -104,10 +105,10 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     const size_t lds = lds_item * ipb;
     threads *= ipb;
     DISPATCH_FAMILY(D.n_s, {
-        int32_t rc = allow_lds(k_forward<NS, NC>, lds);
+        int32_t rc = allow_lds(k_forward<double, NS, NC, false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_forward<NS, NC>), dim3((grid_items + ipb - 1) / ipb), dim3(threads), lds, st, D, mode, x0, X, U,
-                           K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, ipb, (int)(lds_item / sizeof(double)));
+        hipLaunchKernelGGL((k_forward<double, NS, NC, false>), dim3((grid_items + ipb - 1) / ipb), dim3(threads), lds, st, D, mode,
+                           x0, X, U, K, d, alphas, ngrp, Xc, Uc, Jc, S, items, n_items, ipb, (int)(lds_item / sizeof(double)));
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;

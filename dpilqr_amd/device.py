@@ -22,8 +22,8 @@ def to_dev(a, dtype=torch.float64):
     """Host array -> contiguous device tensor."""
     if isinstance(a, torch.Tensor):
         return a.to(device=device(), dtype=dtype).contiguous()
-    np_dtype = np.float64 if dtype == torch.float64 else np.int32
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(device())
+    np_dtype = {torch.float64: np.float64, torch.float32: np.float32}.get(dtype, np.int32)
+    return torch.from_numpy(np.array(a, dtype=np_dtype, order="C", copy=True)).to(device())
 
 
 def empty(shape, dtype=torch.float64):

@@ -13,12 +13,15 @@
  *     negative DPILQR_E* code and never throws or aborts; dpilqr_last_error() holds the message of
  *     the calling thread's last failure.
  *   - every data pointer is a DEVICE pointer owned by the caller (torch.Tensor.data_ptr()); nothing is
- *     allocated behind the caller's back except one small pinned host mailbox used by
- *     dpilqr_solve_batch (allocated once per process).  Workspace sizes come from *_workspace_bytes.
+ *     allocated behind the caller's back.  Workspace sizes come from *_workspace_bytes.  The one piece of
+ *     host-side state -- the pinned mailbox and events through which the synchronous solve follows the device --
+ *     is an explicit object, dpilqr_solver_create / dpilqr_solver_destroy.
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); 0 = null stream.
- *     Launch-only entry points never synchronise; dpilqr_solve_batch synchronises on `stream` because
- *     the number of iLQR iterations is data dependent.
- *   - all real data is IEEE fp64, row-major, C-contiguous; integer arrays are int32.
+ *     Every entry point only ENQUEUES work on `stream` and returns, with one exception: dpilqr_solve_batch[_f32]
+ *     returns when the solve has finished (the number of iLQR iterations is data dependent and it stops launching
+ *     as soon as the device reports that nothing is left).  dpilqr_solve_enqueue is the same solve as pure enqueue.
+ *   - all real data is IEEE fp64, row-major, C-contiguous; integer arrays are int32.  The *_f32 entry points are the
+ *     fp32 arm of BASELINE config 5's tolerance study: same semantics, trajectories and gains in float.
  *   - a "batch" is B independent sub-problems of identical shape: k agents x (n_s states, n_c controls),
  *     horizon T.  Joint dims n_x = k*n_s, n_u = k*n_c.  The reference assumes the same uniformity
  *     (dynamics.py:165-166, util.py:97-109).
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPILQR_ABI_VERSION 1
+#define DPILQR_ABI_VERSION 2
 
 /* error codes */
 #define DPILQR_OK 0
@@ -155,7 +158,10 @@ int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int
                                           int32_t block_nc, const double* tiles, const double* mu, double* K,
                                           double* d, int32_t* singular, const int32_t* items,
                                           const int32_t* n_items, void* stream);
-/* convenience: make_tiles + backward_pass_tiles for recognised plugins; workspace = tile buffer      */
+/* convenience: make_tiles + backward_pass_tiles for recognised plugins; workspace = tile buffer
+ * (dpilqr_tiles_bytes always suffices; dpilqr_backward_pass_workspace_bytes(desc, 8) is exact).  Clusters with
+ * n_x > 60 take the fused sweep of the large-cluster path: it evaluates linearize / quadraticize per step inside the
+ * sweep and uses the workspace as its scratch, no tile records exist there (a record would be 1.28 MB at n_x = 240). */
 int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u);
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
                              double* K, double* d, double* tiles_workspace, void* stream);
@@ -184,10 +190,48 @@ int32_t dpilqr_alphas(double* alphas_host);
  *   Hand the solver the whole Monte-Carlo batch and let `window` bound the memory.
  * workspace: dpilqr_solve_workspace_bytes(desc, window, K_out == NULL) bytes of device memory.           */
 int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
-int32_t dpilqr_solve_batch(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter,
-                           double tol, int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
-                           int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
-                           double* d_out, void* stream);
+/* Host-side state of the synchronous solve: a pinned mailbox (a few words the device posts its active-list counters
+ * into), the events that tell the host when a post has landed, and the optional profiler.  Bound to the device that is
+ * current at creation; one solver serves one solve at a time (use one per host thread / stream).  solver == NULL in
+ * dpilqr_solve_batch selects a per-thread default that is created on first use -- a convenience for scripts; a caller
+ * that must not see an allocation inside a solve creates its solver up front. */
+typedef struct dpilqr_solver dpilqr_solver;
+int32_t dpilqr_solver_create(dpilqr_solver** out);
+int32_t dpilqr_solver_destroy(dpilqr_solver* solver);
+/* Synchronous, adaptive: launches iterations until the device reports that every item has finished (it follows the
+ * device's counters a few iterations late, so launches are always queued ahead), then waits for `stream`. */
+int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const double* x0, double* U,
+                           int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                           double* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
+                           double* K_out, double* d_out, void* stream);
+/* Enqueue-only: no host-side state, no allocation, no host read, no synchronisation -- it can be queued behind other
+ * work, overlapped with another solve on another stream, or captured in a hipGraph.  Exactly n_global_iter global
+ * iterations (backward pass + line search over the active list) are launched with window-wide grids; launches that
+ * find the active list empty exit at once.  Whether everything finished is for the caller to read from `status`
+ * (DPILQR_STATUS_ACTIVE = not yet); dpilqr_solve_iterations_bound gives the n_global_iter that always suffices, a
+ * smaller number plus a second call with resume = 1 (same arguments, same workspace) continues where the first
+ * stopped.  resume = 0 initialises the solver state and rolls out (x0, U); J, X, U, status ... hold the state reached. */
+int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
+                             int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
+                             int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
+                             double* d_out, int32_t n_global_iter, int32_t resume, void* stream);
+int64_t dpilqr_solve_iterations_bound(const dpilqr_batch_desc* desc, int32_t window, int32_t n_lqr_iter);
+
+/* -------------------------------------------------- (5b) the fp32 arm (BASELINE config 5: fp32 vs fp64 tolerance study)
+ * Same passes and the same solve with trajectories, gains and every intermediate in float (the descriptor stays fp64
+ * and is rounded on use; costs J, the regularisation state and the decision trace are reported in double).  They run
+ * on the size-generic kernels of the large-cluster path for every shape. */
+int32_t dpilqr_rollout_f32(const dpilqr_batch_desc* desc, const float* x0, const float* U, float* X, double* J, void* stream);
+int64_t dpilqr_backward_pass_workspace_bytes(const dpilqr_batch_desc* desc, int32_t elem_bytes /* 8: dpilqr_backward_pass, 4: _f32 */);
+int32_t dpilqr_backward_pass_f32(const dpilqr_batch_desc* desc, const float* X, const float* U, const double* mu, float* K,
+                                 float* d, void* workspace, void* stream);
+int32_t dpilqr_forward_pass_f32(const dpilqr_batch_desc* desc, const float* X, const float* U, const float* K, const float* d,
+                                const double* alphas, int32_t n_alpha, float* Xn, float* Un, double* Jn, void* stream);
+int64_t dpilqr_solve_workspace_bytes_f32(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
+int32_t dpilqr_solve_batch_f32(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const float* x0, float* U,
+                               int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                               float* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
+                               float* K_out, float* d_out, void* stream);
 
 /* -------------------------------------------------- measurement hooks (bench.py's roofline leg)
  * When enabled, dpilqr_solve_batch brackets every kernel launch of its iteration loop with HIP events
