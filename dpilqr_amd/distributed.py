@@ -22,10 +22,13 @@ def define_inter_graph_threshold(X, radius, x_dims, ids):
     step = max(n_rows // 10, 1)                      # ~10 samples over the trajectory
     near = compute_pairwise_distance(X, x_dims)[0:n_rows + 1:step] < 2 * radius
     graph = {id_: [id_] for id_ in ids}
-    for col, (a, b) in enumerate(itertools.combinations(ids, 2)):
+    # like the reference (distributed.py:240-246, quirk Q10) the neighbours come out of a NumPy array of id pairs, i.e.
+    # as NumPy integers next to the agent's own Python int: they compare and hash like ints, but they print differently
+    # inside the `subgraphs` field of solve_rhc's CSV rows, which is reproduced byte for byte
+    for col, (a, b) in enumerate(np.array(list(itertools.combinations(ids, 2))).reshape(-1, 2)):
         if near[:, col].any():
-            graph[a].append(b)
-            graph[b].append(a)
+            graph[int(a)].append(b)
+            graph[int(b)].append(a)
     return {id_: sorted(members) for id_, members in graph.items()}
 
 
@@ -72,6 +75,13 @@ def solve_centralized(solver, xi, U, ids, verbose, **kwargs):
     return X, U, J, {id_: (dt, ids) for id_ in ids}
 
 
+def rhc_log_row(model_name, n_agents, i_trial, centralized, last, t, J, N, dt, converged, ids, times, subgraphs, left):
+    """One CSV row of solve_rhc's log, in the format of distributed.py:190-194 / :215-219 (header: analysis.py:120-123):
+    dynamics,n_agents,trial,centralized,last,t,J,horizon,dt,converged,ids,times,subgraphs,dist_left."""
+    return (f'"{model_name}",{n_agents},{i_trial},{centralized},{last},{t},{J},{N},{dt},{converged},"{ids}",'
+            f'"{times}","{subgraphs}","{left}"')
+
+
 def solve_rhc(problem, x0, N, *args, centralized=True, n_d=2, step_size=1, J_converge=None, dist_converge=None,
               t_diverge=None, i_trial=None, verbose=False, **kwargs):
     """Receding-horizon loop around solve_centralized / solve_distributed (distributed.py:106-221); logs the
@@ -108,8 +118,8 @@ def solve_rhc(problem, x0, N, *args, centralized=True, n_d=2, step_size=1, J_con
         U = np.r_[U[step_size:], np.zeros((step_size, n_u))]
         times = [v[0] for v in info.values()]; subgraphs = [v[1] for v in info.values()]
         left = distance_to_goal(xi).tolist()
-        logging.info(f'"{model_name}",{n_agents},{i_trial},{centralized},{False},{t},{J},{N},{dt},{converged},"{ids}",'
-                     f'"{times}","{subgraphs}","{left}"')
+        logging.info(rhc_log_row(model_name, n_agents, i_trial, centralized, False, t, J, N, dt, converged, ids, times,
+                                 subgraphs, left))
         if t_diverge and t >= t_diverge:
             converged = False
             break
@@ -117,8 +127,8 @@ def solve_rhc(problem, x0, N, *args, centralized=True, n_d=2, step_size=1, J_con
     if not X_full.size and not U_full.size:
         X_full = np.asarray(x0, dtype=np.float64).copy(); U_full = np.zeros((1, n_u))
     _, J_full = ilqrSolver(problem, U_full.shape[0])._rollout(np.asarray(x0, dtype=np.float64), U_full)
-    logging.info(f'"{model_name}",{n_agents},{i_trial},{centralized},{True},{U_full.shape[0] * dt},{J_full},{N},{dt},'
-                 f'{converged},"{ids}","{times}","{subgraphs}","{left}"')
+    logging.info(rhc_log_row(model_name, n_agents, i_trial, centralized, True, U_full.shape[0] * dt, J_full, N, dt, converged,
+                             ids, times, subgraphs, left))
     return X_full, U_full, J_full
 
 

@@ -731,6 +731,14 @@ int oracle_solve_batch(const oracle_problem *proto, int B, const double *x0, con
                        int n_lqr_iter, double tol, double *X, double *J, int *status, int *n_bwd,
                        int *n_fwd, int n_threads)
 {
+    return oracle_solve_batch_trace(proto, B, x0, xf, U, n_lqr_iter, tol, X, J, status, n_bwd, n_fwd, n_threads, NULL);
+}
+
+/* the same with the per-iteration decision trace of every item: trace[B][n_lqr_iter][5] (may be NULL) */
+int oracle_solve_batch_trace(const oracle_problem *proto, int B, const double *x0, const double *xf, double *U,
+                             int n_lqr_iter, double tol, double *X, double *J, int *status, int *n_bwd,
+                             int *n_fwd, int n_threads, double *trace)
+{
     const int n = proto->k * proto->n_s, m = proto->k * proto->n_c, T = proto->T;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -742,7 +750,8 @@ int oracle_solve_batch(const oracle_problem *proto, int B, const double *x0, con
         oracle_problem q = *proto;
         q.xf = xf + (size_t)b * n;
         status[b] = oracle_solve(&q, x0 + (size_t)b * n, U + (size_t)b * T * m, n_lqr_iter, tol,
-                                 X + (size_t)b * (T + 1) * n, J + b, NULL, n_bwd + b, n_fwd + b);
+                                 X + (size_t)b * (T + 1) * n, J + b,
+                                 trace ? trace + (size_t)b * (n_lqr_iter > 0 ? n_lqr_iter : 1) * 5 : NULL, n_bwd + b, n_fwd + b);
     }
     return 0;
 }

@@ -101,6 +101,9 @@ int oracle_solve(const oracle_problem *p, const double *x0, double *U, int n_lqr
 int oracle_solve_batch(const oracle_problem *proto, int B, const double *x0, const double *xf,
                        double *U, int n_lqr_iter, double tol, double *X, double *J,
                        int *status, int *n_bwd, int *n_fwd, int n_threads);
+int oracle_solve_batch_trace(const oracle_problem *proto, int B, const double *x0, const double *xf, double *U,
+                             int n_lqr_iter, double tol, double *X, double *J, int *status, int *n_bwd,
+                             int *n_fwd, int n_threads, double *trace /* [B][max(n_lqr_iter,1)][5] or NULL */);
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -232,16 +232,27 @@ def backward_pass_tiles(A, B, Lx, Lu, Lxx, Luu, Lux, mu):
     return K, d
 
 
-def solve_batch(proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0):
-    """B independent problems that differ in (x0, xf) only; OpenMP over the batch."""
+def solve_batch(proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, trace=False):
+    """B independent problems that differ in (x0, xf) only; OpenMP over the batch.
+    trace=True adds the decision trace (B, n_lqr_iter, 5) = (mu_before, accepted alpha index or -1, J_last, J_star_after,
+    n_forward_passes), NaN beyond each item's last iteration."""
     x0, xf = _f64(x0), _f64(xf); U = _f64(U0).copy()
     Bn = x0.shape[0]
     X = np.zeros((Bn, proto.T + 1, proto.n_x)); J = np.zeros(Bn)
     st = np.zeros(Bn, dtype=np.int32); nb = np.zeros(Bn, dtype=np.int32); nf = np.zeros(Bn, dtype=np.int32)
     ip = lambda a: a.ctypes.data_as(c_ip)
-    lib().oracle_solve_batch(proto.ptr, Bn, _p(x0), _p(xf), _p(U), n_lqr_iter, tol, _p(X), _p(J), ip(st), ip(nb),
-                             ip(nf), int(n_threads))
-    return dict(X=X, U=U, J=J, status=st, n_bwd=nb, n_fwd=nf)
+    tr = np.full((Bn, max(n_lqr_iter, 1), 5), np.nan) if trace else None
+    L = lib()
+    L.oracle_solve_batch_trace.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp,
+                                           c_ip, c_ip, c_ip, C.c_int, c_dp]
+    L.oracle_solve_batch_trace(proto.ptr, Bn, _p(x0), _p(xf), _p(U), n_lqr_iter, tol, _p(X), _p(J), ip(st), ip(nb),
+                               ip(nf), int(n_threads), _p(tr) if trace else None)
+    out = dict(X=X, U=U, J=J, status=st, n_bwd=nb, n_fwd=nf)
+    if trace:
+        for i in range(Bn):
+            tr[i, nb[i]:] = np.nan
+        out["trace"] = tr
+    return out
 
 
 def max_threads():

@@ -347,3 +347,80 @@ def test_solve_workspaces_are_pooled(dp):
     assert len(pool._free) == 2
     dp.release_workspaces()
     assert len(pool._free) == 0
+
+
+# ---------------------------------------------------------------- G7: the callers, pinned to the reference
+class _Rows(__import__("logging").Handler):
+    def __init__(self):
+        super().__init__()
+        self.rows = []
+
+    def emit(self, record):
+        self.rows.append(record.getMessage())
+
+
+@pytest.mark.parametrize("tag", ["rhc_c", "rhc_c2", "rhc_d"])
+def test_solve_rhc_vs_reference(dp, golden, tag):
+    """solve_rhc (distributed.py:106-221), centralized and distributed branch, against the reference's own run: the
+    executed trajectory, the final cost and every logged CSV row (fields that are not wall-clock times: exact for the
+    discrete ones, 1e-6 for the floats; the row FORMAT is checked byte for byte in test_host_logic.py)."""
+    import logging
+    from tests.test_host_logic import _parse_row
+    z = golden("g7_callers")
+    prob = problem_from(z, tag + "_")
+    N = int(z[tag + "_N"]); centralized = bool(z[tag + "_centralized"])
+    kw = dict(step_size=int(z[tag + "_kw_step_size"]), dist_converge=float(z[tag + "_kw_dist_converge"]),
+              t_diverge=float(z[tag + "_kw_t_diverge"]))
+    np.random.seed(int(z[tag + "_np_seed"]))                      # solve_rhc draws its warm start from the global RNG (:152)
+    log = logging.getLogger(); old = log.level; log.setLevel(logging.INFO)
+    h = _Rows(); log.addHandler(h)
+    try:
+        args = () if centralized else (0.5, [])
+        Xf, Uf, Jf = dp.solve_rhc(prob, z[tag + "_x0"], N, *args, centralized=centralized, i_trial=7, **kw)
+    finally:
+        log.removeHandler(h); log.setLevel(old)
+    assert Xf.shape == z[tag + "_X_full"].shape and Uf.shape == z[tag + "_U_full"].shape
+    assert relerr(Xf, z[tag + "_X_full"]) < TOL_SOLVE and relerr(Uf, z[tag + "_U_full"]) < TOL_SOLVE
+    assert abs(Jf - float(z[tag + "_J_full"])) < TOL_SOLVE * abs(float(z[tag + "_J_full"]))
+    ref_rows = [str(r) for r in z[tag + "_rows"]]
+    assert len(h.rows) == len(ref_rows)
+    for mine, ref in zip(h.rows, ref_rows):
+        a, b = _parse_row(mine), _parse_row(ref)
+        for key in ("model_name", "n_agents", "i_trial", "centralized", "last", "N", "dt", "converged", "ids"):
+            assert a[key] == b[key], key
+        assert repr(a["subgraphs"]) == repr(b["subgraphs"])          # NumPy-int neighbours next to Python-int owners (Q10)
+        assert repr(a["t"]) == repr(b["t"])
+        assert abs(a["J"] - b["J"]) < 1e-6 * abs(b["J"]) and np.allclose(a["left"], b["left"], rtol=1e-6, atol=1e-9)
+        assert len(a["times"]) == len(b["times"])                      # wall-clock seconds: the one field that cannot match
+
+
+@pytest.mark.parametrize("tag", ["ws_uni", "ws_di"])
+def test_selfish_warmstart_vs_reference(dp, golden, tag):
+    """ilqrProblem.selfish_warmstart (problem.py:66-91): one k = 1 batch on the device against the reference's loop."""
+    z = golden("g7_callers")
+    prob = problem_from(z, tag + "_")
+    Uw = prob.selfish_warmstart(z[tag + "_x0"], int(z[tag + "_N"]))
+    assert Uw.shape == z[tag + "_U_warm"].shape and relerr(Uw, z[tag + "_U_warm"]) < TOL_SOLVE
+
+
+def test_solve_subproblem_vs_reference(dp, golden):
+    """solve_subproblem((subproblem, x0, U, id_, verbose)) (problem.py:97-105) -- the worker the reference's dispatch loop and
+    its multiprocessing pool call -- on the sub-problems of a proximity graph, plus its starmap form."""
+    from dpilqr_amd.problem import solve_subproblem, solve_subproblem_starmap
+    z = golden("g7_callers")
+    prob = problem_from(z, "sub_")
+    ids = prob.ids; T = int(z["sub_T"])
+    graph = dp.define_inter_graph_threshold(z["sub_x0"].reshape(1, -1), 0.5, prob.game_cost.x_dims, ids)
+    adj = np.zeros((len(ids), len(ids)), dtype=np.int32)
+    for i, id_ in enumerate(ids):
+        adj[i, [ids.index(int(j)) for j in graph[id_]]] = 1
+    np.testing.assert_array_equal(adj, z["sub_adj"])
+    subs = prob.split(graph)
+    x0s = dp.split_graph(z["sub_x0"].reshape(1, -1), prob.game_cost.x_dims, graph)
+    U0s = dp.split_graph(np.zeros((T, prob.dynamics.n_u)), prob.game_cost.u_dims, graph)
+    for i, id_ in enumerate(ids):
+        Xi, Ui, rid = solve_subproblem((subs[i], x0s[i], U0s[i], id_, False))
+        assert rid == id_ and Xi.shape == z[f"sub_X_{i}"].shape
+        assert relerr(Xi, z[f"sub_X_{i}"]) < TOL_SOLVE and relerr(Ui, z[f"sub_U_{i}"]) < TOL_SOLVE
+    Xi, Ui, rid = solve_subproblem_starmap(subs[0], x0s[0], U0s[0], ids[0])
+    assert rid == ids[0] and relerr(Xi, z["sub_X_0"]) < TOL_SOLVE

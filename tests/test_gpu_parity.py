@@ -147,39 +147,47 @@ def test_solve_misc(dp, golden, tag):
     check_solve(r, 0, z, tag + "_")
 
 
-def test_solve_batch_vs_oracle_256(dp):
-    """256 seeded cfg2 scenarios: HIP solve vs the CPU oracle, item by item.
+def _to_host(r):
+    return {k: v.cpu().numpy() for k, v in r.items()}
 
-    About 1-2 % of these scenarios are chaotic IN THE REFERENCE ITSELF: perturbing x0 by 1e-13 relative
-    changes the reference's own iteration count and final cost by 10-20 % (measured with the real
-    reference on seeds 1113, 1161, 1163, 1227).  No implementation can reproduce those
-    bit-for-bit-sensitive runs, so items are first classified by the oracle's own sensitivity
-    (same solve with x0*(1+1e-13)); parity is demanded on the well-conditioned ones."""
-    from oracle import oracle as orc
+
+def test_solve_batch_vs_oracle_all_items(dp):
+    """1024 seeded cfg2 scenarios: HIP solve vs the CPU oracle, EVERY item held to a bound (oracle/parity.py).
+
+    A few per cent of these scenarios are chaotic IN THE REFERENCE ITSELF: perturbing x0 by 1e-13 relative changes the
+    reference's own iteration count and final cost by 10-20 % (measured with the real reference on seeds 1113, 1161,
+    1163, 1227).  No item is exempted for that: each one must either reproduce the oracle's decision
+    trace with a final-state error bounded by 100 x the oracle's own 1e-13 sensitivity on that item, or differ by a
+    decision that sat within 100 x that sensitivity of equality, with the accepted costs agreeing iteration by iteration
+    up to there; the linear bounds end only at the iteration where the oracle itself has amplified 1e-13 beyond 1e-7."""
+    from oracle import oracle as orc, parity
     from dpilqr_amd.util import random_setup
-    c = cfg2_params(); B = 256
+    c = cfg2_params(); B = 1024
     x0 = np.zeros((B, 20)); xf = np.zeros((B, 20))
     for s in range(B):
         np.random.seed(1000 + s)
         a, b = random_setup(5, 4, is_rotation=False, rel_dist=5, var=2.5, n_d=2, random=True, energy=10.0)
         x0[s], xf[s] = a.ravel(), b.ravel()
+    U0 = np.zeros((B, 50, 10))
     pb = dp.ProblemBatch(c["model"], c["n_dims"], xf, c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
-    r = pb.solve(x0, np.zeros((B, 50, 10)), trace=True)
+    r = _to_host(pb.solve(x0, U0, trace=True))
     proto = orc.Problem(c["model"], c["n_dims"], xf[0], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
-    o = orc.solve_batch(proto, x0, xf, np.zeros((B, 50, 10)))
-    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, np.zeros((B, 50, 10)))
-    sens = np.array([relerr(op["X"][i], o["X"][i]) for i in range(B)])
-    well = (op["n_bwd"] == o["n_bwd"]) & (op["n_fwd"] == o["n_fwd"]) & (sens < 1e-6)
-    assert well.mean() > 0.9, "scenario set unexpectedly ill-conditioned"
-    nb = r["n_bwd"].cpu().numpy(); st = r["status"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy()
-    same = (nb == o["n_bwd"]) & (st == o["status"]) & (nf == o["n_fwd"])
-    assert same[well].all(), f"decision trace differs on well-conditioned items {np.where(well & ~same)[0]}"
-    X = r["X"].cpu().numpy(); U = r["U"].cpu().numpy(); J = r["J"].cpu().numpy()
-    for i in np.where(well)[0]:
+    o = orc.solve_batch(proto, x0, xf, U0, trace=True)
+    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, trace=True)
+    rep = parity.report(r, o, op)
+    sm = rep["summary"]
+    assert sm["all_ok"], (sm, [f"item {i}: {w}" for i, w in enumerate(rep["why"]) if w][:10])
+    assert sm["identical_decision_trace_frac"] > 0.95 and sm["chaotic_in_oracle_frac"] < 0.15, sm
+    # the items that are neither chaotic nor unstable in the oracle meet the north star's fixed 1e-5 as well
+    plain = rep["same"] & ~rep["unstable"] & (rep["chaotic_from"] < 0)
+    assert plain.mean() > 0.85
+    X, U, J, st = r["X"], r["U"], r["J"], r["status"]
+    for i in np.where(plain)[0]:
         assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(U[i], o["U"][i]) < TOL_SOLVE, i
         assert abs(J[i] - o["J"][i]) < TOL_SOLVE * abs(o["J"][i])
+        assert r["n_fwd"][i] == o["n_fwd"][i] and st[i] == o["status"][i]
     # every item, chaotic or not: a finished, finite solve that did not increase the cost
-    J0 = pb.rollout(x0, np.zeros((B, 50, 10)))[1].cpu().numpy()
+    J0 = pb.rollout(x0, U0)[1].cpu().numpy()
     assert np.isfinite(X).all() and np.isfinite(U).all() and (st >= 1).all() and (st <= 3).all()
     Jfin = pb.rollout(x0, U)[1].cpu().numpy()
     assert (Jfin <= J0 * (1 + 1e-12)).all()
@@ -408,15 +416,17 @@ def test_sweep_twelve_state_family(dp, k):
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
 
 
-@pytest.mark.parametrize("model,k,T", [(0, 7, 20), (0, 13, 15), (0, 15, 12), (3, 7, 20), (3, 12, 12), (4, 8, 15)])
+@pytest.mark.parametrize("model,k,T", [(0, 7, 50), (0, 13, 50), (0, 15, 50), (3, 7, 100), (3, 12, 100), (3, 13, 100), (3, 14, 100),
+                                       (3, 15, 100), (4, 8, 75), (4, 10, 75)])
 def test_solve_large_clusters_vs_oracle(dp, model, k, T):
-    """Whole solves of 7..15-agent clusters: the workgroup-per-item sweep and the two / three-wavefront line search
-    against the CPU oracle, on the scenarios whose oracle solve is insensitive to a 1e-13 perturbation."""
-    from oracle import oracle as orc
+    """Whole solves of 7..15-agent clusters at the configs' horizons (cfg3: unicycles T = 100, cfg4: quadcopters T = 75) and
+    the reference's n_lqr_iter = 50: the workgroup-per-item sweep and the two / three-wavefront line search against the
+    CPU oracle, every item held to the sensitivity-scaled bound of oracle/parity.py."""
+    from oracle import oracle as orc, parity
     from dpilqr_amd.util import random_setup
     ns, nc = (6, 3) if model == 4 else (4, 2)
     nd = 3 if ns == 6 else 2
-    B = 4
+    B = 6
     x0 = np.zeros((B, k * ns)); xf = np.zeros((B, k * ns))
     for s in range(B):
         np.random.seed(300 + s)
@@ -428,17 +438,19 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     if model == 4:
         U0[:, :, 0::3] = 9.80665
     pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.5, 0.1, T)
-    r = pb.solve(x0, U0, n_lqr_iter=6)
+    r = _to_host(pb.solve(x0, U0, trace=True))
     proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.5, 0.1, T)
-    o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=6)
-    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, n_lqr_iter=6)
-    well = np.array([relerr(op["X"][i], o["X"][i]) < 1e-6 and op["n_fwd"][i] == o["n_fwd"][i] for i in range(B)])
-    assert well.any(), "every scenario of this set is chaotic in the oracle itself"
-    X = r["X"].cpu().numpy(); nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy()
-    for i in np.where(well)[0]:
-        assert nb[i] == o["n_bwd"][i] and nf[i] == o["n_fwd"][i], i
-        assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i].cpu().numpy(), o["U"][i]) < TOL_SOLVE, i
-    assert np.isfinite(X).all()
+    o = orc.solve_batch(proto, x0, xf, U0, trace=True)
+    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, trace=True)
+    rep = parity.report(r, o, op)
+    assert rep["summary"]["all_ok"], (rep["summary"], [w for w in rep["why"] if w])
+    plain = rep["same"] & ~rep["unstable"] & (rep["chaotic_from"] < 0)
+    # (ten quadcopters solved centrally from hover are chaotic in the oracle on most seeds: the bound above still holds)
+    assert plain.sum() >= (1 if (model, k) == (4, 10) else 3), rep["summary"]
+    for i in np.where(plain)[0]:
+        assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i
+        assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i
+    assert np.isfinite(r["X"]).all()
 
 
 def _fuzz_cases():
@@ -488,8 +500,9 @@ def test_fuzz_shapes_against_oracle(dp, seed, model, k, T, B, window):
     proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.6, 0.1, T)
     o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=3)
     op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, n_lqr_iter=3)
-    nb = r["n_bwd"].cpu().numpy(); Xs = r["X"].cpu().numpy()
+    nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy(); st = r["status"].cpu().numpy(); Xs = r["X"].cpu().numpy()
     for i in range(B):
         if relerr(op["X"][i], o["X"][i]) < 1e-7 and op["n_fwd"][i] == o["n_fwd"][i]:      # well conditioned in the oracle
-            assert nb[i] == o["n_bwd"][i] and relerr(Xs[i], o["X"][i]) < TOL_SOLVE, i
+            assert (nb[i], nf[i], st[i]) == (o["n_bwd"][i], o["n_fwd"][i], o["status"][i]), i
+            assert relerr(Xs[i], o["X"][i]) < TOL_SOLVE, i
     assert np.isfinite(Xs).all()

@@ -8,7 +8,8 @@ from dpilqr_amd import lowering
 from dpilqr_amd.sharding import pack_results, shard_bounds, unpack_results
 
 MODEL_CLASSES = {0: dp.DoubleIntDynamics4D, 1: dp.DoubleIntDynamics6D, 2: dp.CarDynamics3D, 3: dp.UnicycleDynamics4D,
-                 4: dp.QuadcopterDynamics6D, 5: dp.HumanDynamics6D, 6: dp.HumanDynamicsLin6D, 7: dp.QuadcopterDynamics12D}
+                 4: dp.QuadcopterDynamics6D, 5: dp.HumanDynamics6D, 6: dp.HumanDynamicsLin6D, 7: dp.QuadcopterDynamics12D,
+                 8: dp.HumanDynamics6DPadded12}
 
 
 def problem_from(z, prefix=""):
@@ -109,3 +110,38 @@ def test_column_dominance_implies_no_row_exchange():
         _, piv = sl.lu_factor(A)
         assert np.array_equal(piv, np.arange(m))
     assert tested > 2500
+
+
+def _parse_row(row):
+    """A CSV row of solve_rhc's log -> the objects it was printed from (the subgraphs hold NumPy ints, quirk Q10)."""
+    import ast
+    import csv
+    f = next(csv.reader([row]))
+    num = lambda s: float(s) if ("." in s or "e" in s or "inf" in s or "nan" in s) else int(s)
+    return dict(model_name=f[0], n_agents=int(f[1]), i_trial=ast.literal_eval(f[2]), centralized=f[3] == "True", last=f[4] == "True",
+                t=num(f[5]), J=float(f[6]), N=int(f[7]), dt=float(f[8]), converged=f[9] == "True", ids=ast.literal_eval(f[10]),
+                times=ast.literal_eval(f[11]), subgraphs=eval(f[12], {"np": np}), left=ast.literal_eval(f[13]))
+
+
+@pytest.mark.parametrize("tag", ["rhc_c", "rhc_c2", "rhc_d"])
+def test_rhc_log_row_format_is_the_references_byte_for_byte(golden, tag):
+    """The CSV row of distributed.py:190-194,215-219: printing the reference's own values through this package's formatter
+    reproduces the reference's rows byte for byte (the wall-clock `times` field included, as data)."""
+    from dpilqr_amd.distributed import rhc_log_row
+    z = golden("g7_callers")
+    for row in z[tag + "_rows"]:
+        f = _parse_row(str(row))
+        assert rhc_log_row(f["model_name"], f["n_agents"], f["i_trial"], f["centralized"], f["last"], f["t"], f["J"], f["N"],
+                           f["dt"], f["converged"], f["ids"], f["times"], f["subgraphs"], f["left"]) == str(row)
+
+
+def test_graph_neighbours_are_numpy_ints_like_the_references(golden):
+    """Quirk Q10: define_inter_graph_threshold returns the agent's own id as a Python int and its neighbours as NumPy
+    ints; the difference is visible in the log rows, so it is kept."""
+    z = golden("g5_dispatch"); tag = "uni5"
+    prob = problem_from(z, tag + "_")
+    g = dp.define_inter_graph_threshold(z[tag + "_x0"].reshape(1, -1), 0.5, prob.game_cost.x_dims, prob.ids)
+    for id_, members in g.items():
+        assert members == sorted(members) and id_ in members
+        for v in members:
+            assert isinstance(v, int) if v == id_ else isinstance(v, np.integer)
