@@ -65,9 +65,9 @@ SIGNATURES = {
     "dpilqr_solve_workspace_bytes_f32": (i64, [_DP, i32, i32]),
     "dpilqr_solve_batch_f32": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_debug_stamps": (i32, [vp]),
-    "dpilqr_profile_enable": (i32, [i32]),
-    "dpilqr_profile_read": (i32, [C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
-    "dpilqr_profile_read_sweep": (i32, [i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(i64), i32]),
+    "dpilqr_profile_enable": (i32, [vp, i32]),
+    "dpilqr_profile_read": (i32, [vp, C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
+    "dpilqr_profile_read_sweep": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(i64), i32]),
     "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
 }
 
@@ -121,13 +121,13 @@ PROFILE_CLASSES = {"tiles": 1, "riccati": 2, "forward": 4, "rollout": 8}
 def profile_enable(on=True, classes=None):
     """classes: iterable of PROFILE_CLASSES names to bracket with events (None = all)."""
     mask = 0 if not classes else sum(PROFILE_CLASSES[c] for c in classes)
-    return load().dpilqr_profile_enable(int(bool(on)) | (mask << 1))
+    return load().dpilqr_profile_enable(solver(), int(bool(on)) | (mask << 1))
 
 
 def profile_read(reset=True):
     """Per kernel class (tiles, riccati, forward, rollout): total ms, launches, sub-problems processed."""
     ms, ln, it = (f64 * 4)(), (i64 * 4)(), (i64 * 4)()
-    check(load().dpilqr_profile_read(C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
+    check(load().dpilqr_profile_read(solver(), C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
     names = ["tiles", "riccati", "forward", "rollout"]
     return {n: dict(ms=ms[i], launches=ln[i], items=it[i]) for i, n in enumerate(names)}
 
@@ -135,7 +135,7 @@ def profile_read(reset=True):
 def profile_read_sweep(waves, reset=True):
     """The wavefront sweep's launches of one variant (waves = 4, 8 or 12 wavefronts per workgroup): ms, launches, items."""
     ms, ln, it = f64(), i64(), i64()
-    check(load().dpilqr_profile_read_sweep(int(waves), C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
+    check(load().dpilqr_profile_read_sweep(solver(), int(waves), C.byref(ms), C.byref(ln), C.byref(it), int(bool(reset))))
     return dict(ms=ms.value, launches=ln.value, items=it.value)
 
 

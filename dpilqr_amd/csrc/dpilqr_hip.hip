@@ -740,17 +740,17 @@ int32_t dpilqr_debug_stamps(void* buf) {
     return rc ? rc : set_stamp_buffer_forward(buf);
 }
 
-int32_t dpilqr_profile_enable(int32_t enable) {
-    Profiler& g_prof = g_default_solver.prof;
+int32_t dpilqr_profile_enable(dpilqr_solver* solver, int32_t enable) {
+    Profiler& g_prof = solver ? solver->prof : g_default_solver.prof;
     const int32_t prev = g_prof.on ? 1 : 0;
     g_prof.on = (enable & 1) != 0;
     g_prof.mask = (enable >> 1) & 0xF ? (enable >> 1) & 0xF : 0xF;
     return prev;
 }
 
-int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset) {
+int32_t dpilqr_profile_read(dpilqr_solver* solver, double ms[4], int64_t launches[4], int64_t items[4], int32_t reset) {
     if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read: NULL pointer");
-    Profiler& g_prof = g_default_solver.prof;
+    Profiler& g_prof = solver ? solver->prof : g_default_solver.prof;
     for (int c = 0; c < 4; ++c) {
         ms[c] = g_prof.ms[c]; launches[c] = g_prof.launches[c]; items[c] = g_prof.items[c];
         if (reset) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; g_prof.items[c] = 0; }
@@ -758,11 +758,11 @@ int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4],
     return DPILQR_OK;
 }
 
-int32_t dpilqr_profile_read_sweep(int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset) {
+int32_t dpilqr_profile_read_sweep(dpilqr_solver* solver, int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset) {
     if (!ms || !launches || !items) return fail(DPILQR_EINVAL, "profile_read_sweep: NULL pointer");
     if (waves != 4 && waves != 8 && waves != 12) return fail(DPILQR_EINVAL, "profile_read_sweep: waves=%d (4, 8 or 12)", waves);
     const int v = waves / 4 - 1;
-    Profiler& g_prof = g_default_solver.prof;
+    Profiler& g_prof = solver ? solver->prof : g_default_solver.prof;
     *ms = g_prof.sweep_ms[v]; *launches = g_prof.sweep_launches[v]; *items = g_prof.sweep_items[v];
     if (reset) { g_prof.sweep_ms[v] = 0; g_prof.sweep_launches[v] = 0; g_prof.sweep_items[v] = 0; }
     return DPILQR_OK;

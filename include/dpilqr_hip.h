@@ -235,19 +235,19 @@ int32_t dpilqr_solve_batch_f32(dpilqr_solver* solver, const dpilqr_batch_desc* d
 
 /* -------------------------------------------------- measurement hooks (bench.py's roofline leg)
  * When enabled, dpilqr_solve_batch brackets every kernel launch of its iteration loop with HIP events
- * recorded on `stream` and accumulates, per calling thread, for each kernel class c
+ * recorded on `stream` and accumulates, in the solver object it was given, for each kernel class c
  * (0 = tile producer, 1 = Riccati sweep, 2 = line search / forward pass, 3 = initial rollout):
  * total milliseconds, number of launches, and number of sub-problems those launches processed.
  * enable: bit 0 = on; bits 1..4 = optional mask of the classes to bracket (0 = all).  Every bracketed launch
  * costs a dispatch gap, so a measurement of one kernel asks for that class only.                       */
-int32_t dpilqr_profile_enable(int32_t enable);
+int32_t dpilqr_profile_enable(dpilqr_solver* solver /* NULL: the calling thread's default solver */, int32_t enable);
 /* diagnostic: register (or clear with NULL) a device buffer of 4 x uint64 per sweep workgroup that receives
  * {start, end} wall-clock stamps (100 MHz) and the HW_ID / XCC_ID registers of the wave that ran it.   */
 int32_t dpilqr_debug_stamps(void* device_buffer);
-int32_t dpilqr_profile_read(double ms[4], int64_t launches[4], int64_t items[4], int32_t reset);
+int32_t dpilqr_profile_read(dpilqr_solver* solver, double ms[4], int64_t launches[4], int64_t items[4], int32_t reset);
 /* the wavefront sweep's share of class 1, by variant: waves = wavefronts per workgroup (4, 8 or 12), i.e. the
  * k_riccati_mfma<n_x, n_u, waves, ...> instantiation a rocprofv3 kernel trace lists under that name               */
-int32_t dpilqr_profile_read_sweep(int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset);
+int32_t dpilqr_profile_read_sweep(dpilqr_solver* solver, int32_t waves, double* ms, int64_t* launches, int64_t* items, int32_t reset);
 
 /* -------------------------------------------------- (6) dispatch front end ("next" row)
  * define_inter_graph_threshold (distributed.py:224-247) for S scenarios at once:
