@@ -50,6 +50,7 @@ SIGNATURES = {
     "dpilqr_backward_pass_tiles_blocks": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_tiles_bytes": (i64, [i32, i32, i32, i32]),
     "dpilqr_backward_pass": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_backward_pass_fused": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_forward_pass": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dpilqr_alphas": (i32, [C.POINTER(f64 * N_ALPHA)]),
     "dpilqr_solve_workspace_bytes": (i64, [_DP, i32, i32]),

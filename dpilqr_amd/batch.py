@@ -117,6 +117,9 @@ class ProblemBatch:
         nd_all = np.asarray(n_dims, dtype=np.int32)
         if nd_all.size and bool((nd_all == nd_all.reshape(-1)[0]).all()):
             uniform |= (1 + int(nd_all.reshape(-1)[0])) << 8
+        Qk, Rk, Qfk = (np.asarray(expand(M_, n_)) for M_, n_ in ((Q, ns), (R, nc), (Qf, ns)))
+        if qs == 0 and rs == 0 and fs == 0 and all(M_.ndim == 3 and bool((M_ == M_[0]).all()) for M_ in (Qk, Rk, Qfk)):
+            uniform |= 1 << 16                                       # one Q, R, Q_f for every agent of every item
         self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, uniform, self.dt, self.w_ref, self.w_prox,
                                    ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
@@ -187,6 +190,16 @@ class ProblemBatch:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
         fn = self._lib.dpilqr_backward_pass if dtype == torch.float64 else self._lib.dpilqr_backward_pass_f32
         _lib.check(fn(self._d, ptr(X), ptr(U), ptr(mu_t), ptr(K), ptr(d), ptr(ws), stream_handle()))
+        return K, d
+
+    def backward_pass_fused(self, X, U, mu):
+        """The backward pass without tile records (dpilqr_backward_pass_fused); raises DpilqrError(EUNSUPPORTED) for batches
+        the fused sweep does not serve."""
+        B, T, n, m = self.B, self.T, self.n_x, self.n_u
+        X = self._in(X, (B, T + 1, n)); U = self._in(U, (B, T, m))
+        mu_t = to_dev(np.broadcast_to(np.asarray(mu, dtype=np.float64), (B,))) if not isinstance(mu, torch.Tensor) else mu
+        K = empty((B, T, m, n)); d = empty((B, T, m))
+        _lib.check(self._lib.dpilqr_backward_pass_fused(self._d, ptr(X), ptr(U), ptr(mu_t), ptr(K), ptr(d), None, stream_handle()))
         return K, d
 
     def forward_pass(self, X, U, K, d, alphas, dtype=torch.float64):

@@ -381,7 +381,9 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
     const int um = hint_model(D);
     // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every item
-    const bool static_part = !sh.big && !no_static && D.R_bstride == 0 &&
+    // the fused sweep evaluates the plugins itself: no tile producer, no records
+    const bool fused = sizeof(R) == 8 && !sh.big && fused_sweep_applies(D);
+    const bool static_part = !fused && !sh.big && !no_static && D.R_bstride == 0 &&
                              (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
     if (!resume) {
         double a[DPILQR_N_ALPHA];
@@ -400,7 +402,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         if (n_lqr_iter > 0) {
             // tile records: the producer of the loop writes only structurally non-zero entries, so the zeros are put in
             // place once; the big sweep's scratch: its padding is zero and never written
-            if (hipMemsetAsync(tiles, 0, W.K - W.tiles, st) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipMemsetAsync failed"));
+            if (!fused && hipMemsetAsync(tiles, 0, W.K - W.tiles, st) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipMemsetAsync failed"));
             // the static part is written once into all Wn slots here (with items 0..Wn-1 as stand-ins; their (X, U)
             // dependent entries are overwritten by each iteration's producer launch) and skipped afterwards
             if (static_part) {
@@ -427,7 +429,13 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
         S.next_count = nxt_n;
         int32_t r = DPILQR_OK;
-        if (!sh.big) {
+        if (fused) {
+            if constexpr (sizeof(R) == 8) {
+                prof.begin(1, it, st);
+                if ((r = launch_riccati_fused(D, X, U, S.mu, K, d, singular, cur, cur_n, upper, S.gains_by_item, st))) return r;
+                prof.end(st, g_sweep_waves);
+            }
+        } else if (!sh.big) {
             if constexpr (sizeof(R) == 8) {
                 prof.begin(0, it, st);
                 if ((r = launch_make_tiles(D, X, U, tiles, cur, cur_n, upper, true, static_part, st))) return r;
@@ -622,6 +630,19 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
     if (rc) return rc;
     return launch_riccati(desc->B, desc->T, n, m, tiles_workspace, mu, K, d, nullptr, nullptr, nullptr, desc->B, 0, desc->n_s,
                           desc->n_c, as_stream(stream));
+}
+
+int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
+                                   double* d, int32_t* singular, void* stream) {
+    int32_t rc = check_desc(desc);
+    if (rc) return rc;
+    if (desc->B == 0) return DPILQR_OK;
+    if (!X || !U || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_fused: NULL pointer");
+    if (!fused_sweep_applies(*desc))
+        return fail(DPILQR_EUNSUPPORTED, "backward_pass_fused: needs DoubleIntDynamics4D agents (<= 5), n_dims = 2 and one Q, R, Q_f "
+                                         "for all agents and items (uniform_model hints)");
+    rc = launch_riccati_fused(*desc, X, U, mu, K, d, singular, nullptr, nullptr, desc->B, 0, as_stream(stream));
+    return rc == DPILQR_EUNSUPPORTED ? fail(rc, "backward_pass_fused: no instantiation for n_x=%d", desc->k * desc->n_s) : rc;
 }
 
 int32_t dpilqr_backward_pass_f32(const dpilqr_batch_desc* desc, const float* X, const float* U, const double* mu, float* K,

@@ -50,6 +50,14 @@ int device_cus();
 // hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
 inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
 inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
+inline bool hint_shared_weights(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 16) & 1) != 0; }
+// the fused sweep's condition: DoubleIntDynamics4D agents only, planar proximity cost, one Q / R / Q_f for every agent of
+// every item (the descriptor's hints), at most five agents (the wavefront sweep's sizes)
+inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
+    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr;   // A/B switch: the record-fed sweep
+    return !off && hint_model(D) == 0 && hint_n_dims(D) == 2 && hint_shared_weights(D) && D.Q_bstride == 0 && D.R_bstride == 0 &&
+           D.Qf_bstride == 0 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
+}
 
 // ---- tu_tiles.hip
 int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,
@@ -62,6 +70,9 @@ extern thread_local int g_sweep_waves;   // wavefronts per workgroup of the last
 int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const double* mu, double* K, double* d,
                        int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
                        int gains_by_item, int block_ns, int block_nc, hipStream_t st);
+int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K,
+                             double* d, int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
+                             int gains_by_item, hipStream_t st);
 int32_t set_stamp_buffer_riccati(void* device_buffer);
 
 // ---- tu_forward.hip

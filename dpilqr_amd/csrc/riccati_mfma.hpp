@@ -38,7 +38,7 @@ namespace dpilqr {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int N, int M>
+template <int N, int M, bool FUSED = false>
 struct MfmaCfg {
     static constexpr int NM = N + M;
     static constexpr int NP = N + 1;                   // columns of [P|p], [K|d], [Q_ux|Q_u]
@@ -63,7 +63,13 @@ struct MfmaCfg {
     //   G : [Q_uu | Q_ux | Q_u] (S1/S2 epilogues .. S5 operands) + Q_x staging (S1 -> S2 epilogue) -> a2 (S5 epilogue,
     //       read transposed).  Its reduction-padding rows >= M therefore hold finite left-overs instead of zeros;
     //       they only ever multiply the zero padding rows of [K|d].
-    static constexpr int szR1 = round_up(N * LAB > N * LQ ? N * LAB : N * LQ, 2);
+    // FUSED (riccati_mfma_lane.inc, "fused variant"): no [A|B] in LDS; R1 = [Q_xx | Q_x] followed by the step's plugin data:
+    // pair gradients [NPAIR][2], pair Hessians [NPAIR][4], their per-agent sums [KA][4], Q + Q^T [16], R + R^T [4], x_f [N]
+    static constexpr int F_KA = N / 4, F_NP = F_KA * (F_KA - 1) / 2;
+    // and the step's [l_x | l_u] [N + M]
+    static constexpr int oFG = N * LQ, oFH = oFG + 2 * F_NP, oFD = oFH + 4 * F_NP, oFQQ = oFD + 4 * F_KA, oFRR = oFQQ + 16,
+                         oFXf = oFRR + 4, oFL = oFXf + N, szF = round_up(oFL + NM, 2);
+    static constexpr int szR1 = FUSED ? szF : round_up(N * LAB > N * LQ ? N * LAB : N * LQ, 2);
     static constexpr int szT0 = N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N;
     static constexpr int szT1 = szT0 > NM * LTB ? szT0 : NM * LTB;
     static constexpr int szR2 = round_up(szT1 > N * LP ? szT1 : N * LP, 2);
@@ -234,12 +240,26 @@ __device__ __forceinline__ int phase_lane(int lane) {
 // WAVES = 12 (block-diagonal variant, launches of more than 2048 items): three wavefronts per SIMD in 168 registers
 // each and 13.5 KB of LDS per item (12 items = 158 KB of the CU's 160 KB).  The lane terms are recomputed per phase
 // group instead of being kept (riccati_mfma_lane.inc) and the S2 l-values are requested at the top of their own step.
-template <int N, int M, int WAVES, int NS, int NC>
+// FUSED (NS = 4, NC = 2, every agent a DoubleIntDynamics4D, one Q / R / Q_f for all agents and items, planar proximity
+// cost): the sweep evaluates linearize / quadraticize itself -- no tile records are read.  A = I + dt A_c, B = dt B_c are
+// compile-time patterns in dt, so the block products S1 / S2 shrink to the few non-trivial terms (the dropped ones are
+// multiplications by exact 0 and 1: the results are those of the record-fed sweep bit for bit); the (X, U)-dependent
+// l-values are computed per step in the lanes that add them, with the tile producer's own expressions and orders
+// (tiles_wave.hpp), from pair derivatives that ten lanes evaluate at the top of the step.  Per pass and item the sweep
+// reads 8 ((T + 1) n_x + T n_u) = 12 160 B of trajectory instead of 535 360 B of records ("fused variant").
+struct FusedArgs {
+    dpilqr_batch_desc D;
+    const double* X;
+    const double* U;
+};
+
+template <int N, int M, int WAVES, int NS, int NC, bool FUSED = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus) {
-    using C = MfmaCfg<N, M>;
+    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
+    using C = MfmaCfg<N, M, FUSED>;
+    static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variant is written for DoubleIntDynamics4D blocks");
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
     constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
     // Items are DEALT to workgroups in layers, not blocked.  A workgroup owns a CU (its LDS), so a launch runs in rounds
@@ -283,7 +303,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     double* sMt = sG;                  // a2, after the S5 products
 
     const double mu = mu_arr[b];
-    const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
+    const double f_radius = FUSED ? F.D.radius[(int64_t)b * F.D.radius_bstride] : 0.0;
+    const double* base = FUSED ? nullptr : tiles + (int64_t)slot * (T + 1) * L.stride;
     int sing = 0;
     unsigned long long* const stamps = g_stamp_buf;
     unsigned long long t_start = 0;
@@ -307,11 +328,48 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     double nL[T_NM][T_NM][4];
     double nLxu[T_NM][4];
     constexpr bool REMAT = (WAVES == 12);   // see riccati_mfma_lane.inc
+    v2d pf[2];   // FUSED: this lane's share of (X[t], U[t]), one step ahead
+    bool f_prox = false;   // FUSED: some pair of the current step is within the radius (wave uniform)
+    // FUSED: the part of this lane's S2 l-values that does not depend on (X, U) -- w_ref (Q + Q^T), w_ref (R + R^T) on the
+    // agent's own blocks -- and where the part that does (a pair Hessian, or the agent's sum of them) is found
+    double lvc[FUSED ? RPL : 1][FUSED ? NSC : 1];
+    int lv_h[FUSED ? RPL : 1];          // offset into the step's Hessian data (doubles from sFH), -1: no proximity part
+    bool lv_neg[FUSED ? RPL : 1];
+    if constexpr (FUSED) {
+        const ItemParams IP = item_params(F.D, b);
+        constexpr int FKA_ = C::F_KA;
+        const int ag_ = min(lane0 / LPA, KA - 1), sub2_ = min(lane0 - (lane0 / LPA) * LPA, (NM - 1) / RPL);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+#pragma unroll
+            for (int c = 0; c < NSC; ++c) lvc[r][c] = 0.0;
+            lv_h[r] = -1; lv_neg[r] = false;
+            const int ip = min(RPL * sub2_ + r, NM - 1);
+            if (ip < N) {
+                const int ar = ip >> 2, li = ip & 3;
+                if (ar == ag_) {
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) lvc[r][c] = F.D.w_ref * (IP.Q[li * 4 + c] + IP.Q[c * 4 + li]);
+                }
+                if (FKA_ > 1 && li < 2) {
+                    lv_neg[r] = ar != ag_;
+                    lv_h[r] = (ar == ag_) ? (C::oFD - C::oFH) + ag_ * 4 + li * 2
+                                          : ((ar < ag_) ? pair_index(ar, ag_, FKA_) : pair_index(ag_, ar, FKA_)) * 4 + li * 2;
+                }
+            } else {
+                const int a = ip - N;
+                if ((a >> 1) == ag_) {
+                    lvc[r][NS] = F.D.w_ref * (IP.R[(a & 1) * 2] + IP.R[a & 1]);
+                    lvc[r][NS + 1] = F.D.w_ref * (IP.R[(a & 1) * 2 + 1] + IP.R[2 + (a & 1)]);
+                }
+            }
+        }
+    }
     {
     const int lane = lane0;
     for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
     DPILQR_LDS_FENCE();
-    {
+    if constexpr (!FUSED) {
         const double* rec = base + (int64_t)T * L.stride;
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N;
@@ -321,6 +379,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     }
 
 #include "riccati_mfma_lane.inc"
+    if constexpr (FUSED) {
+        // symmetrised weights and the goal, once; then the terminal condition p = l_x(T), P = l_xx(T) (control.py:125-129)
+        // with the tile producer's expressions (tiles_wave.hpp phases A2-B2, Q_f in place of Q)
+        const ItemParams IP = item_params(F.D, b);
+        if (lane < 16) sFQQ[lane] = IP.Q[lane] + IP.Q[(lane & 3) * 4 + (lane >> 2)];
+        if (lane < 4) sFRR[lane] = IP.R[lane] + IP.R[(lane & 1) * 2 + (lane >> 1)];
+        for (int e = lane; e < N; e += 64) sFXf[e] = IP.xf[e];
+        DPILQR_LDS_FENCE();
+        fused_prefetch(T);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        fused_step_data(T, IP.Qf);           // pair derivatives at X[T]; [l_x | .] with Q_f
+        for (int e = lane; e < N * N; e += 64) {
+            const int i = e / N, j = e - i * N, ai = i >> 2, li = i & 3, aj = j >> 2, lj = j & 3;
+            double val = 0.0;
+            if (ai == aj) val = F.D.w_ref * (IP.Qf[li * 4 + lj] + IP.Qf[lj * 4 + li]);
+            if (FKA > 1 && li < 2 && lj < 2 && f_prox) {
+                double acc = 0.0;
+                if (ai == aj) acc = sFD[ai * 4 + li * 2 + lj];
+                else acc += -sFH[((ai < aj) ? pair_index(ai, aj, FKA) : pair_index(aj, ai, FKA)) * 4 + li * 2 + lj];
+                val += F.D.w_prox * acc;
+            }
+            sP[i * LP + j] = val;
+        }
+        for (int j = lane; j < N; j += 64) sP[j * LP + N] = sFL[j];
+        DPILQR_LDS_FENCE();
+        fused_prefetch(T - 1);
+    } else {
     prefetch_ab(T - 1);
     if constexpr (BD) {
         prefetch_bd_x(T - 1);
@@ -328,6 +413,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     } else {
         prefetch_lxu(T - 1);
         prefetch_l(T - 1);
+    }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see riccati_tiled.hpp
     }
@@ -343,11 +429,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         {   // ---- S0, S1
         const int lane = phase_lane<REMAT>(lane0);
 #include "riccati_mfma_lane.inc"
+        if constexpr (FUSED) {
+            // the step's pair derivatives and [l_x | l_u]; then the next step's share of the trajectory is requested
+            fused_step_data(t, nullptr);
+            fused_prefetch(tn);
+        } else {
 #pragma unroll
         for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
         DPILQR_LDS_FENCE();
         if constexpr (LATE_L) prefetch_bd_l(t);
         prefetch_ab(tn);
+        }
         MPHASE(0)
 
         // The two wavefronts of a SIMD should be in DIFFERENT halves of a step -- one in the vector-pipe phases (S1-S3:
@@ -357,7 +449,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         // per 2048-item launch.
         __builtin_amdgcn_s_setprio(1);
         // ---- S1: [A|B]^T [P|p]
-        if constexpr (BD) {
+        if constexpr (FUSED) {
+            // [A|B]^T [P|p] for A = I + dt A_c, B = dt B_c of the double integrator: rows 0, 1 of A^T P are rows 0, 1 of P;
+            // rows 2, 3 are dt P_0 + P_2, dt P_1 + P_3 (product rounded, then the sum: what the four-term chain of the
+            // record-fed sweep computes, whose other terms are exact zeros); B^T P = dt [P_2; P_3]
+            const double fdt = F.D.dt;
+            double acc[NSC][CPL], pr[NS][CPL];
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                const v2d v = *reinterpret_cast<const v2d*>(bP + l * LP);
+                pr[l][0] = v.x; pr[l][1] = v.y;
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                acc[0][c] = pr[0][c];
+                acc[1][c] = pr[1][c];
+                acc[2][c] = fdt * pr[0][c] + pr[2][c];
+                acc[3][c] = fdt * pr[1][c] + pr[3][c];
+                acc[4][c] = fdt * pr[2][c];
+                acc[5][c] = fdt * pr[3][c];
+                // T2 rows: + mu B[j][c] with B[j][2 ag + q] = dt iff j = 4 ag + 2 + q   (quirk Q6)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) acc[NS + q][c] = fma(mu, (j0 + c == 4 * ag + 2 + q) ? fdt : 0.0, acc[NS + q][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < NS; ++r) *reinterpret_cast<v2d*>(bTa + r * LTB) = v2d{acc[r][0], acc[r][1]};
+#pragma unroll
+            for (int r = 0; r < NC; ++r) *reinterpret_cast<v2d*>(bTb + r * LTB) = v2d{acc[NS + r][0], acc[NS + r][1]};
+            if (bPcol) {   // Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+#pragma unroll
+                for (int r = 0; r < NS; ++r) sQx[NS * ag + r] = sFL[NS * ag + r] + acc[r][0];
+#pragma unroll
+                for (int r = 0; r < NC; ++r) sG[(NC * ag + r) * LG + M + N] = sFL[N + NC * ag + r] + acc[NS + r][0];
+            }
+        } else if constexpr (BD) {
             double acc[NSC][CPL];
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
@@ -424,7 +549,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 }
         }
         DPILQR_LDS_FENCE();
-        if constexpr (!BD) prefetch_lxu(tn);
+        if constexpr (!BD && !FUSED) prefetch_lxu(tn);
         MPHASE(1)
         }
         {
@@ -432,7 +557,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 #include "riccati_mfma_lane.inc"
 
         // ---- S2: [T1;T2][A|B] -> Q_xx (rows < n, cols < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped
-        if constexpr (BD) {
+        if constexpr (FUSED) {
+            // [T1;T2] [A|B] with the same patterns: columns 0, 1 of T A are T's, columns 2, 3 are dt T_0 + T_2, dt T_1 + T_3,
+            // T B = dt [T_2 T_3]; then the step's l-values, formed here instead of being read
+            const double fdt = F.D.dt, wp = F.D.w_prox;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                double tv[NS], acc[NSC], lv[NSC];
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q) {
+                    const v2d v = *reinterpret_cast<const v2d*>(bT2[r] + 2 * q);
+                    tv[2 * q] = v.x; tv[2 * q + 1] = v.y;
+                }
+                acc[0] = tv[0]; acc[1] = tv[1];
+                acc[2] = tv[0] * fdt + tv[2]; acc[3] = tv[1] * fdt + tv[3];
+                acc[4] = tv[2] * fdt; acc[5] = tv[3] * fdt;
+#pragma unroll
+                for (int c = 0; c < NSC; ++c) lv[c] = lvc[r][c];
+                if (FKA > 1 && f_prox && lv_h[r] >= 0) {     // the pair Hessian (or the agent's sum of them) on the position entries
+                    const v2d h = *reinterpret_cast<const v2d*>(sFH + lv_h[r]);
+                    lv[0] += wp * (lv_neg[r] ? -h.x : h.x);
+                    lv[1] += wp * (lv_neg[r] ? -h.y : h.y);
+                }
+#pragma unroll
+                for (int q = 0; q < NS / 2; ++q)
+                    *reinterpret_cast<v2d*>(bDa[r] + 2 * q) = v2d{lv[2 * q] + acc[2 * q], lv[2 * q + 1] + acc[2 * q + 1]};
+                *reinterpret_cast<v2d*>(bDb[r]) = v2d{lv[NS] + acc[NS], lv[NS + 1] + acc[NS + 1]};
+            }
+        } else if constexpr (BD) {
             double acc[RPL][NSC];
             double tv[RPL][NS];
             {
@@ -488,7 +640,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         }
         DPILQR_LDS_FENCE();
         if (lane < N) sQ[lane * LQ + N] = sQx[lane];   // Q_x joins Q_xx now that [A|B] is dead
-        if constexpr (BD) { prefetch_bd_x(tn); if constexpr (!LATE_L) prefetch_bd_l(tn); } else prefetch_l(tn);
+        if constexpr (FUSED) {} else if constexpr (BD) { prefetch_bd_x(tn); if constexpr (!LATE_L) prefetch_bd_l(tn); } else prefetch_l(tn);
         // sT is dead from here on and becomes [K | d] + T3^T: the reduction-padding rows of [K | d] must read as zero
         for (int e = lane; e < (C::KROWS - M) * LK; e += 64) sK[M * LK + e] = 0.0;
         MPHASE(2)

@@ -53,7 +53,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         const int cus = device_cus();                                                                              \
         const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d,                      \
-                           singular, items, n_items, gains_by_item, cus);                                          \
+                           singular, items, n_items, gains_by_item, cus, FusedArgs{});                             \
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
@@ -108,6 +108,39 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
                        d, singular, items, n_items, gains_by_item);
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;
+}
+
+// The fused sweep (riccati_mfma.hpp, FUSED): no tile records; for batches of DoubleIntDynamics4D agents with one Q, R, Q_f
+// for all agents and items and a planar proximity cost (the caller checks the descriptor's hints).  Returns
+// DPILQR_EUNSUPPORTED without touching the error text when the shape has no fused instantiation.
+int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K,
+                             double* d, int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
+                             int gains_by_item, hipStream_t st) {
+    g_sweep_waves = 0;
+    if (grid_items <= 0) return DPILQR_OK;
+    const int n = D.k * D.n_s, m = D.k * D.n_c;
+    static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;
+#define DPILQR_TRY_FUSED(NN, MM)                                                                                   \
+    if (n == NN && m == MM) {                                                                                      \
+        using CF = MfmaCfg<NN, MM, true>;                                                                          \
+        const int wv = (grid_items > 2048 && max_wv >= 12 && CF::total * 8 * 12 <= kMaxLds) ? 12                   \
+                       : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
+        g_sweep_waves = wv;                                                                                        \
+        const size_t lds_t = sizeof(double) * CF::total * wv;                                                      \
+        auto kern = wv == 12 ? k_riccati_mfma<NN, MM, 12, 4, 2, true>                                              \
+                    : wv == 8 ? k_riccati_mfma<NN, MM, 8, 4, 2, true> : k_riccati_mfma<NN, MM, 4, 4, 2, true>;     \
+        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
+        if (rc_t) return rc_t;                                                                                     \
+        const int cus = device_cus();                                                                              \
+        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, D.B, D.T, nullptr, mu, K, d, singular, items, \
+                           n_items, gains_by_item, cus, FusedArgs{D, X, U});                                       \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+    DPILQR_TILED_SIZES(DPILQR_TRY_FUSED)
+#undef DPILQR_TRY_FUSED
+    return DPILQR_EUNSUPPORTED;
 }
 
 int32_t set_stamp_buffer_riccati(void* buf) {

@@ -84,8 +84,9 @@ typedef struct dpilqr_batch_desc {
     int32_t T;   /* horizon N (control.py:56)                                    */
     int32_t uniform_model; /* hints, 0 = unknown / mixed (always valid).  Bits 0..7: 1 + Model enum when EVERY agent of
                               EVERY item uses that model; bits 8..15: 1 + n_dims when every agent of every item has
-                              that ProximityCost.n_dims.  They let the solver pick kernels compiled per model and skip
-                              work that cannot depend on the item.                                              */
+                              that ProximityCost.n_dims; bit 16: every agent has the same Q, the same R and the same Q_f
+                              (and their batch strides are 0).  They let the solver pick kernels compiled per model and
+                              skip work that cannot depend on the item.                                         */
     double dt;     /* DynamicalModel.dt                                          */
     double w_ref;  /* GameCost.REF_WEIGHT  = 1   (cost.py:185)                   */
     double w_prox; /* GameCost.PROX_WEIGHT = 200 (cost.py:186)                   */
@@ -165,6 +166,13 @@ int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int
 int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u);
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
                              double* K, double* d, double* tiles_workspace, void* stream);
+/* The same backward pass without tile records ("fused variant"): for batches whose descriptor hints say
+ * "DoubleIntDynamics4D agents only (at most five), n_dims = 2 everywhere, one Q, R, Q_f for every agent of every item" the
+ * sweep evaluates linearize / quadraticize itself and reads only (X, U): 12 KB instead of 535 KB per cfg2 pass.  Gains
+ * are bit-identical to dpilqr_backward_pass.  DPILQR_EUNSUPPORTED for any other batch.  dpilqr_solve_batch picks it by
+ * itself. */
+int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
+                                   double* d, int32_t* singular, void* stream);
 /* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:
  * Xn[B][n_alpha][T+1][n_x], Un[B][n_alpha][T][n_u], Jn[B][n_alpha].                                  */
 int32_t dpilqr_forward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* K,

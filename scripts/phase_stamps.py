@@ -1,34 +1,57 @@
-"""Diagnostic: per-phase shader cycles of the tiled sweep (needs a -DDPILQR_PHASE_STAMPS build in /tmp)."""
-import ctypes as C, sys, os
+"""Diagnostic: per-phase shader cycles of the wavefront sweep (record-fed or fused), from in-kernel s_memtime stamps.
+Needs a -DDPILQR_PHASE_STAMPS build of the library: `python scripts/phase_stamps.py --build` makes build/libdpilqr_stamps.so
+(no GPU needed); then, on the GPU box, `python scripts/phase_stamps.py [B] [--fused]`."""
+import subprocess
+import sys
 from pathlib import Path
+
 import numpy as np
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import subprocess, torch
-so = "/tmp/libdpilqr_stamps.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-                "-DDPILQR_PHASE_STAMPS", f"-I{ROOT/'include'}", f"-I{ROOT/'dpilqr_amd'/'csrc'}", "-o", so,
-                str(ROOT/"dpilqr_amd"/"csrc"/"dpilqr_hip.hip")], check=True)
-from dpilqr_amd import _lib
-_lib.LIB_PATH = Path(so)
-import dpilqr_amd as dp
-from dpilqr_amd.device import empty, ptr, stream_handle, to_dev
-from bench import scenarios, K_AGENTS, T, N_U, N_X
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+so = ROOT / "build" / "libdpilqr_stamps.so"
+if "--build" in sys.argv:
+    so.parent.mkdir(exist_ok=True)
+    csrc = ROOT / "dpilqr_amd" / "csrc"
+    objs = []
+    procs = []
+    for src in sorted(csrc.glob("*.hip")):
+        obj = so.parent / f"stamps_{src.stem}.o"
+        objs.append(str(obj))
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                                       "-DDPILQR_PHASE_STAMPS", f"-I{ROOT / 'include'}", f"-I{csrc}", "-c", "-o", str(obj), str(src)]))
+    assert all(p.wait() == 0 for p in procs)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(so), *objs], check=True)
+    sys.exit(0)
+import torch  # noqa: E402
+from dpilqr_amd import _lib  # noqa: E402
+_lib.LIB_PATH = so
+import dpilqr_amd as dp  # noqa: E402
+from dpilqr_amd.device import empty, ptr, stream_handle, to_dev  # noqa: E402
+from bench import K_AGENTS, N_U, N_X, T, scenarios  # noqa: E402
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+fused = "--fused" in sys.argv
+B = int(args[0]) if args else 1024
 x0, xf = scenarios(0, B)
 pb = dp.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
-X, J = pb.rollout(x0, np.zeros((B, T, N_U))); U = torch.zeros((B, T, N_U), dtype=torch.float64, device="cuda")
-mu = to_dev(np.ones(B)); K = empty((B, T, N_U, N_X)); d = empty((B, T, N_U)); tl = pb.make_tiles(X, U)
+r = pb.solve(x0, np.zeros((B, T, N_U)), n_lqr_iter=2)       # an operating point where agents interact
+X, U = r["X"], r["U"]
+mu = to_dev(np.full(B, 0.125)); K = empty((B, T, N_U, N_X)); d = empty((B, T, N_U)); tl = pb.make_tiles(X, U)
 lib = _lib.load()
 buf = torch.zeros((B * 12,), dtype=torch.int64, device="cuda")
 _lib.check(lib.dpilqr_debug_stamps(ptr(buf)))
 for rep in range(3):
-    _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, 4, 2, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    if fused:
+        _lib.check(lib.dpilqr_backward_pass_fused(pb._d, ptr(X), ptr(U), ptr(mu), ptr(K), ptr(d), None, stream_handle()))
+    else:
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, T, N_X, N_U, 4, 2, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
 torch.cuda.synchronize()
 s = buf.cpu().numpy()
 ph = s[4 * B:].reshape(B, 8)[:, :7] / T
-names = ["S0 park AB", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6 sums, symmetrise", "-"]
+names = ["S0 park AB / pair derivatives", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6 sums, symmetrise", "-"]
 tot = ph.sum(1).mean()
 for n, v in zip(names, ph.mean(0)):
-    print(f"{n:22s} {v:8.0f} cycles/step  {100 * v / tot:5.1f} %")
+    print(f"{n:30s} {v:8.0f} cycles/step  {100 * v / tot:5.1f} %")
 print(f"total {tot:.0f} cycles/step (stamps serialise LDS at phase ends, so the sum is an upper bound)")
+dur = (s[:4 * B].reshape(B, 4)[:, 1] - s[:4 * B].reshape(B, 4)[:, 0]) / 100.0
+print(f"{'fused' if fused else 'record-fed'} sweep, {B} items: wavefront duration mean {dur.mean():.0f} us, max {dur.max():.0f} us")

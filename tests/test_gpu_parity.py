@@ -506,3 +506,33 @@ def test_fuzz_shapes_against_oracle(dp, seed, model, k, T, B, window):
             assert (nb[i], nf[i], st[i]) == (o["n_bwd"][i], o["n_fwd"][i], o["status"][i]), i
             assert relerr(Xs[i], o["X"][i]) < TOL_SOLVE, i
     assert np.isfinite(Xs).all()
+
+
+@pytest.mark.parametrize("k,B", [(5, 3000), (5, 1500), (5, 70), (4, 2600), (3, 1100), (2, 2100), (1, 333)])
+def test_fused_sweep_is_bit_identical_to_the_record_fed_sweep(dp, k, B):
+    """The sweep that evaluates linearize / quadraticize itself (no tile records) against the one that reads the tile
+    producer's records: same gains bit for bit, for all three wavefront layouts (B > 2048, > 1024, smaller) and 1..5
+    DoubleIntDynamics4D agents, at states where agents are inside each other's radius."""
+    import torch
+    from dpilqr_amd.device import to_dev
+    from dpilqr_amd.util import random_setup
+    T = 20
+    rng = np.random.default_rng(77 + k)
+    x0 = np.zeros((B, 4 * k)); xf = rng.normal(size=(B, 4 * k))
+    for s in range(B):
+        x0[s] = rng.normal(size=4 * k) * 0.6           # dense: most pairs interact
+    U0 = rng.normal(size=(B, T, 2 * k)) * 0.3
+    Q = np.array([[1.0, 0.2, 0, 0], [0.1, 1.5, 0, 0.3], [0, 0, 0.4, 0], [0, 0.2, 0, 0.1]])     # non-symmetric: exercises Q + Q^T
+    R = np.array([[1.0, 0.1], [0.3, 2.0]]); Qf = 50.0 * np.eye(4) + 0.5
+    pb = dp.ProblemBatch([0] * k, [2] * k, xf, Q, R, Qf, rng.uniform(0.3, 0.9, size=B), 0.1, T)
+    X, _ = pb.rollout(x0, U0)
+    mu = to_dev(rng.choice([0.0, 0.125, 1.0], size=B))
+    K0, d0 = pb.backward_pass(X, U0, mu)
+    K1, d1 = pb.backward_pass_fused(X, U0, mu)
+    assert torch.equal(K0, K1) and torch.equal(d0, d1)
+    # per-agent weights that differ: the fused sweep must refuse, not silently use the first agent's
+    if k > 1:
+        Qk = np.stack([Q * (1 + 0.1 * i) for i in range(k)])
+        pb2 = dp.ProblemBatch([0] * k, [2] * k, xf, Qk, R, Qf, 0.5, 0.1, T)
+        with pytest.raises(dp._lib.DpilqrError):
+            pb2.backward_pass_fused(X, U0, mu)
