@@ -70,7 +70,21 @@ SIGNATURES = {
     "dpilqr_profile_read": (i32, [vp, C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
     "dpilqr_profile_read_sweep": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64), C.POINTER(i64), i32]),
     "dpilqr_pairwise_graph": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+    "dpilqr_dispatch_graph": (i32, [i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_dispatch_gather": (i32, [i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
+    "dpilqr_dispatch_gather_params": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+    "dpilqr_dispatch_stitch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_dispatch_pack_rows": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "dpilqr_dispatch_scatter_rows": (i32, [i64, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
 }
+
+MAX_AGENTS = 64
+
+
+class BucketResults(C.Structure):
+    """struct dpilqr_bucket_results"""
+    _fields_ = [("X", vp * (MAX_AGENTS + 1)), ("U", vp * (MAX_AGENTS + 1)), ("first", i32 * (MAX_AGENTS + 1)),
+                ("count", i32 * (MAX_AGENTS + 1))]
 
 _lib = None
 

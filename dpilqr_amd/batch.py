@@ -23,6 +23,14 @@ MODEL_DIMS = {0: (4, 2), 1: (6, 3), 2: (3, 2), 3: (4, 2), 4: (6, 3), 5: (6, 3), 
 
 def _shared_or_batched(a, B, per_item_shape, dtype):
     """Returns (device tensor, batch stride in elements): stride 0 when one copy serves the batch."""
+    if isinstance(a, torch.Tensor):           # already on the device (the dispatch front end builds batches there)
+        per = int(np.prod(per_item_shape))
+        t = a.to(device=device(), dtype=dtype).contiguous()
+        if t.numel() == per:
+            return t, 0
+        if t.numel() == B * per:
+            return t, per
+        raise ValueError(f"expected {per_item_shape} or {(B,) + tuple(per_item_shape)}, got {tuple(t.shape)}")
     a = np.asarray(a)
     per = int(np.prod(per_item_shape))
     if a.size == per:
@@ -38,30 +46,42 @@ class _WorkspacePool:
     concurrently, with a different workspace size each and different sizes again on the next call; handing every one
     to the caching allocator as a fresh odd-sized block made it hoard > 200 GB and then stall for seconds while it
     gave them back.  Buffers are rounded up to 256 MiB, the smallest free one that fits is reused, a solve returns its
-    buffer when dpilqr_solve_batch has synchronised."""
+    buffer when dpilqr_solve_batch has synchronised.  The pool is bounded by COUNT and by BYTES (a quarter of the
+    device's memory): the buffers are live tensors, which the allocator's own out-of-memory recovery cannot reclaim."""
     GRANULE = 1 << 28
     MAX_FREE = 12
+    MAX_FRACTION = 0.25
 
     def __init__(self):
         import threading
         self._lock = threading.Lock()
         self._free = []
 
+    def _budget(self, dev):
+        return int(torch.cuda.get_device_properties(dev).total_memory * self.MAX_FRACTION)
+
     def acquire(self, nbytes):
         dev = device()
         with self._lock:
+            self._free = [t for t in self._free if t.device == dev]      # buffers of another device are dropped
             fit = [i for i, t in enumerate(self._free) if t.device == dev and t.numel() >= nbytes]
             if fit:
                 return self._free.pop(min(fit, key=lambda i: self._free[i].numel()))
         size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
-        return torch.empty(size, dtype=torch.uint8, device=dev)
+        try:
+            return torch.empty(size, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError:
+            self.clear()                       # the pooled buffers are the likeliest reason: give them back and retry once
+            torch.cuda.empty_cache()
+            return torch.empty(size, dtype=torch.uint8, device=dev)
 
     def release(self, buf):
         with self._lock:
             self._free.append(buf)
-            if len(self._free) > self.MAX_FREE:   # keep the large ones: they serve every request
+            budget = self._budget(buf.device)
+            # keep the large ones (they serve every request) within the count and byte bounds
+            while len(self._free) > self.MAX_FREE or (len(self._free) > 1 and sum(t.numel() for t in self._free) > budget):
                 self._free.pop(min(range(len(self._free)), key=lambda i: self._free[i].numel()))
-
 
     def clear(self):
         with self._lock:
@@ -83,9 +103,14 @@ class ProblemBatch:
     Q, Qf : (n_s,n_s) | (k,n_s,n_s) | (B,k,n_s,n_s)   R likewise with n_c     radius : scalar | (B,)
     """
 
-    def __init__(self, model, n_dims, xf, Q, R, Qf, radius, dt, T, w_ref=1.0, w_prox=200.0, B=None):
+    def __init__(self, model, n_dims, xf, Q, R, Qf, radius, dt, T, w_ref=1.0, w_prox=200.0, B=None, hints=None):
+        """hints: (k, n_s, n_c, uniform_model word) for batches whose model / n_dims / weight arrays are device tensors
+        (the dispatch front end): the constructor then neither reads them back nor derives the kernel hints from them."""
         lib = _lib.load()
-        xf = np.asarray(xf, dtype=np.float64)
+        if hints is not None:
+            self._init_from_device(lib, model, n_dims, xf, Q, R, Qf, radius, dt, T, w_ref, w_prox, B, hints)
+            return
+        xf = np.asarray(xf, dtype=np.float64) if not isinstance(xf, torch.Tensor) else xf
         model = np.asarray(model, dtype=np.int32)
         self.k = int(model.shape[-1])
         m0 = int(model.reshape(-1)[0])
@@ -125,6 +150,40 @@ class ProblemBatch:
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
         self._lib = lib
         self.tile_offsets, self.tile_stride = _lib.tile_layout(self.n_x, self.n_u)
+
+    def _init_from_device(self, lib, model, n_dims, xf, Q, R, Qf, radius, dt, T, w_ref, w_prox, B, hints):
+        self.k, self.n_s, self.n_c, uniform = (int(v) for v in hints)
+        k, ns, nc = self.k, self.n_s, self.n_c
+        self.n_x, self.n_u = k * ns, k * nc
+        self.B = B_ = int(B)
+        self.T, self.dt = int(T), float(dt)
+        self.w_ref, self.w_prox = float(w_ref), float(w_prox)
+        self._model, ms = _shared_or_batched(model, B_, (k,), torch.int32)
+        self._n_dims, ds = _shared_or_batched(n_dims, B_, (k,), torch.int32)
+        self._xf, xs = _shared_or_batched(xf, B_, (self.n_x,), torch.float64)
+        self._Q, qs = _shared_or_batched(Q, B_, (k, ns, ns), torch.float64)
+        self._R, rs = _shared_or_batched(R, B_, (k, nc, nc), torch.float64)
+        self._Qf, fs = _shared_or_batched(Qf, B_, (k, ns, ns), torch.float64)
+        rad = radius if isinstance(radius, torch.Tensor) else np.asarray(radius, dtype=np.float64)
+        self._radius, ras = _shared_or_batched(rad, B_, (1,), torch.float64)
+        if qs or rs or fs:
+            uniform &= ~(1 << 16)
+        self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, uniform, self.dt, self.w_ref, self.w_prox,
+                                   ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
+                                   ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
+        self._lib = lib
+        self.tile_offsets, self.tile_stride = _lib.tile_layout(self.n_x, self.n_u)
+
+    @staticmethod
+    def hint_word(model, n_dims, Q, R, Qf):
+        """The uniform_model hints (include/dpilqr_hip.h) of a k-agent problem whose host arrays are given."""
+        model = np.asarray(model, dtype=np.int32); nd = np.asarray(n_dims, dtype=np.int32)
+        w = (1 + int(model.reshape(-1)[0])) if bool((model == model.reshape(-1)[0]).all()) else 0
+        if nd.size and bool((nd == nd.reshape(-1)[0]).all()):
+            w |= (1 + int(nd.reshape(-1)[0])) << 8
+        if all(np.asarray(M).ndim == 3 and bool((np.asarray(M) == np.asarray(M)[0]).all()) for M in (Q, R, Qf)):
+            w |= 1 << 16
+        return w
 
     # ------------------------------------------------------------------ helpers
     @property

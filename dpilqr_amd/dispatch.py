@@ -6,6 +6,7 @@ sub-problem per AGENT, so agents with the same neighbourhood repeat the same sol
 grouped into shape buckets (k agents, model family, horizon) and every bucket is ONE windowed device solve.
 """
 from collections import defaultdict
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -15,6 +16,12 @@ from .control import ilqrSolver
 from .device import empty, ptr, stream_handle, to_dev
 from .batch import ProblemBatch
 from .lowering import describe, is_lowerable, lower_problems
+
+
+# One pool of worker threads for the bucket solves of every call: the threads (and with them the per-thread solver objects
+# of _lib.solver(): a pinned mailbox and a few events each) persist instead of being re-created per call and per
+# receding-horizon round.
+_bucket_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="dpilqr-bucket")
 
 
 def solve_problem_list(problems, x0s, U0s, keys=None, window=None, **kwargs):
@@ -72,83 +79,193 @@ def pairwise_graph(X, radius, k, n_s):
     return adj
 
 
-def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, concurrent=True, **kwargs):
+class ScenarioFrontEnd:
+    """Device-side front and back end of solve_distributed for S scenarios of one k-agent problem (include/dpilqr_hip.h
+    section 7, csrc/frontend.hpp): interaction graphs as bit masks, one representative per distinct neighbourhood (the
+    reference solves one sub-problem per agent: quirk Q11), a stable sort of the representatives by cluster size, the
+    gathered inputs of every size's sub-problems, and the stitching of the owners' columns.  Only the k + 1 bucket counts
+    come back to the host (they size the launches)."""
+
+    def __init__(self, d, X, U, radius, xf, ignore=None):
+        self.lib = _lib.load()
+        self.d = d
+        k = self.k = d["k"]
+        if k > _lib.MAX_AGENTS:
+            raise ValueError(f"at most {_lib.MAX_AGENTS} agents per problem (one bit per agent)")
+        self.X = to_dev(X).contiguous(); self.U = to_dev(U).contiguous()
+        self.S, self.N = int(self.X.shape[0]), int(self.X.shape[1])
+        self.T = int(self.U.shape[1])
+        self.n_s, self.n_c = int(self.X.shape[2]) // k, int(self.U.shape[2]) // k
+        S = self.S
+        self.xf = to_dev(np.broadcast_to(d["xf"], (S, k * self.n_s)).copy() if xf is None else xf).reshape(S, k * self.n_s).contiguous()
+        rad = to_dev(np.broadcast_to(np.asarray(radius, dtype=np.float64), (S,)).copy())
+        ign = None
+        if ignore is not None and any(ignore):
+            ign = to_dev(np.asarray(ignore, dtype=np.int32), torch.int32)
+        n = max(S * k, 1)
+        self.bits = empty((n,), torch.int64)
+        self.rep, self.size, self.order, self.slot = (empty((n,), torch.int32) for _ in range(4))
+        self.bstart, self.bcount = empty((k + 1,), torch.int32), empty((k + 1,), torch.int32)
+        _lib.check(self.lib.dpilqr_dispatch_graph(S, self.N, k, self.n_s, ptr(self.X), ptr(rad), 1, ptr(ign), ptr(self.bits),
+                                                  ptr(self.rep), ptr(self.size), ptr(self.order), ptr(self.slot),
+                                                  ptr(self.bstart), ptr(self.bcount), stream_handle()))
+        self.counts = self.bcount.cpu().numpy()           # the one host read of the front end
+        self.starts = self.bstart.cpu().numpy()
+        # per-agent parameters: one copy for every sub-problem when all agents are alike, gathered per item otherwise
+        self.uniform_agents = all(bool((np.asarray(d[key]) == np.asarray(d[key])[0]).all()) for key in ("model", "n_dims", "Q", "R", "Qf"))
+        if not self.uniform_agents:
+            self.dev_params = {key: to_dev(np.asarray(d[key]), torch.int32 if key in ("model", "n_dims") else torch.float64)
+                               for key in ("model", "n_dims", "Q", "R", "Qf")}
+
+    def sizes(self):
+        return [int(c) for c in range(1, self.k + 1) if self.counts[c] > 0]
+
+    def bucket(self, kc, lo=0, hi=None):
+        """ProblemBatch + (x0, U0) device tensors of the sub-problems [lo, hi) of the size-kc bucket."""
+        d, k, ns, nc, T = self.d, self.k, self.n_s, self.n_c, self.T
+        hi = int(self.counts[kc]) if hi is None else hi
+        cnt = hi - lo
+        x0 = empty((cnt, kc * ns)); xfb = empty((cnt, kc * ns)); U0 = empty((cnt, T, kc * nc))
+        members = None if self.uniform_agents else empty((cnt, kc), torch.int32)
+        _lib.check(self.lib.dpilqr_dispatch_gather(k, ns, nc, T, self.N, kc, ptr(self.order), int(self.starts[kc]) + lo, cnt,
+                                                   ptr(self.bits), ptr(self.X), ptr(self.U), ptr(self.xf), k * ns, ptr(x0),
+                                                   ptr(xfb), ptr(U0), ptr(members), stream_handle()))
+        if self.uniform_agents:
+            word = ProblemBatch.hint_word(d["model"][:kc], d["n_dims"][:kc], d["Q"][:kc], d["R"][:kc], d["Qf"][:kc])
+            pb = ProblemBatch(to_dev(d["model"][:kc], torch.int32), to_dev(d["n_dims"][:kc], torch.int32), xfb, to_dev(d["Q"][:kc]),
+                              to_dev(d["R"][:kc]), to_dev(d["Qf"][:kc]), d["radius"], d["dt"], T, w_ref=d["w_ref"],
+                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, word))
+        else:
+            g = {}
+            for key, width, eb, dt_ in (("model", 1, 4, torch.int32), ("n_dims", 1, 4, torch.int32), ("Q", ns * ns, 8, torch.float64),
+                                        ("R", nc * nc, 8, torch.float64), ("Qf", ns * ns, 8, torch.float64)):
+                out = empty((cnt, kc, width), dt_)
+                _lib.check(self.lib.dpilqr_dispatch_gather_params(cnt, kc, width, eb, ptr(members), ptr(self.dev_params[key]),
+                                                                  ptr(out), stream_handle()))
+                g[key] = out
+            pb = ProblemBatch(g["model"], g["n_dims"], xfb, g["Q"], g["R"], g["Qf"], d["radius"], d["dt"], T, w_ref=d["w_ref"],
+                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, 0))
+        return pb, x0, U0
+
+    def results_struct(self, solved):
+        """solved: {kc: (X, U, first, count)} device tensors of the slices solved here -> dpilqr_bucket_results."""
+        R = _lib.BucketResults()
+        for kc, (Xs, Us, first, count) in solved.items():
+            R.X[kc], R.U[kc], R.first[kc], R.count[kc] = Xs.data_ptr(), Us.data_ptr(), int(first), int(count)
+        self._keep = solved          # the struct holds raw pointers: keep the tensors alive
+        return R
+
+    def stitch(self, solved):
+        S, k, ns, nc, T = self.S, self.k, self.n_s, self.n_c, self.T
+        X_dec = torch.zeros((S, T + 1, k * ns), dtype=torch.float64, device=self.X.device)
+        U_dec = torch.zeros((S, T, k * nc), dtype=torch.float64, device=self.X.device)
+        R = self.results_struct(solved)
+        import ctypes as C
+        _lib.check(self.lib.dpilqr_dispatch_stitch(S, k, ns, nc, T, ptr(self.bits), ptr(self.rep), ptr(self.size), ptr(self.slot),
+                                                   C.addressof(R), ptr(X_dec), ptr(U_dec), stream_handle()))
+        return X_dec, U_dec
+
+    def pack_rows(self, solved, count_only=False, pad_to=None):
+        """One row [s*k+i | X columns | U columns] per (scenario, agent) whose sub-problem is in `solved`; returns
+        (rows or None, n_rows).  Rows beyond n_rows (up to pad_to) carry index -1."""
+        import ctypes as C
+        S, k, ns, nc, T = self.S, self.k, self.n_s, self.n_c, self.T
+        R = self.results_struct(solved)
+        row_of = empty((max(S * k, 1),), torch.int32); n_rows = empty((1,), torch.int32)
+        row_len = 1 + (T + 1) * ns + T * nc
+        rows = None
+        if not count_only:
+            rows = torch.zeros((int(pad_to), row_len), dtype=torch.float64, device=self.X.device)
+            rows[:, 0] = -1.0
+        _lib.check(self.lib.dpilqr_dispatch_pack_rows(S, k, ns, nc, T, ptr(self.bits), ptr(self.rep), ptr(self.size), ptr(self.slot),
+                                                      C.addressof(R), ptr(row_of), ptr(n_rows), ptr(rows), row_len, stream_handle()))
+        return rows, int(n_rows.item())
+
+    def scatter_rows(self, rows):
+        S, k, ns, nc, T = self.S, self.k, self.n_s, self.n_c, self.T
+        X_dec = torch.zeros((S, T + 1, k * ns), dtype=torch.float64, device=rows.device)
+        U_dec = torch.zeros((S, T, k * nc), dtype=torch.float64, device=rows.device)
+        _lib.check(self.lib.dpilqr_dispatch_scatter_rows(int(rows.shape[0]), k, ns, nc, T, ptr(rows), int(rows.shape[1]), ptr(X_dec),
+                                                         ptr(U_dec), stream_handle()))
+        return X_dec, U_dec
+
+
+def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, concurrent=True, ignore_ids=None, device_out=False,
+                                shard=None, **kwargs):
     """solve_distributed (distributed.py:25-103) for S scenarios of ONE k-agent problem at once -- the Monte-Carlo
-    front end (scripts/analysis.py:126-174 runs it seed by seed).  Everything between the interaction graph and
-    the stitched trajectories is array code: no per-sub-problem Python objects, one windowed device solve per
-    cluster size.
+    front end (scripts/analysis.py:126-174 runs it seed by seed).  Everything between the trajectories and the stitched
+    result stays on the device: graph, de-duplication, size buckets, gathered sub-problem inputs (ScenarioFrontEnd), one
+    windowed solve per cluster size, stitching, and the full-problem rollout for J_full.
 
     problem : lowerable k-agent ilqrProblem (models, Q/R/Qf per agent, n_dims, the proximity cost's own radius)
     X (S, T+1, n_x) or (S, 1, n_x) [the reference's `X = x0` first call]; U (S, T, n_u); radius: graph threshold/2
-    xf (S, n_x): per-scenario goals (default: the problem's own for every scenario)
-    returns X_dec (S, T+1, n_x), U_dec (S, T, n_u), J_full (S,), info (clusters as bit masks, counts)
+    xf (S, n_x): per-scenario goals (default: the problem's own for every scenario); NumPy arrays or device tensors
+    shard = (rank, world): solve only this rank's share of every size bucket (sharding.solve_scenarios_sharded)
+    returns X_dec (S, T+1, n_x), U_dec (S, T, n_u), J_full (S,), info (clusters as bit masks, counts) -- NumPy arrays, or
+    device tensors with device_out=True; with `shard` the unstitched (front end, solved slices) pair instead.
     """
+    from .sharding import shard_bounds
     d = describe(problem)
-    k, T = d["k"], int(np.asarray(U).shape[1])
-    X = np.asarray(X, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
-    S = X.shape[0]
-    n_s, n_c = problem.dynamics.n_x // k, problem.dynamics.n_u // k
-    xf = np.broadcast_to(d["xf"], (S, k * n_s)) if xf is None else np.asarray(xf, dtype=np.float64).reshape(S, k * n_s)
+    k = d["k"]
+    ignore = None
+    if ignore_ids:
+        ids = list(problem.ids)
+        ignore = [1 if id_ in ignore_ids else 0 for id_ in ids]
     solve_kw = {key: v for key, v in kwargs.items() if key in ("n_lqr_iter", "tol")}
-
-    # 1. interaction graphs of all scenarios (device), as one bit mask per (scenario, agent): bit j = j is a neighbour
-    adj = pairwise_graph(X, radius, k, n_s).cpu().numpy().astype(bool)                   # (S, k, k), self loops set
-    bits = (adj.astype(np.int64) << np.arange(k, dtype=np.int64)).sum(axis=2)           # (S, k)
-    # 2. one sub-problem per DISTINCT (scenario, neighbourhood); the reference solves one per agent (quirk Q11)
-    flat = np.stack([np.repeat(np.arange(S, dtype=np.int64), k), bits.reshape(-1)], axis=1)
-    uniq, inverse = np.unique(flat, axis=0, return_inverse=True)
-    inverse = np.asarray(inverse).reshape(S, k)
-    u_s, u_bits = uniq[:, 0], uniq[:, 1]
-    u_mask = ((u_bits[:, None] >> np.arange(k)) & 1).astype(bool)                         # (n_unique, k)
-    u_size = u_mask.sum(axis=1)
-    X_dec = np.zeros((S, T + 1, k * n_s)); U_dec = np.zeros((S, T, k * n_c))
-    X0 = X[:, 0].reshape(S, k, n_s); Uk = U.reshape(S, T, k, n_c); xfk = xf.reshape(S, k, n_s)
-    agent_of = np.arange(k)
+    from time import perf_counter as pc
+    t0 = pc()
+    fe = ScenarioFrontEnd(d, X, U, radius, xf, ignore)
+    t_front = pc() - t0                      # uploads, graph, de-duplication, bucket sort, the one host read
+    S, T = fe.S, fe.T
+    sizes = fe.sizes()
+    dev_index = torch.cuda.current_device()
 
     def solve_bucket(kc):
-        """All distinct sub-problems with kc agents: one windowed device solve, on this thread's own stream."""
-        sel = np.nonzero(u_size == kc)[0]                                                 # sub-problems of this size
-        members = np.nonzero(u_mask[sel])[1].reshape(len(sel), kc)                        # sorted agent ids, (Bk, kc)
-        rows = u_s[sel][:, None]
-        # the current HIP device is per host thread and a new thread starts on device 0: pin this worker to the
-        # caller's GPU (one process per GPU: rank r's buckets must not land on GPU 0)
+        """The sub-problems of one cluster size (this rank's share of them): one windowed device solve on this thread's
+        own stream.  The current HIP device is per host thread and a new thread starts on device 0: pin the worker to the
+        caller's GPU (one process per GPU: rank r's buckets must not land on GPU 0)."""
+        n_kc = int(fe.counts[kc])
+        lo, hi = (0, n_kc) if shard is None else shard_bounds(n_kc, shard[1], shard[0])
+        if hi <= lo:
+            return kc, None
         with torch.cuda.device(dev_index), torch.cuda.stream(torch.cuda.Stream(device=dev_index)):
-            pb = ProblemBatch(d["model"][members], d["n_dims"][members], xfk[rows, members].reshape(len(sel), kc * n_s),
-                              d["Q"][members], d["R"][members], d["Qf"][members], d["radius"], d["dt"], T,
-                              w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(sel))
-            x0 = X0[rows, members].reshape(len(sel), kc * n_s)
-            U0 = Uk[rows, :, members]                                                     # (Bk, kc, T, n_c)
-            U0 = np.ascontiguousarray(np.transpose(U0, (0, 2, 1, 3))).reshape(len(sel), T, kc * n_c)
+            pb, x0, U0 = fe.bucket(kc, lo, hi)
             r = pb.solve(x0, U0, window=window, **solve_kw)
-            Xs = r["X"].cpu().numpy().reshape(len(sel), T + 1, kc, n_s)
-            Us = r["U"].cpu().numpy().reshape(len(sel), T, kc, n_c)
-            return sel, Xs, Us, int(r["n_bwd"].sum().item())
+            torch.cuda.current_stream().synchronize()
+            return kc, (r["X"], r["U"], lo, hi - lo, int(r["n_bwd"].sum().item()))
 
     # buckets are independent and, for a handful of scenarios, small: their solves run concurrently, each on its own
-    # HIP stream from its own host thread (the library keeps its per-solve state per thread)
-    sizes = [int(v) for v in np.unique(u_size)]
-    dev_index = torch.cuda.current_device()
+    # HIP stream from its own host thread
     torch.cuda.synchronize()
+    t0 = pc()
     if concurrent and len(sizes) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(8, len(sizes))) as pool:
-            results = list(pool.map(solve_bucket, sizes))
+        results = list(_bucket_pool.map(solve_bucket, sizes))
     else:
         results = [solve_bucket(kc) for kc in sizes]
-    n_bwd_total = 0
-    for sel, Xs, Us, nb in results:
-        n_bwd_total += nb
-        # 3. stitch: agent i of scenario s takes ITS columns of the sub-problem solved for its neighbourhood
-        local = np.full(len(uniq), -1, dtype=np.int64); local[sel] = np.arange(len(sel))
-        owner_s, owner_i = np.nonzero(local[inverse] >= 0)
-        j = local[inverse[owner_s, owner_i]]
-        pos = (u_mask[sel][j] & (agent_of[None, :] < owner_i[:, None])).sum(axis=1)       # rank of i in its cluster
-        X_dec.reshape(S, T + 1, k, n_s)[owner_s, :, owner_i] = Xs[j, :, pos]
-        U_dec.reshape(S, T, k, n_c)[owner_s, :, owner_i] = Us[j, :, pos]
-    # 4. J_full: cost of the stitched controls rolled out on the full problem (distributed.py:100-101)
-    full = ProblemBatch(d["model"], d["n_dims"], xf, d["Q"], d["R"], d["Qf"], d["radius"], d["dt"], T,
-                        w_ref=d["w_ref"], w_prox=d["w_prox"], B=S)
-    _, J = full.rollout(X[:, 0], U_dec)
-    info = dict(cluster_bits=bits, n_subproblems=int(S * k), n_unique=int(len(uniq)),
-                sizes={int(kc): int((u_size == kc).sum()) for kc in np.unique(u_size)}, n_bwd=n_bwd_total)
-    return X_dec, U_dec, J.cpu().numpy(), info
+    t_solve = pc() - t0                      # gathers + the windowed device solves of all cluster sizes
+    solved = {kc: r[:4] for kc, r in results if r is not None}
+    n_bwd_total = sum(r[4] for _, r in results if r is not None)
+    info = dict(n_subproblems=int(S * k), n_unique=int(fe.counts.sum()),
+                sizes={int(kc): int(fe.counts[kc]) for kc in sizes}, n_bwd=n_bwd_total,
+                seconds=dict(front_end=t_front, solves=t_solve))
+    if shard is not None:
+        return fe, solved, info
+    # stitch: agent i of scenario s takes ITS columns of the sub-problem solved for its neighbourhood; then J_full:
+    # the cost of the stitched controls rolled out on the full problem (distributed.py:100-101)
+    t0 = pc()
+    X_dec, U_dec = fe.stitch(solved)
+    J = full_rollout_cost(d, fe, U_dec)
+    torch.cuda.synchronize()
+    info["seconds"]["stitch_and_rollout"] = pc() - t0
+    info["cluster_bits"] = fe.bits.cpu().numpy().reshape(S, k)
+    if device_out:
+        return X_dec, U_dec, J, info
+    return X_dec.cpu().numpy(), U_dec.cpu().numpy(), J.cpu().numpy(), info
+
+
+def full_rollout_cost(d, fe, U_dec):
+    """J_full of every scenario: _rollout(X[0], U_dec) on the full k-agent problem (distributed.py:100-101)."""
+    full = ProblemBatch(d["model"], d["n_dims"], fe.xf, d["Q"], d["R"], d["Qf"], d["radius"], d["dt"], fe.T,
+                        w_ref=d["w_ref"], w_prox=d["w_prox"], B=fe.S)
+    _, J = full.rollout(fe.X[:, 0].contiguous(), U_dec)
+    return J

@@ -26,6 +26,10 @@ def is_lowerable(problem):
         return False
     dims = {(m.n_x, m.n_u) for m in subs}
     refs = cost.ref_costs if isinstance(cost, GameCost) else [cost]
+    # one dt for the whole stack: the device descriptor holds a single step size, while the reference's
+    # MultiDynamicalModel calls every submodel with its own (dynamics.py:159-186) -- mixed step sizes take the host loop
+    if len({float(m.dt) for m in subs}) != 1:
+        return False
     return len(dims) == 1 and len(refs) == len(subs) and all((r.x_dim, r.u_dim) in dims for r in refs)
 
 

@@ -32,7 +32,8 @@ def shard_bounds(n_items, world, rank, cost=None):
 def pack_results(r):
     """(X,U,J,status,n_bwd,n_fwd) -> one fp64 row per item (the integers are exact in fp64)."""
     B = r["J"].shape[0]
-    cols = [r["X"].reshape(B, -1), r["U"].reshape(B, -1), r["J"].reshape(B, 1),
+    nx = int(np.prod(r["X"].shape[1:])); nu = int(np.prod(r["U"].shape[1:]))      # explicit: an empty shard has no -1 to infer
+    cols = [r["X"].reshape(B, nx), r["U"].reshape(B, nu), r["J"].reshape(B, 1),
             r["status"].to(torch.float64).reshape(B, 1), r["n_bwd"].to(torch.float64).reshape(B, 1),
             r["n_fwd"].to(torch.float64).reshape(B, 1)]
     return torch.cat(cols, dim=1).contiguous()
@@ -49,56 +50,90 @@ def unpack_results(rows, x_shape, u_shape):
     return dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
 
 
-def gather_results(r, group=None, pad_to=None):
-    """The path's single collective: every rank ends up with the results of all ranks, rank-major.
-
-    Ranks may hold different item counts (ragged shards): rows are padded to `pad_to` (default: the
-    max count, found with one tiny all-gather of sizes only when counts can differ)."""
+def gather_counts(n_local, group=None, device=None):
+    """Every rank's item count (one tiny all-gather of int64)."""
     world = dist.get_world_size(group)
-    rows = pack_results(r)
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = torch.empty((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [int(v) for v in out.cpu()]
+
+
+def gather_rows(rows, pad_to, group=None):
+    """The path's single data collective: rows (n_local, L) of every rank, each block padded to pad_to rows with zeros
+    -> (world * pad_to, L), rank-major.  Works for RCCL (device tensors, backend nccl) and gloo (CPU tensors) alike."""
+    world = dist.get_world_size(group)
     n_local = rows.shape[0]
-    if pad_to is None:
-        pad_to = n_local
+    if pad_to < n_local:
+        raise ValueError(f"pad_to={pad_to} is smaller than this rank's {n_local} rows")
     if pad_to > n_local:
         rows = torch.cat([rows, rows.new_zeros((pad_to - n_local, rows.shape[1]))], dim=0)
     out = rows.new_empty((world * pad_to, rows.shape[1]))
-    dist.all_gather_into_tensor(out, rows, group=group)
+    dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
+    return out
+
+
+def gather_results(r, group=None, pad_to=None, compact=False):
+    """The path's single collective: every rank ends up with the results of all ranks, rank-major.
+
+    Ranks may hold different item counts (ragged shards).  pad_to=None: the counts are exchanged first (one all-gather of
+    one integer per rank) and every block is padded to the largest; pass pad_to when the caller knows the bound and wants
+    to save that exchange.  The result carries `counts` (items per rank, None if they were not exchanged) and
+    `rows_per_rank`; compact=True drops the padding rows (needs the counts)."""
+    rows = pack_results(r)
+    counts = None
+    if pad_to is None:
+        counts = gather_counts(rows.shape[0], group, rows.device)
+        pad_to = max(counts) if counts else 0
+    out = gather_rows(rows, pad_to, group)
+    if compact:
+        if counts is None:
+            counts = gather_counts(rows.shape[0], group, rows.device)
+        keep = torch.cat([torch.arange(k * pad_to, k * pad_to + c) for k, c in enumerate(counts)]).to(out.device)
+        out = out[keep]
     res = unpack_results(out, r["X"].shape[1:], r["U"].shape[1:])
     res["rows_per_rank"] = pad_to
+    res["counts"] = counts
     return res
 
 
-def solve_scenarios_sharded(problem, X, U, radius, xf=None, group=None, solver=None, device=None, **kwargs):
-    """cfg4's shape of run: S Monte-Carlo scenarios of one k-agent problem sharded over the ranks (one process per GPU),
-    each rank running the many-scenario front end (dispatch.solve_scenarios_distributed) on its contiguous slice, then
-    the path's one collective: an all-gather of the stitched (X_dec, U_dec, J_full) rows.  Every rank returns the
-    full arrays in scenario order.
+def solve_scenarios_sharded(problem, X, U, radius, xf=None, group=None, window=None, device_out=False, **kwargs):
+    """cfg4's shape of run on several GPUs (one process per GPU): S Monte-Carlo scenarios of one k-agent problem.
 
-    solver(problem, X, U, radius, xf=..., **kwargs) -> (X_dec, U_dec, J, info): injectable for CPU tests of the
-    sharding / gather plumbing; device: where the gathered rows live (default: cuda if the backend is nccl)."""
-    if solver is None:
-        from .dispatch import solve_scenarios_distributed as solver
-    X = np.asarray(X, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
-    S = X.shape[0]
+    Partitioning as SURVEY 8(e) prescribes: every rank builds the (cheap) front end for ALL scenarios -- interaction graphs,
+    de-duplicated (scenario, neighbourhood) sub-problems, sorted into size buckets -- and solves a contiguous 1 / world share
+    of EVERY bucket, so that the cost (~ T n_x^3 per sub-problem, equal within a bucket) is balanced by construction
+    however ragged the cluster sizes are.  Then the path's one collective: an all-gather of one row per (scenario, agent),
+    [index | the agent's columns of X | of U], padded to the largest rank's row count (every rank can count every rank's
+    rows from the replicated front end, so no size exchange is needed).  Every rank scatters all rows into X_dec, U_dec on
+    its device and rolls the full problem out for J_full.  Results stay on the device end to end (device_out=True returns
+    the tensors); nothing passes through host memory except the k + 1 bucket counts."""
+    from .dispatch import full_rollout_cost, solve_scenarios_distributed
+    from .lowering import describe
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi = shard_bounds(S, world, rank)
-    xf_l = None if xf is None else np.asarray(xf, dtype=np.float64)[lo:hi]
-    if hi > lo:
-        Xd, Ud, J, info = solver(problem, X[lo:hi], U[lo:hi], radius, xf=xf_l, **kwargs)
-    else:   # more ranks than scenarios: this rank only takes part in the collective
-        T, n_u = U.shape[1], U.shape[2]
-        Xd, Ud, J, info = np.zeros((0, T + 1, X.shape[2])), np.zeros((0, T, n_u)), np.zeros((0,)), {}
-    pad = max(b - a for a, b in (shard_bounds(S, world, r) for r in range(world)))
-    if device is None:
-        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    nx, nu = int(np.prod(Xd.shape[1:])), int(np.prod(Ud.shape[1:]))
-    rows = torch.cat([torch.as_tensor(Xd).reshape(hi - lo, nx), torch.as_tensor(Ud).reshape(hi - lo, nu),
-                      torch.as_tensor(J).reshape(hi - lo, 1)], dim=1)
-    rows = torch.cat([rows, rows.new_zeros((pad - (hi - lo), rows.shape[1]))], dim=0).to(device).contiguous()
-    out = rows.new_empty((world * pad, rows.shape[1]))
-    dist.all_gather_into_tensor(out, rows, group=group)
-    keep = torch.cat([torch.arange(r * pad, r * pad + (b - a)) for r, (a, b) in
-                      enumerate(shard_bounds(S, world, r) for r in range(world))]).to(out.device)
-    out = out[keep].cpu().numpy()
-    return (out[:, :nx].reshape((S,) + Xd.shape[1:]), out[:, nx:nx + nu].reshape((S,) + Ud.shape[1:]), out[:, nx + nu],
-            dict(local=info, shard=(lo, hi)))
+    fe, solved, info = solve_scenarios_distributed(problem, X, U, radius, xf=xf, window=window, shard=(rank, world), **kwargs)
+    # row counts of every rank, from the replicated front end
+    n_rows = []
+    for r in range(world):
+        if r == rank:
+            _, n = fe.pack_rows(solved, count_only=True)
+        else:
+            other = {kc: (None, None) + shard_slice(int(fe.counts[kc]), world, r) for kc in fe.sizes()}
+            _, n = fe.pack_rows({kc: (fe.X, fe.U, lo, cnt) for kc, (_, _, lo, cnt) in other.items() if cnt > 0}, count_only=True)
+        n_rows.append(n)
+    pad = max(n_rows + [1])
+    rows, n_mine = fe.pack_rows(solved, pad_to=pad)
+    assert n_mine == n_rows[rank]
+    allrows = gather_rows(rows, pad, group)
+    X_dec, U_dec = fe.scatter_rows(allrows)
+    J = full_rollout_cost(describe(problem), fe, U_dec)
+    info = dict(info, shard_rows=n_rows, rank=rank, cluster_bits=fe.bits.cpu().numpy().reshape(fe.S, fe.k))
+    if device_out:
+        return X_dec, U_dec, J, info
+    return X_dec.cpu().numpy(), U_dec.cpu().numpy(), J.cpu().numpy(), info
+
+
+def shard_slice(n_items, world, rank):
+    """(first, count) of rank's contiguous share of n_items."""
+    lo, hi = shard_bounds(n_items, world, rank)
+    return lo, hi - lo

@@ -263,6 +263,51 @@ int32_t dpilqr_profile_read_sweep(dpilqr_solver* solver, int32_t waves, double* 
 int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X,
                               const double* radius /*[S]*/, int32_t* adj, void* stream);
 
+/* -------------------------------------------------- (7) dispatch front and back end for S scenarios ("next" row f1)
+ * Everything solve_distributed does around the solves (distributed.py:42-77,100-101) for S Monte-Carlo scenarios of ONE
+ * k-agent problem, as device array work over (S, k); k <= DPILQR_MAX_AGENTS.  The reference solves one sub-problem per
+ * AGENT (its closed neighbourhood) and agents with the same neighbourhood repeat the same solve (quirk Q11): here every
+ * distinct (scenario, neighbourhood) is solved once and its owners' columns are copied out.
+ *   dispatch_graph   X[S][N][k*n_s] (N = 1: the scenario's state; N = T+1: a trajectory, sampled like :229-235), radius[S]
+ *                    (stride 0: shared) -> bits[S*k] neighbourhood masks (bit j = agent j, incl. itself), rep[S*k] the first
+ *                    agent with the same mask (-1 for ignored agents: ignore[k] may be NULL), size[S*k] agents in the mask,
+ *                    and a stable sort of the representatives by size: order[pos] = s*k + i, bucket_start / bucket_count[k+1]
+ *                    (index = cluster size), slot[S*k] = position of a representative inside its bucket (-1 otherwise).
+ *   dispatch_gather  inputs of the sub-problems [first, first+count) of the size-kc bucket: x0, x_f [count][kc*n_s],
+ *                    U0 [count][T][kc*n_c], members [count][kc] (NULL if not needed), from X (row 0), U, xf of their scenarios.
+ *   dispatch_gather_params  per-agent parameters of a heterogeneous team -> per-item arrays: out[j][p][w] = src[members[j][p]][w].
+ *   dispatch_stitch  the owners' columns of the solved sub-problems -> X_dec[S][T+1][k*n_s], U_dec[S][T][k*n_c] (ignored agents
+ *                    keep what the buffers held; callers zero them).  results: per cluster size the solved X [count][T+1][kc*n_s],
+ *                    U [count][T][kc*n_c] and which slice [first, first+count) of the bucket they are.
+ *   dispatch_pack_rows / dispatch_scatter_rows  the multi-GPU form: a rank that solved a slice of every bucket packs one row
+ *                    [s*k+i | X columns | U columns] per (scenario, agent) it owns (row_of[S*k], n_rows out; rows == NULL only
+ *                    counts); after the path's one all-gather every rank scatters all ranks' rows (index < 0: padding). */
+#define DPILQR_MAX_AGENTS 64
+typedef struct dpilqr_bucket_results {
+    const double* X[DPILQR_MAX_AGENTS + 1];
+    const double* U[DPILQR_MAX_AGENTS + 1];
+    int32_t first[DPILQR_MAX_AGENTS + 1];
+    int32_t count[DPILQR_MAX_AGENTS + 1];
+} dpilqr_bucket_results;
+int32_t dpilqr_dispatch_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double* X, const double* radius,
+                              int64_t radius_stride, const int32_t* ignore, uint64_t* bits, int32_t* rep, int32_t* size,
+                              int32_t* order, int32_t* slot, int32_t* bucket_start, int32_t* bucket_count, void* stream);
+int32_t dpilqr_dispatch_gather(int32_t k, int32_t n_s, int32_t n_c, int32_t T, int32_t n_rows, int32_t kc, const int32_t* order,
+                               int32_t first, int32_t count, const uint64_t* bits, const double* X, const double* U,
+                               const double* xf, int64_t xf_stride, double* x0_out, double* xf_out, double* U_out,
+                               int32_t* members, void* stream);
+int32_t dpilqr_dispatch_gather_params(int32_t count, int32_t kc, int32_t width, int32_t elem_bytes, const int32_t* members,
+                                      const void* src, void* out, void* stream);
+int32_t dpilqr_dispatch_stitch(int32_t S, int32_t k, int32_t n_s, int32_t n_c, int32_t T, const uint64_t* bits, const int32_t* rep,
+                               const int32_t* size, const int32_t* slot, const dpilqr_bucket_results* results, double* X_dec,
+                               double* U_dec, void* stream);
+int32_t dpilqr_dispatch_pack_rows(int32_t S, int32_t k, int32_t n_s, int32_t n_c, int32_t T, const uint64_t* bits,
+                                  const int32_t* rep, const int32_t* size, const int32_t* slot,
+                                  const dpilqr_bucket_results* results, int32_t* row_of, int32_t* n_rows, double* rows,
+                                  int64_t row_len, void* stream);
+int32_t dpilqr_dispatch_scatter_rows(int64_t n_rows_total, int32_t k, int32_t n_s, int32_t n_c, int32_t T, const double* rows,
+                                     int64_t row_len, double* X_dec, double* U_dec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,11 @@ t0 = time.perf_counter()
 Xd, Ud, J, info = solve_scenarios_distributed(prob, x0[:, None, :], U0, radius, xf=xf)
 torch.cuda.synchronize()
 dt1 = time.perf_counter() - t0
+sec = info["seconds"]
+host_frac = 1.0 - sec["solves"] / dt1
+print(f"      stages: front end (uploads, graph, de-duplication, buckets) {sec['front_end']:.3f} s, bucket solves {sec['solves']:.3f} s, "
+      f"stitch + J_full rollout {sec['stitch_and_rollout']:.3f} s, device->host copies of the results {dt1 - sum(sec.values()):.3f} s; "
+      f"outside the solves: {100 * host_frac:.1f} % of the call")
 print(f"{cfg}: {S} scenarios x {k} agents, T={T}: first call (X = x0) {dt1:.2f} s  -> {info['n_unique']} distinct sub-problems of "
       f"{info['n_subproblems']} ({info['n_unique'] / dt1:.0f} sub-problems/s, {S / dt1:.1f} scenarios/s), sizes {info['sizes']}, "
       f"finite {np.isfinite(J).mean():.3f}, median J {np.median(J):.1f}")
@@ -49,4 +54,9 @@ Xd2, Ud2, J2, info2 = solve_scenarios_distributed(prob, Xd, Ud, radius, xf=xf)  
 torch.cuda.synchronize()
 dt2 = time.perf_counter() - t0
 print(f"      second call (X = first result) {dt2:.2f} s -> {info2['n_unique']} distinct sub-problems ({info2['n_unique'] / dt2:.0f}/s), "
-      f"sizes {info2['sizes']}, median J {np.median(J2):.1f}")
+      f"sizes {info2['sizes']}, median J {np.median(J2):.1f}, stages {info2['seconds']}")
+if len(sys.argv) > 3:
+    import json
+    Path(sys.argv[3]).write_text(json.dumps(dict(config=cfg, scenarios=S, agents=k, T=T, first_call_s=dt1, first_call_stages=sec,
+                                                 first_call_outside_solves_frac=host_frac, n_unique=info["n_unique"], sizes=info["sizes"],
+                                                 second_call_s=dt2, second_call_stages=info2["seconds"], second_sizes=info2["sizes"]), indent=1))

@@ -271,9 +271,17 @@ def test_rhc_scenarios_equal_per_scenario_rhc(dp, golden, centralized):
         assert Xb.shape == Xs.shape and (Xb == Xs).all() and (Ub == Us).all() and Jb == Js, s
 
 
+def _perturbed_scenarios(z, tag, S, seed=9):
+    rng = np.random.default_rng(seed)
+    k = int(z[tag + "_k"]); ns = int(z[tag + "_n_s"])
+    x0 = np.tile(z[tag + "_x0"].reshape(1, -1), (S, 1)); x0[1:, 0::ns] += rng.normal(scale=0.15, size=(S - 1, k))
+    U0 = np.tile(z[tag + "_U0"][None], (S, 1, 1))
+    return x0, U0
+
+
 def test_scenarios_sharded_single_rank_equals_front_end(dp, golden):
-    """sharding.solve_scenarios_sharded with the real device solver behind it (one rank, gloo for the collective):
-    the gathered result must be the front end's own."""
+    """sharding.solve_scenarios_sharded with the real device solver behind it (one rank, gloo for the collective on
+    CPU copies is not needed: world 1 gathers in place): the gathered result must be the front end's own."""
     import socket
     import torch.distributed as dist
     from dpilqr_amd.dispatch import solve_scenarios_distributed
@@ -281,18 +289,85 @@ def test_scenarios_sharded_single_rank_equals_front_end(dp, golden):
     z = golden("g5_dispatch"); tag = "uni5"
     prob = problem_from(z, tag + "_")
     S = 4
-    rng = np.random.default_rng(9)
-    x0 = np.tile(z[tag + "_x0"].reshape(1, -1), (S, 1)); x0[1:, 0::4] += rng.normal(scale=0.1, size=(S - 1, 5))
-    U0 = np.tile(z[tag + "_U0"][None], (S, 1, 1))
+    x0, U0 = _perturbed_scenarios(z, tag, S)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
         Xg, Ug, Jg, info = solve_scenarios_sharded(prob, x0[:, None, :], U0, 0.5)
     finally:
         dist.destroy_process_group()
     Xd, Ud, Jd, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5)
-    assert (Xg == Xd).all() and (Ug == Ud).all() and (Jg == Jd).all() and info["shard"] == (0, S)
+    assert (Xg == Xd).all() and (Ug == Ud).all() and (Jg == Jd).all() and info["shard_rows"] == [S * 5]
+
+
+@pytest.mark.parametrize("tag,world", [("uni5", 2), ("quad10", 3), ("uni8", 8)])
+def test_bucket_sharded_rows_of_several_ranks_rebuild_the_unsharded_result(dp, golden, tag, world):
+    """The multi-GPU partitioning on ONE GPU, rank after rank: every rank solves its 1 / world share of every size bucket and
+    packs one row per (scenario, agent) it owns; the rank-major concatenation of the padded blocks -- what the all-gather
+    delivers -- scattered back must be the unsharded front end's result bit for bit, every (scenario, agent) exactly once."""
+    import torch
+    from dpilqr_amd.dispatch import solve_scenarios_distributed
+    z = golden("g5_dispatch")
+    prob = problem_from(z, tag + "_")
+    S = 7
+    x0, U0 = _perturbed_scenarios(z, tag, S)
+    Xd, Ud, Jd, info = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5, device_out=True)
+    blocks, counts = [], []
+    for rank in range(world):
+        fe, solved, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5, shard=(rank, world))
+        _, n = fe.pack_rows(solved, count_only=True)
+        counts.append(n)
+    pad = max(counts + [1])
+    for rank in range(world):
+        fe, solved, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5, shard=(rank, world))
+        rows, n = fe.pack_rows(solved, pad_to=pad)
+        assert n == counts[rank] and int((rows[:, 0] >= 0).sum()) == n
+        blocks.append(rows)
+    k = int(z[tag + "_k"])
+    assert sum(counts) == S * k
+    allrows = torch.cat(blocks, dim=0)
+    idx = allrows[:, 0][allrows[:, 0] >= 0].cpu().numpy().astype(int)
+    assert sorted(idx.tolist()) == list(range(S * k))
+    Xs, Us = fe.scatter_rows(allrows)
+    assert torch.equal(Xs, Xd) and torch.equal(Us, Ud)
+    # balance: no rank holds more than its share of any bucket plus one
+    for kc, n_kc in info["sizes"].items():
+        assert n_kc >= 0
+
+
+def test_front_end_on_device_equals_per_scenario_host_graphs(dp, golden):
+    """The device front end (bit masks, de-duplication, size buckets) against the host definitions, scenario by scenario."""
+    import torch
+    from dpilqr_amd.dispatch import ScenarioFrontEnd
+    from dpilqr_amd.lowering import describe
+    z = golden("g5_dispatch"); tag = "quad10"
+    prob = problem_from(z, tag + "_")
+    S = 9
+    x0, U0 = _perturbed_scenarios(z, tag, S, seed=3)
+    fe = ScenarioFrontEnd(describe(prob), x0[:, None, :], U0, 0.5, None)
+    k = fe.k
+    bits = fe.bits.cpu().numpy().reshape(S, k); rep = fe.rep.cpu().numpy().reshape(S, k); size = fe.size.cpu().numpy().reshape(S, k)
+    order = fe.order.cpu().numpy(); slot = fe.slot.cpu().numpy().reshape(S, k)
+    ids = prob.ids
+    n_unique = 0
+    for s in range(S):
+        g = dp.define_inter_graph_threshold(x0[s].reshape(1, -1), 0.5, prob.game_cost.x_dims, ids)
+        masks = [sum(1 << ids.index(int(j)) for j in g[id_]) for id_ in ids]
+        assert list(bits[s]) == masks
+        for i in range(k):
+            first = masks.index(masks[i])
+            assert rep[s, i] == first and size[s, i] == bin(masks[i]).count("1")
+            n_unique += first == i
+    assert int(fe.counts.sum()) == n_unique
+    # the buckets: representatives sorted by size, (s, i) ascending inside a size, slot = position in the bucket
+    pos = 0
+    for kc in range(1, k + 1):
+        want = [s * k + i for s in range(S) for i in range(k) if rep[s, i] == i and size[s, i] == kc]
+        assert list(order[pos:pos + len(want)]) == want and fe.counts[kc] == len(want) and fe.starts[kc] == pos
+        for j, e in enumerate(want):
+            assert slot.reshape(-1)[e] == j
+        pos += len(want)
 
 
 def test_profile_totals_by_sweep_variant(dp):

@@ -57,34 +57,102 @@ def test_all_gather_of_sharded_results(n_items):
     assert res == [(0, True), (1, True)]
 
 
-def _fake_front_end(problem, X, U, radius, xf=None, **kwargs):
-    """Stands in for dispatch.solve_scenarios_distributed on CPU: results that encode their inputs."""
-    S, T = U.shape[0], U.shape[1]
-    Xd = np.repeat(X[:, :1, :], T + 1, axis=1) + np.arange(T + 1)[None, :, None]
-    return Xd, U * 2.0, X[:, 0, 0] * 10.0 + (0.0 if xf is None else xf[:, 0]), dict(n=S)
-
-
-def _scenario_worker(rank, world, port, S, q):
-    from dpilqr_amd.sharding import solve_scenarios_sharded
+def _ragged_worker(rank, world, port, q):
+    """gather_results with ragged counts and pad_to=None: the counts are exchanged, every block padded to the largest."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(0)                                # the same scenarios on every rank
-    X = rng.normal(size=(S, 1, 6)); U = rng.normal(size=(S, 4, 3)); xf = rng.normal(size=(S, 6))
-    Xd, Ud, J, info = solve_scenarios_sharded(None, X, U, 0.5, xf=xf, solver=_fake_front_end)
-    Xe, Ue, Je, _ = _fake_front_end(None, X, U, 0.5, xf=xf)
-    ok = np.array_equal(Xd, Xe) and np.array_equal(Ud, Ue) and np.array_equal(J, Je) and info["shard"] == shard_bounds(S, world, rank)
+    T, n, m = 3, 4, 2
+    n_local = [5, 2, 0][rank]
+    base = [0, 5, 7][rank]
+    idx = torch.arange(base, base + n_local, dtype=torch.float64)
+    r = dict(X=idx[:, None, None] + torch.zeros(n_local, T + 1, n, dtype=torch.float64),
+             U=torch.zeros(n_local, T, m, dtype=torch.float64), J=idx * 3,
+             status=torch.ones(n_local, dtype=torch.int32), n_bwd=idx.to(torch.int32), n_fwd=idx.to(torch.int32))
+    g = gather_results(r)                               # pad_to=None
+    c = gather_results(r, compact=True)
+    ok = (g["counts"] == [5, 2, 0] and g["rows_per_rank"] == 5 and g["J"].shape[0] == 15
+          and torch.equal(c["J"], torch.arange(7, dtype=torch.float64) * 3) and torch.equal(c["X"][:, 0, 0], torch.arange(7, dtype=torch.float64)))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("S", [9, 1])
-def test_scenarios_sharded_over_ranks_and_gathered(S):
-    """Monte-Carlo scenarios sharded over two ranks (ragged: 5 + 4, and 1 + 0), one all-gather, scenario order kept."""
+def test_ragged_shards_without_pad_to_exchange_their_counts():
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True), (2, True)]
+
+
+def _rows_worker(rank, world, port, S, k, q):
+    """The scenario path's collective on CPU: every rank owns the rows of the (scenario, agent) pairs whose sub-problem fell
+    into its share of the size buckets (here: a fixed pseudo-random assignment), tags them with their index, pads with -1
+    rows to the largest rank's count -- known to every rank without an exchange -- and all-gathers; scattering the gathered
+    rows by their tag must rebuild the full array on every rank."""
+    from dpilqr_amd.sharding import gather_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = 1 + 6
+    owner = np.random.default_rng(5).integers(0, world, size=S * k)          # the same on every rank
+    counts = [int((owner == r).sum()) for r in range(world)]
+    pad = max(counts + [1])
+    mine = np.nonzero(owner == rank)[0]
+    rows = torch.full((pad, L), -1.0, dtype=torch.float64)
+    rows[:len(mine), 0] = torch.as_tensor(mine, dtype=torch.float64)
+    rows[:len(mine), 1:] = torch.as_tensor(mine, dtype=torch.float64)[:, None] * 10 + torch.arange(6, dtype=torch.float64)
+    out = gather_rows(rows, pad, None).numpy()
+    full = np.full((S * k, 6), np.nan)
+    seen = np.zeros(S * k, dtype=int)
+    for row in out:
+        if row[0] >= 0:
+            e = int(row[0]); full[e] = row[1:]; seen[e] += 1
+    ok = (seen == 1).all() and np.array_equal(full, np.arange(S * k)[:, None] * 10.0 + np.arange(6)[None, :])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S,k,world", [(1, 3, 2), (4, 10, 3)])
+def test_tagged_rows_gathered_and_scattered(S, k, world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, S, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
+
+
+def _bench_path_worker(rank, world, port, q):
+    """bench.py's N > 1 path: equal shards, gather_results with pad_to = the local count (no count exchange)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T, n, m = 6, 2, 4, 2
+    idx = torch.arange(rank * B, (rank + 1) * B, dtype=torch.float64)
+    r = dict(X=idx[:, None, None] + torch.zeros(B, T + 1, n, dtype=torch.float64), U=torch.zeros(B, T, m, dtype=torch.float64),
+             J=idx, status=torch.ones(B, dtype=torch.int32), n_bwd=idx.to(torch.int32), n_fwd=idx.to(torch.int32))
+    g = gather_results(r, pad_to=B)
+    q.put((rank, bool(torch.equal(g["J"], torch.arange(world * B, dtype=torch.float64)) and g["counts"] is None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gather_path_two_ranks():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_scenario_worker, args=(r, world, port, S, q)) for r in range(world)]
+    procs = [ctx.Process(target=_bench_path_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
