@@ -81,8 +81,11 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         DPILQR_TRY_WG(11, 4, 2) DPILQR_TRY_WG(12, 4, 2) DPILQR_TRY_WG(13, 4, 2) DPILQR_TRY_WG(14, 4, 2) DPILQR_TRY_WG(15, 4, 2)
         DPILQR_TRY_WG(2, 6, 3) DPILQR_TRY_WG(3, 6, 3) DPILQR_TRY_WG(4, 6, 3) DPILQR_TRY_WG(5, 6, 3) DPILQR_TRY_WG(6, 6, 3)
         DPILQR_TRY_WG(7, 6, 3) DPILQR_TRY_WG(8, 6, 3) DPILQR_TRY_WG(9, 6, 3) DPILQR_TRY_WG(10, 6, 3)
-        // Quadcopter12D, 2..5 agents
+        // Quadcopter12D / the padded human, 2..5 agents
         DPILQR_TRY_WG(2, 12, 4) DPILQR_TRY_WG(3, 12, 4) DPILQR_TRY_WG(4, 12, 4) DPILQR_TRY_WG(5, 12, 4)
+        // single six- and twelve-state agents (cfg4's k = 1 bucket, selfish_warmstart); CarDynamics3D pairs (n_x even)
+        DPILQR_TRY_WG(1, 6, 3) DPILQR_TRY_WG(1, 12, 4)
+        DPILQR_TRY_WG(2, 3, 2) DPILQR_TRY_WG(4, 3, 2) DPILQR_TRY_WG(6, 3, 2)
 #undef DPILQR_TRY_WG
     }
     if (pick <= 1) {

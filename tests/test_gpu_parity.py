@@ -536,3 +536,23 @@ def test_fused_sweep_is_bit_identical_to_the_record_fed_sweep(dp, k, B):
         pb2 = dp.ProblemBatch([0] * k, [2] * k, xf, Qk, R, Qf, 0.5, 0.1, T)
         with pytest.raises(dp._lib.DpilqrError):
             pb2.backward_pass_fused(X, U0, mu)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
+def test_sweep_three_state_family(dp, k):
+    """CarDynamics3D (3 states / 2 controls): even agent counts take the workgroup-per-item sweep, odd ones the size-generic
+    kernel; gains against the oracle, many items per launch, per-item mu."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    rng = np.random.default_rng(60 + k)
+    B, T = 37, 12
+    xf = rng.normal(size=(B, 3 * k)) * 2; x0 = rng.normal(size=(B, 3 * k)) * 0.8; U = rng.normal(size=(B, T, 2 * k)) * 0.5
+    Q, R, Qf = np.eye(3), np.eye(2), 100.0 * np.eye(3)
+    pb = dp.ProblemBatch([2] * k, [2] * k, xf, Q, R, Qf, 0.6, 0.1, T)
+    X, _ = pb.rollout(x0, U)
+    mu = rng.uniform(0, 1, size=B)
+    K, d = pb.backward_pass(X, U, to_dev(mu))
+    for i in range(0, B, 6):
+        p = orc.Problem([2] * k, [2] * k, xf[i], Q, R, Qf, 0.6, 0.1, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
