@@ -113,10 +113,13 @@ def main():
     B = args.batch
 
     def make_job(n_steps, seed0):
-        """n_steps batches of B scenarios each, resident in HBM; seeds are disjoint across ranks and steps."""
-        x0_h, xf_h = scenarios(seed0, n_steps * B)
-        pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf_h, Q, R, Qf, 0.5, 0.1, T)
-        return pb, to_dev(x0_h), torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda"), x0_h, xf_h
+        """n_steps batches of B scenarios each, resident in HBM; seeds are disjoint across ranks and steps.  The scenarios
+        are generated on the device (dpilqr_random_setup: bit for bit np.random.seed(s); random_setup(...), checked against
+        the reference's own outputs in tests/test_gpu_api.py); the host copies feed the CPU baseline."""
+        from dpilqr_amd.util import random_setup_batch
+        x0, xf = random_setup_batch((seed0, n_steps * B), K_AGENTS, N_S, var=K_AGENTS / 2, n_d=2, energy=10.0)
+        pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, Q, R, Qf, 0.5, 0.1, T)
+        return pb, x0, torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda"), x0.cpu().numpy(), xf.cpu().numpy()
 
     Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
     seeds_per_rank = (args.steps + args.warmup) * B

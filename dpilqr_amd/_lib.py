@@ -76,6 +76,7 @@ SIGNATURES = {
     "dpilqr_dispatch_stitch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_dispatch_pack_rows": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "dpilqr_dispatch_scatter_rows": (i32, [i64, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "dpilqr_random_setup": (i32, [i32, i64, i32, i32, i32, f64, f64, vp, vp, vp]),
 }
 
 MAX_AGENTS = 64

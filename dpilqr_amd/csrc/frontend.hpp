@@ -264,4 +264,86 @@ static __global__ void k_scatter_rows(int64_t n_rows_total, int k, int n_s, int 
     }
 }
 
+
+// ---- scenario generation ("next" row f4): util.random_setup (util.py:165-195) with random=True, is_rotation=False,
+// as scripts/analysis.py:45-54 calls it after np.random.seed(s) -- reproduced bit for bit on the device, one thread per
+// scenario: NumPy's legacy global generator is MT19937 seeded by init_genrand(s); np.random.uniform(-1, 1, (k, n_d))
+// draws k * n_d doubles in C order, each from two 32-bit outputs, (a >> 5) * 2^26 + (b >> 6) over 2^53, as
+// -1 + 2 u; starts first, then goals (util.py:181-182).  normalize_energy (util.py:203-217): subtract the mean position,
+// scale so that the summed distance from the origin is `energy` -- with NumPy's summation orders: the mean over agents is
+// sequential, the sum of the k norms is NumPy's pairwise sum (eight running partial sums once k >= 8).
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    __device__ void seed(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    __device__ void twist() {
+        for (int i = 0; i < 624; ++i) {
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        idx = 0;
+    }
+    __device__ uint32_t next32() {
+        if (idx >= 624) twist();
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    __device__ double next_double() {
+        const uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+__device__ inline double numpy_pairwise_sum(const double* a, int n) {   // numpy/core/src/umath/loops_utils.h, n <= 128
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+static __global__ void k_random_setup(int S, int64_t seed0, int k, int n_s, int n_d, double var, double energy,
+                                      double* __restrict__ x0, double* __restrict__ xf) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    Mt19937 g;
+    g.seed((uint32_t)(seed0 + s));
+    double pos[kFrontMaxAgents * 3], nrm[kFrontMaxAgents];
+    for (int which = 0; which < 2; ++which) {
+        double* out = (which == 0 ? x0 : xf) + (int64_t)s * k * n_s;
+        for (int e = 0; e < k * n_d; ++e) pos[e] = var * (-1.0 + 2.0 * g.next_double());
+        if (energy != 0.0) {
+            double centre[3];
+            for (int c = 0; c < n_d; ++c) {
+                double acc = 0.0;
+                for (int a = 0; a < k; ++a) acc += pos[a * n_d + c];
+                centre[c] = acc / k;
+            }
+            for (int e = 0; e < k * n_d; ++e) pos[e] -= centre[e % n_d];
+            for (int a = 0; a < k; ++a) {
+                double q = 0.0;
+                for (int c = 0; c < n_d; ++c) q += pos[a * n_d + c] * pos[a * n_d + c];
+                nrm[a] = sqrt(q);
+            }
+            const double scale = energy / numpy_pairwise_sum(nrm, k);
+            for (int e = 0; e < k * n_d; ++e) pos[e] *= scale;
+        }
+        for (int a = 0; a < k; ++a)
+            for (int c = 0; c < n_s; ++c) out[a * n_s + c] = c < n_d ? pos[a * n_d + c] : 0.0;
+    }
+}
+
 }  // namespace dpilqr

@@ -118,4 +118,15 @@ int32_t dpilqr_dispatch_scatter_rows(int64_t n_rows_total, int32_t k, int32_t n_
     return DPILQR_OK;
 }
 
+int32_t dpilqr_random_setup(int32_t S, int64_t seed0, int32_t k, int32_t n_s, int32_t n_d, double var, double energy,
+                            double* x0, double* xf, void* stream) {
+    if (S < 0 || k < 1 || k > kFrontMaxAgents || n_d < 1 || n_d > 3 || n_s < n_d || !x0 || !xf || seed0 < 0 ||
+        seed0 + (int64_t)S > 0xffffffffll)
+        return fail(DPILQR_EINVAL, "random_setup: bad argument (k <= %d, n_d in 1..3, seeds in [0, 2^32))", kFrontMaxAgents);
+    if (S == 0) return DPILQR_OK;
+    hipLaunchKernelGGL(k_random_setup, dim3((S + 63) / 64), dim3(64), 0, as_stream(stream), S, seed0, k, n_s, n_d, var, energy, x0, xf);
+    HIP_TRY(hipGetLastError());
+    return DPILQR_OK;
+}
+
 }  // extern "C"

@@ -170,3 +170,18 @@ def perturb_state(x, x_dims, n_d=2, var=0.5):
     mask = pos_mask(x_dims, n_d)
     x[mask] += var * np.random.randn(*x[mask].shape)
     return x
+
+
+def random_setup_batch(seeds, n_agents, n_states, var, n_d=2, energy=None):
+    """(x0, xf) device tensors (S, n_agents * n_states) of the scenarios np.random.seed(s); random_setup(n_agents, n_states,
+    is_rotation=False, var=var, n_d=n_d, random=True, energy=energy) for s in range(seeds[0], seeds[0] + S) -- generated on
+    the device, bit for bit what the host loop gives (dpilqr_random_setup).  seeds: (first seed, count) or a range."""
+    from . import _lib
+    from .device import empty, ptr, stream_handle
+    seed0, S = (seeds.start, len(seeds)) if isinstance(seeds, range) else (int(seeds[0]), int(seeds[1]))
+    if isinstance(seeds, range) and seeds.step != 1:
+        raise ValueError("consecutive seeds only")
+    x0 = empty((S, n_agents * n_states)); xf = empty((S, n_agents * n_states))
+    _lib.check(_lib.load().dpilqr_random_setup(S, seed0, n_agents, n_states, n_d, float(var), float(energy or 0.0), ptr(x0), ptr(xf),
+                                               stream_handle()))
+    return x0, xf

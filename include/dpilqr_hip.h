@@ -308,6 +308,14 @@ int32_t dpilqr_dispatch_pack_rows(int32_t S, int32_t k, int32_t n_s, int32_t n_c
 int32_t dpilqr_dispatch_scatter_rows(int64_t n_rows_total, int32_t k, int32_t n_s, int32_t n_c, int32_t T, const double* rows,
                                      int64_t row_len, double* X_dec, double* U_dec, void* stream);
 
+/* -------------------------------------------------- (8) scenario generation on the device ("next" row f4)
+ * x0, x_f [S][k*n_s] of the scenarios s = seed0 .. seed0 + S - 1 of scripts/analysis.py:45-54: what
+ *     np.random.seed(s); random_setup(k, n_s, is_rotation=False, rel_dist=., var=var, n_d=n_d, random=True, energy=energy)
+ * returns (util.py:125-217), bit for bit -- NumPy's legacy MT19937 stream, its uniform(), its mean / norm / pairwise-sum
+ * orders -- so that a Monte-Carlo driver needs neither a host loop over seeds nor an upload.  energy = 0: no normalisation. */
+int32_t dpilqr_random_setup(int32_t S, int64_t seed0, int32_t k, int32_t n_s, int32_t n_d, double var, double energy,
+                            double* x0, double* xf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -499,3 +499,24 @@ def test_solve_subproblem_vs_reference(dp, golden):
         assert relerr(Xi, z[f"sub_X_{i}"]) < TOL_SOLVE and relerr(Ui, z[f"sub_U_{i}"]) < TOL_SOLVE
     Xi, Ui, rid = solve_subproblem_starmap(subs[0], x0s[0], U0s[0], ids[0])
     assert rid == ids[0] and relerr(Xi, z["sub_X_0"]) < TOL_SOLVE
+
+
+@pytest.mark.parametrize("tag,k,ns,nd", [("k5s4", 5, 4, 2), ("k3s4", 3, 4, 2), ("k10s6", 10, 6, 3), ("k15s4", 15, 4, 2)])
+def test_scenarios_generated_on_the_device_equal_the_references(dp, golden, tag, k, ns, nd):
+    """dpilqr_random_setup against the reference's own np.random.seed(s); random_setup(...) outputs (G6), bit for bit, and
+    against the host generator for seeds the fixture does not hold (large seeds, more than one MT19937 block is never
+    needed: 4 k n_d <= 624 draws)."""
+    from dpilqr_amd.util import random_setup, random_setup_batch
+    z = golden("g6_scenarios")
+    x0, xf = random_setup_batch(range(0, 8), k, ns, var=k / 2, n_d=nd, energy=10.0)
+    np.testing.assert_array_equal(x0.cpu().numpy(), z[tag + "_x0"]); np.testing.assert_array_equal(xf.cpu().numpy(), z[tag + "_xf"])
+    for seed0 in (1000, 4_000_000_000):
+        a, b = random_setup_batch((seed0, 33), k, ns, var=k / 2, n_d=nd, energy=10.0)
+        for i in (0, 7, 32):
+            np.random.seed(seed0 + i)
+            h0, hf = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0)
+            np.testing.assert_array_equal(a[i].cpu().numpy(), h0.ravel()); np.testing.assert_array_equal(b[i].cpu().numpy(), hf.ravel())
+    a, b = random_setup_batch((5, 4), k, ns, var=2.0, n_d=nd, energy=None)          # no normalisation
+    np.random.seed(5)
+    h0, hf = random_setup(k, ns, is_rotation=False, var=2.0, n_d=nd, random=True, energy=None)
+    np.testing.assert_array_equal(a[0].cpu().numpy(), h0.ravel())
