@@ -89,9 +89,10 @@ def study(name, models, n_dims, T, B, seed0, energy, n_lqr_iter, oracle_items):
         rollout_J=float(np.median(np.abs(Jr32.cpu().numpy() - Jr64.cpu().numpy()) / np.abs(Jr64.cpu().numpy()))),
         K_median=float(np.median(rel(K32.cpu().numpy(), K64.cpu().numpy()))), K_max=float(rel(K32.cpu().numpy(), K64.cpu().numpy()).max()),
         d_median=float(np.median(rel(d32.cpu().numpy(), d64.cpu().numpy()))), d_max=float(rel(d32.cpu().numpy(), d64.cpu().numpy()).max()),
-        forward_X_median=float(efwd[fin].median()) if fin.any() else None,
-        forward_X_max=float(efwd[fin].max()) if fin.any() else None,
-        forward_J_median=float(((Jf32 - Jf64).abs() / Jf64.abs())[fin].median()) if fin.any() else None,
+        forward_X_median=float(efwd[fin].nanmedian()) if fin.any() else None,
+        forward_X_max=float(efwd[fin][~torch.isnan(efwd[fin])].max()) if fin.any() else None,
+        forward_fp32_nan_where_fp64_finite=float(torch.isnan(efwd[fin]).double().mean()) if fin.any() else None,
+        forward_J_median=float(((Jf32 - Jf64).abs() / Jf64.abs())[fin].nanmedian()) if fin.any() else None,
         forward_candidates_finite_fp64=float(fin.double().mean()), forward_candidates_finite_fp32=float(torch.isfinite(Jf32).double().mean()))
     # ---- whole solves
     t0 = time.perf_counter(); s64 = pb.solve(x0, U0, n_lqr_iter=n_lqr_iter); torch.cuda.synchronize(); t64 = time.perf_counter() - t0
@@ -101,13 +102,15 @@ def study(name, models, n_dims, T, B, seed0, energy, n_lqr_iter, oracle_items):
         same = ((a["n_bwd"] == b["n_bwd"]) & (a["n_fwd"] == b["n_fwd"]) & (a["status"] == b["status"])).cpu().numpy().astype(bool)
         Ja, Jb = a["J"].cpu().numpy(), b["J"].cpu().numpy()
         eX = rel(a["X"].double().cpu().numpy(), b["X"].double().cpu().numpy())
-        eJ = np.abs(Ja - Jb) / np.maximum(np.abs(Jb), 1e-300)
+        with np.errstate(invalid="ignore"):
+            eJ = np.abs(Ja - Jb) / np.maximum(np.abs(Jb), 1e-300)
+        eJ = np.where(np.isnan(Ja) & np.isnan(Jb), 0.0, eJ)     # both report the NaN cost of a rejected last candidate (quirk Q2)
         return dict(decision_flip_rate=float(1.0 - same.mean()),
-                    J_rel_median_same=float(np.median(eJ[same])) if same.any() else None,
-                    J_rel_max_same=float(eJ[same].max()) if same.any() else None,
+                    J_rel_median_same=float(np.nanmedian(eJ[same])) if same.any() else None,
+                    J_rel_max_same=float(np.nanmax(eJ[same])) if same.any() else None,
                     X_rel_median_same=float(np.median(eX[same])) if same.any() else None,
                     X_rel_max_same=float(eX[same].max()) if same.any() else None,
-                    J_rel_median_all=float(np.median(eJ)), frac_within_1e5=float((eX < 1e-5).mean()))
+                    J_rel_median_all=float(np.nanmedian(eJ)), frac_within_1e5=float((eX < 1e-5).mean()))
     out["solve_fp32_vs_fp64"] = compare(s32, s64)
     out["solve_seconds"] = dict(fp64=t64, fp32=t32)
     out["mean_iterations"] = dict(fp64=float(s64["n_bwd"].double().mean()), fp32=float(s32["n_bwd"].double().mean()))

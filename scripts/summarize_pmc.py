@@ -12,9 +12,11 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-fetch_csv, write_csv, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-window = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
-ALGO = 619360  # bytes per sub-problem backward pass, bench.py
+fused = "--fused" in sys.argv           # the passes were taken with the fused sweep (bench.py's default from round 2 on)
+argv = [a for a in sys.argv if a != "--fused"]
+fetch_csv, write_csv, tag = argv[1], argv[2], argv[3]
+window = int(argv[4]) if len(argv) > 4 else 2048
+ALGO = 96160 if fused else 619360  # bytes per sub-problem backward pass, bench.py (fused: trajectory in, gains out)
 
 seen_wave_producer = 'k_make_tiles_wave' in open(fetch_csv).read()
 
@@ -60,6 +62,16 @@ js = {"kernel": name.split("(")[0].replace("void dpilqr::", ""), "window_items":
       "algorithmic_bytes_per_subproblem_pass": ALGO,
       "source": f"profiles/{tag}_bench_hbm_counters.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                 "bench.py --steps 8 --warmup 1 --no-cpu-baseline)"}
-(ROOT / "profiles" / "riccati_traffic.json").write_text(json.dumps(js, indent=1))
+tj = ROOT / "profiles" / "riccati_traffic.json"
+old = json.loads(tj.read_text()) if tj.exists() else {}
+if fused:      # keep the record-fed sweep's entry (bench.py reads it when DPILQR_NO_FUSED is set), add the fused one beside it
+    old["hbm_bytes_per_subproblem_pass_fused"] = js["hbm_bytes_per_subproblem_pass"]
+    old["fused"] = js
+    js = old
+else:
+    for key in ("hbm_bytes_per_subproblem_pass_fused", "fused"):
+        if key in old:
+            js[key] = old[key]
+tj.write_text(json.dumps(js, indent=1))
 for r in rows: print(r)
 print(json.dumps(js, indent=1))
