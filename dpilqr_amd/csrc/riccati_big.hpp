@@ -27,12 +27,24 @@
 
 namespace dpilqr {
 
-constexpr int kBigThreads = 256;
+constexpr int kBigThreads = 1024;   // sixteen wavefronts per sub-problem: the phases below are latency-bound loops over L2-resident data
 
 __host__ __device__ constexpr int big_round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 // 16x16x4 matrix-pipe tile: lane (g = lane / 16, c = lane % 16) supplies A = X[l0 + g][i0 + c], B = Y[l0 + g][j0 + c]
 // and owns four elements of D = X^T Y in column j0 + c; their rows differ between the two instructions.
+// Value of another lane of the same 16-lane row, by DPP (one vector-pipe operation per 32 bits instead of a trip through the
+// LDS crossbar): CTRL 0xB1 / 0x4E = quad_perm [1,0,3,2] / [2,3,0,1], 0x141 = row_half_mirror, 0x140 = row_mirror.  Applied in
+// that order to a symmetric reduction they make every lane of the row hold the result.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_val(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_val(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+
 template <typename R> struct Mfma;
 template <> struct Mfma<double> {
     typedef double acc_t __attribute__((ext_vector_type(4)));
@@ -81,7 +93,7 @@ struct BigLds {   // offsets in elements of R (all even)
         H = o;   o += ev(np * 9);               // pair Hessians
         p = o;   o += ev(n);
         ldlu = mk + 2;
-        LU = o;  o += mk * ldlu;
+        LU = o;  o += ev(mk * ldlu > k * ns * (ns + nc) ? mk * ldlu : k * ns * (ns + nc));   // also the Jacobians' scratch between steps
         inv = o; o += mk;
         perm = o; o += 2 * mk + 4;              // int32 perm[mk], piv[mk], flags, in R-sized slots (>= 4 bytes each)
         total = ev(o);
@@ -145,22 +157,17 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     auto stage_step = [&](int t, bool terminal) {
         const R* xt = Xb + (int64_t)t * n;
         const R* ut = Ub + (int64_t)(terminal ? 0 : t) * m;
+        // the Jacobians are written straight into LDS (a Quadcopter12D Jacobian held in registers costs 400 of them and
+        // with that every other phase its occupancy): per agent a scratch block [A | B] inside the LU buffer, which is dead
+        // between the steps, interleaved into sAB below
+        R* sJ = sLU;
         for (int a = tid; a < k; a += kBigThreads) {
-            R x[NS], u[NC], A[NS * NS], Bm[NS * NC];
+            R x[NS], u[NC];
 #pragma unroll
             for (int i = 0; i < NS; ++i) x[i] = xt[a * NS + i];
 #pragma unroll
             for (int i = 0; i < NC; ++i) u[i] = terminal ? (R)0.0 : ut[a * NC + i];
-            if (!terminal) {
-                linearize_rt<NS>(P.model[a], x, u, dt, A, Bm);
-#pragma unroll
-                for (int l = 0; l < NS; ++l) {
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) sAB[(a * NS + l) * NSC + i] = A[l * NS + i];
-#pragma unroll
-                    for (int i = 0; i < NC; ++i) sAB[(a * NS + l) * NSC + NS + i] = Bm[l * NC + i];
-                }
-            }
+            if (!terminal) linearize_rt<NS>(P.model[a], x, u, dt, sJ + a * NS * NSC, sJ + a * NS * NSC + NS * NS);
 #pragma unroll
             for (int i = 0; i < NS; ++i) sE[a * NS + i] = x[i] - (R)P.xf[a * NS + i];
 #pragma unroll
@@ -177,6 +184,19 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             for (int c = 0; c < 3; ++c) sG3[p * 3 + c] = gg[c];
 #pragma unroll
             for (int c = 0; c < 9; ++c) sH[p * 9 + c] = HH[c];
+        }
+        if (!terminal) {
+            __syncthreads();
+            for (int e = tid; e < k * NS * NSC; e += kBigThreads) {
+                const int a = e / (NS * NSC), q = e - a * NS * NSC, l = q / NSC, i = q - l * NSC;
+                sAB[e] = (i < NS) ? sJ[a * NS * NSC + l * NS + i] : sJ[a * NS * NSC + NS * NS + l * NC + (i - NS)];
+            }
+            __syncthreads();
+            // the LU buffer again: zero inside, identity on the padding's diagonal
+            for (int e = tid; e < mk * ldlu; e += kBigThreads) {
+                const int r = e / ldlu, c = e - r * ldlu;
+                sLU[e] = (r == c && r >= m) ? (R)1.0 : (R)0.0;
+            }
         }
         if (t == T || t == T - 1) {   // the weights change once: Q_f for the terminal record, Q for all others
             for (int e = tid; e < k * NS * NS; e += kBigThreads) {
@@ -233,12 +253,21 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     for (int i = tid; i < n; i += kBigThreads) sp[i] = lx(i / NS, i % NS);
     __syncthreads();
 
+#ifdef DPILQR_PHASE_STAMPS
+    unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bph_t = __builtin_amdgcn_s_memtime();
+#define BPHASE(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[i] += now_ - bph_t; bph_t = now_; }
+#else
+#define BPHASE(i)
+#endif
     for (int t = T - 1; t >= 0; --t) {
         stage_step(t, false);
         __syncthreads();
+        BPHASE(0)
 
         // ---- S1: the block products.  Work item (ai, aj, r): row r of [A_ai | B_ai]^T P_(ai,aj) (NS terms), then times
-        // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).
+        // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).  (An MFMA formulation -- two
+        // 16x16x4 products per block pair with T transposed through LDS -- was built and measured SLOWER, 500 k against 250 k
+        // cycles per step: fifty dependent load -> MFMA -> LDS -> MFMA -> store chains per wavefront hide no latency.)
         for (int w = tid; w < k * k * NSC; w += kBigThreads) {
             const int blk = w / NSC, r = w - blk * NSC, ai = blk / k, aj = blk - ai * k;
             R Tr[NS];
@@ -304,63 +333,57 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
         }
         __syncthreads();
+        BPHASE(1)
 
-        // ---- S3a: LU of Q_uu in LDS, partial pivoting (dgetf2: first row of largest magnitude)
+        // ---- S3a: LU of Q_uu in LDS, partial pivoting in dgetf2's order (first POSITION of largest magnitude), without moving
+        // rows: sPerm[pos] is the row that stands at position pos after the exchanges so far; the factors stay where they are
+        // and every later access goes through sPerm
+        for (int r = tid; r < mk; r += kBigThreads) sPerm[r] = r;
+        __syncthreads();
         for (int kk = 0; kk < m; ++kk) {
             if (wave == 0) {
-                // wave-wide pivot search: lane-strided scan, then a butterfly that keeps the smaller row on ties
+                // sixteen lanes scan the column, five candidates each at n_u = 80; ties go to the lower position
                 R best = -1.0;
                 int piv = kk;
-                for (int r = kk + lane; r < m; r += 64) {
-                    const R v = fabs(sLU[r * ldlu + kk]);
-                    if (v > best) { best = v; piv = r; }
+                for (int ps = kk + (lane & 15); ps < m; ps += 16) {
+                    const R v = fabs(sLU[sPerm[ps] * ldlu + kk]);
+                    if (v > best) { best = v; piv = ps; }
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const R ob = __shfl_xor(best, off);
-                    const int op = __shfl_xor(piv, off);
-                    if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+#define DPILQR_ARGMAX_STEP(CTRL)                                                                \
+                {                                                                               \
+                    const R ob = dpp_val<CTRL>(best);                                           \
+                    const int op = dpp_i32<CTRL>(piv);                                          \
+                    if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }         \
                 }
+                DPILQR_ARGMAX_STEP(0xB1) DPILQR_ARGMAX_STEP(0x4E) DPILQR_ARGMAX_STEP(0x141) DPILQR_ARGMAX_STEP(0x140)
+#undef DPILQR_ARGMAX_STEP
                 if (lane == 0) {
-                    sPiv[kk] = piv;
-                    sFlag[1] = piv;
-                    const R pv = sLU[piv * ldlu + kk];
+                    const int rk = sPerm[kk], rp = sPerm[piv];
+                    sPerm[kk] = rp; sPerm[piv] = rk;
+                    const R pv = sLU[rp * ldlu + kk];
                     if (!(best > (R)0.0)) sFlag[0] = 1;            // zero (or NaN) pivot: np.linalg.solve would raise
                     sInv[kk] = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
                 }
             }
             __syncthreads();
-            const int piv = sFlag[1];
-            if (piv != kk) {
-                for (int c = tid; c < m; c += kBigThreads) {
-                    const R a0 = sLU[kk * ldlu + c];
-                    sLU[kk * ldlu + c] = sLU[piv * ldlu + c];
-                    sLU[piv * ldlu + c] = a0;
-                }
-                __syncthreads();
-            }
             const R inv = sInv[kk];
-            const int rem = m - kk - 1;
-            for (int e = tid; e < rem * rem; e += kBigThreads) {
-                const int r = kk + 1 + e / rem, c = kk + 1 + e % rem;
-                const R l = sLU[r * ldlu + kk] * inv;
-                sLU[r * ldlu + c] = fma(-l, sLU[kk * ldlu + c], sLU[r * ldlu + c]);
+            const R* prow = sLU + sPerm[kk] * ldlu;
+            // trailing update over positions > kk, a 32 x 32 thread tile
+            for (int ps = kk + 1 + (tid >> 5); ps < m; ps += kBigThreads / 32) {
+                R* row = sLU + sPerm[ps] * ldlu;
+                const R l = row[kk] * inv;
+                for (int c = kk + 1 + (tid & 31); c < m; c += 32) row[c] = fma(-l, prow[c], row[c]);
             }
             __syncthreads();
         }
-        // multipliers l = a / pivot in place (exactly the values the elimination used); row order of the right-hand sides
-        for (int e = tid; e < m * m; e += kBigThreads) {
-            const int r = e / m, c = e - r * m;
-            if (r > c) sLU[r * ldlu + c] *= sInv[c];
-        }
-        if (tid == 0) {
-            for (int r = 0; r < mk; ++r) sPerm[r] = r;
-            for (int kk = 0; kk < m; ++kk) {
-                const int pv = sPiv[kk];
-                const int a0 = sPerm[kk]; sPerm[kk] = sPerm[pv]; sPerm[pv] = a0;
-            }
+        // multipliers l = a / pivot in place (exactly the values the elimination used)
+        for (int e = tid; e < m * 32; e += kBigThreads) {
+            const int ps = e >> 5;
+            R* row = sLU + sPerm[ps] * ldlu;
+            for (int c = (e & 31); c < ps; c += 32) row[c] *= sInv[c];
         }
         __syncthreads();
+        BPHASE(2)
 
         // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u]: one right-hand side per thread, substitution in blocks of 16 rows
         // (solved blocks go through the scratch; a row of 16 threads' values is one coalesced access)
@@ -379,7 +402,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     for (int c = 0; c < 16; ++c) yj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const R* Lr = sLU + (16 * I + i) * ldlu + 16 * J;
+                        const R* Lr = sLU + sPerm[16 * I + i] * ldlu + 16 * J;
 #pragma unroll
                         for (int c = 0; c < 16; ++c) y[i] = fma(-Lr[c], yj[c], y[i]);
                     }
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
 #pragma unroll
-                    for (int i = c + 1; i < 16; ++i) y[i] = fma(-sLU[(16 * I + i) * ldlu + 16 * I + c], y[c], y[i]);
+                    for (int i = c + 1; i < 16; ++i) y[i] = fma(-sLU[sPerm[16 * I + i] * ldlu + 16 * I + c], y[c], y[i]);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gKd[(int64_t)(16 * I + i) * ldw + j] = y[i];
             }
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     for (int c = 0; c < 16; ++c) xj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const R* Ur = sLU + (16 * I + i) * ldlu + 16 * J;
+                        const R* Ur = sLU + sPerm[16 * I + i] * ldlu + 16 * J;
 #pragma unroll
                         for (int c = 0; c < 16; ++c) y[i] = fma(Ur[c], xj[c], y[i]);   // xj holds -x
                     }
@@ -410,8 +433,8 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 for (int i = 15; i >= 0; --i) {
                     R s = y[i];
 #pragma unroll
-                    for (int c = i + 1; c < 16; ++c) s = fma(sLU[(16 * I + i) * ldlu + 16 * I + c], y[c], s);
-                    y[i] = -(s / sLU[(16 * I + i) * ldlu + 16 * I + i]);
+                    for (int c = i + 1; c < 16; ++c) s = fma(sLU[sPerm[16 * I + i] * ldlu + 16 * I + c], y[c], s);
+                    y[i] = -(s / sLU[sPerm[16 * I + i] * ldlu + 16 * I + i]);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
         }
         __syncthreads();
-        // restore the LU buffer's identity padding is not needed: rows / columns >= m are never touched
+        BPHASE(3)
 
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]   (K^T Q_uu, associated as the reference's K.T @ Q_uu @ K)
         {
@@ -459,6 +482,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
         }
         __syncthreads();
+        BPHASE(4)
 
         // ---- S5: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T   rows < n, columns <= n
         {
@@ -487,6 +511,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
         }
         __syncthreads();
+        BPHASE(5)
 
         // ---- S6: P <- (V + V^T) / 2 ; p <- V[:, n]
         for (int e = tid; e < n * n; e += kBigThreads) {
@@ -495,7 +520,15 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         }
         for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
         __syncthreads();
+        BPHASE(6)
     }
+#ifdef DPILQR_PHASE_STAMPS
+    if (tid == 0 && slot == 0) {
+        printf("k_riccati_big phases (s_memtime ticks per step, 100 MHz): stage %.0f  S1 %.0f  LU %.0f  solve %.0f  S4 %.0f  S5 %.0f  S6 %.0f\n",
+               (double)bph[0] / T, (double)bph[1] / T, (double)bph[2] / T, (double)bph[3] / T, (double)bph[4] / T, (double)bph[5] / T,
+               (double)bph[6] / T);
+    }
+#endif
     if (singular && tid == 0 && sFlag[0]) singular[b] = 1;
 }
 

@@ -22,6 +22,8 @@ Qf = np.stack([1000.0 * np.eye(12)] * k)
 n, m = 12 * k, 4 * k
 # dense fp64 flops of one backward pass with the block structure of A, B exploited
 flops_pass = T * 2.0 * (k * k * 16 * (144 + 16 * 12) + m ** 3 / 3 + (n + 1) * m * m + m * m * n + 3 * n * (n + 1) * m)
+# SURVEY 8(d)'s dense count (what bench.py uses for cfg2): T (4 n^3 + 8 n^2 m + 6 n m^2 + 2/3 m^3) = 15.3 Gflop
+flops_dense = T * (4.0 * n ** 3 + 8.0 * n * n * m + 6.0 * n * m * m + 2.0 * m ** 3 / 3.0)
 
 
 def timeit(fn, reps=3):
@@ -51,5 +53,6 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 32, 256]:
         t_f = timeit(lambda: pb.forward_pass(X, Ud, K, d, al, dtype=dtype))
         t_r = timeit(lambda: pb.rollout(x0, U0, dtype=dtype))
         name = "fp64" if dtype == torch.float64 else "fp32"
-        print(f"B={B:4d} {name}: backward {t_b * 1e3:8.2f} ms ({B * flops_pass / t_b / 1e12:6.2f} TFLOP/s structured), "
+        print(f"B={B:4d} {name}: backward {t_b * 1e3:8.2f} ms ({B * flops_pass / t_b / 1e12:6.2f} TFLOP/s of the flops left with the block structure, "
+              f"{B * flops_dense / t_b / 1e12:6.2f} by SURVEY 8(d)'s dense count), "
               f"10 forward passes {t_f * 1e3:8.2f} ms, rollout {t_r * 1e3:7.2f} ms", flush=True)
