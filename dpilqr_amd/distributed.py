@@ -137,11 +137,15 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
     """solve_rhc (distributed.py:106-221) for S Monte-Carlo scenarios of one k-agent problem in lock step: every
     receding-horizon round is ONE batched solve over the scenarios still running (solve_scenarios_distributed, or one
     ProblemBatch when centralized), with the reference's warm-start shift and stopping rules applied per scenario.
+    The state of the loop -- current states, shifted warm starts (:184-185), executed prefixes -- stays on the device
+    between rounds; per round only the S stopping flags come to the host.
 
     x0 (S, n_x); xf (S, n_x) goals (default: the problem's own); U0 (S, N, n_u) warm starts (default: drawn per
     scenario, in order, as solve_rhc draws them: np.random.rand(N, n_u) * 0.01).
     Returns a list of S tuples (X_full, U_full, J_full, converged), what solve_rhc returns plus its `converged` flag."""
+    import torch
     from .batch import ProblemBatch
+    from .device import to_dev
     from .dispatch import solve_scenarios_distributed
     from .lowering import describe
     if (J_converge is None) == (dist_converge is None):
@@ -152,59 +156,58 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
     n_s = n_x // k
     x0 = np.asarray(x0, dtype=np.float64).reshape(-1, n_x)
     S = x0.shape[0]
-    xf = np.broadcast_to(d["xf"], (S, n_x)).copy() if xf is None else np.asarray(xf, dtype=np.float64).reshape(S, n_x)
-    U = np.stack([np.random.rand(N, n_u) * 0.01 for _ in range(S)]) if U0 is None else np.array(U0, dtype=np.float64)
+    xf_h = np.broadcast_to(d["xf"], (S, n_x)).copy() if xf is None else np.asarray(xf, dtype=np.float64).reshape(S, n_x)
+    U_h = np.stack([np.random.rand(N, n_u) * 0.01 for _ in range(S)]) if U0 is None else np.array(U0, dtype=np.float64)
     solve_kw = {key: v for key, v in kwargs.items() if key in ("n_lqr_iter", "tol")}
-
-    def left(xs, idx):
-        return np.linalg.norm((xs - xf[idx]).reshape(len(idx), k, n_s)[:, :, :n_d], axis=2)
-
-    xi = x0.copy()
-    X = xi[:, None, :].copy()                      # first round: the graph is built from x0 alone (distributed.py:152)
-    J = np.full(S, np.inf)
+    xf_d, U, xi = to_dev(xf_h), to_dev(U_h), to_dev(x0)
+    X = None                                       # first round: the graph is built from x0 alone (distributed.py:152)
+    J = torch.full((S,), float("inf"), dtype=torch.float64, device=xi.device)
     t = np.zeros(S)
     converged = np.ones(S, dtype=bool)
-    X_full = [np.zeros((0, n_x)) for _ in range(S)]
-    U_full = [np.zeros((0, n_u)) for _ in range(S)]
+    X_parts = [[] for _ in range(S)]; U_parts = [[] for _ in range(S)]
 
-    def keep_going(idx):
+    def keep_going(idx):      # one small device -> host read per round: the stopping flags
         if J_converge:
-            return J[idx] >= J_converge
-        return (left(xi[idx], idx) > dist_converge).any(axis=1)
+            return (J[idx] >= J_converge).cpu().numpy()
+        left = torch.linalg.vector_norm((xi[idx] - xf_d[idx]).reshape(len(idx), k, n_s)[:, :, :n_d], dim=2)
+        return (left > dist_converge).any(dim=1).cpu().numpy()
 
-    active = np.nonzero(keep_going(np.arange(S)))[0]
+    active = np.nonzero(keep_going(torch.arange(S, device=xi.device)))[0]
     while active.size:
+        ia = torch.as_tensor(active, device=xi.device)
         if centralized:
-            pb = ProblemBatch(d["model"], d["n_dims"], xf[active], d["Q"], d["R"], d["Qf"], d["radius"], dt, N,
+            pb = ProblemBatch(d["model"], d["n_dims"], xf_d[ia], d["Q"], d["R"], d["Qf"], d["radius"], dt, N,
                               w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(active))
-            r = pb.solve(xi[active], U[active], window=window, **solve_kw)
-            Xa, Ua, Ja = r["X"].cpu().numpy(), r["U"].cpu().numpy(), r["J"].cpu().numpy()
+            r = pb.solve(xi[ia], U[ia], window=window, **solve_kw)
+            Xa, Ua, Ja = r["X"], r["U"], r["J"]
         else:
-            Xa, Ua, Ja, _ = solve_scenarios_distributed(problem, X[active] if X.shape[1] > 1 else xi[active][:, None, :],
-                                                        U[active], radius, xf=xf[active], window=window, **solve_kw)
-        if X.shape[1] == 1:
-            X = np.zeros((S, N + 1, n_x))
+            Xin = xi[ia][:, None, :] if X is None else X[ia]
+            Xa, Ua, Ja, _ = solve_scenarios_distributed(problem, Xin, U[ia], radius, xf=xf_d[ia], window=window, device_out=True,
+                                                        **solve_kw)
+        if X is None:
+            X = torch.zeros((S, N + 1, n_x), dtype=torch.float64, device=xi.device)
         for j, s in enumerate(active):
-            X_full[s] = np.r_[X_full[s], Xa[j, :step_size]]
-            U_full[s] = np.r_[U_full[s], Ua[j, :step_size]]
-        xi[active] = Xa[:, step_size]
+            X_parts[s].append(Xa[j, :step_size]); U_parts[s].append(Ua[j, :step_size])
+        xi[ia] = Xa[:, step_size]
         # warm start of the next round: shift, stay at the last visited state, zero controls (distributed.py:184-185)
-        X[active] = np.concatenate([Xa[:, step_size:], np.repeat(Xa[:, -1:], step_size, axis=1)], axis=1)
-        U[active] = np.concatenate([Ua[:, step_size:], np.zeros((len(active), step_size, n_u))], axis=1)
-        J[active] = Ja
+        X[ia] = torch.cat([Xa[:, step_size:], Xa[:, -1:].expand(-1, step_size, -1)], dim=1)
+        U[ia] = torch.cat([Ua[:, step_size:], torch.zeros((len(active), step_size, n_u), dtype=torch.float64, device=xi.device)], dim=1)
+        J[ia] = Ja
         diverged = np.zeros(len(active), dtype=bool)
         if t_diverge:
             diverged = t[active] >= t_diverge
             converged[active[diverged]] = False
         t[active[~diverged]] += step_size * dt
-        still = keep_going(active) & ~diverged
+        still = keep_going(ia) & ~diverged
         active = active[still]
     out = []
     for s in range(S):
-        if not X_full[s].size and not U_full[s].size:
-            X_full[s] = x0[s].copy(); U_full[s] = np.zeros((1, n_u))
-        pbs = ProblemBatch(d["model"], d["n_dims"], xf[s:s + 1], d["Q"], d["R"], d["Qf"], d["radius"], dt, U_full[s].shape[0],
+        if X_parts[s]:
+            Xf = torch.cat(X_parts[s]).cpu().numpy(); Uf = torch.cat(U_parts[s]).cpu().numpy()
+        else:
+            Xf = x0[s].copy(); Uf = np.zeros((1, n_u))
+        pbs = ProblemBatch(d["model"], d["n_dims"], xf_h[s:s + 1], d["Q"], d["R"], d["Qf"], d["radius"], dt, Uf.shape[0],
                            w_ref=d["w_ref"], w_prox=d["w_prox"], B=1)
-        _, Jf = pbs.rollout(x0[s:s + 1], U_full[s][None])
-        out.append((X_full[s], U_full[s], float(Jf.cpu().numpy()[0]), bool(converged[s])))
+        _, Jf = pbs.rollout(x0[s:s + 1], Uf[None])
+        out.append((Xf, Uf, float(Jf.cpu().numpy()[0]), bool(converged[s])))
     return out
