@@ -324,3 +324,28 @@ def test_enqueue_only_solve_equals_synchronous_solve(dp):
     assert int((r["status"] == 0).sum()) == 0
     for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
         assert torch.equal(r[key], ref[key]), key
+
+
+def test_enqueue_only_solve_can_be_captured_in_a_hip_graph(dp):
+    """dpilqr_solve_enqueue neither allocates, nor reads anything on the host, nor synchronises: the whole iteration
+    loop of a solve is captured into a HIP graph (torch.cuda.graph drives hipStreamBeginCapture / EndCapture) and
+    replayed; the replayed solve gives the synchronous solve's answer bit for bit."""
+    import torch
+    from tests.golden_util import cfg2_params
+    from dpilqr_amd.util import random_setup_batch
+    c = cfg2_params(); B = 64
+    x0, xf = random_setup_batch((7000, B), 5, 4, var=2.5, n_d=2, energy=10.0)
+    pb = dp.ProblemBatch(c["model"], c["n_dims"], xf, c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    U0 = torch.zeros((B, 50, 10), dtype=torch.float64, device="cuda")
+    ref = pb.solve(x0, U0, window=32)
+    bound = pb.iterations_bound(50, window=32)
+    r, state = pb.solve_enqueue(x0, U0, 0, window=32)          # initialise + rollout, eagerly (also warms every kernel)
+    r, state = pb.solve_enqueue(None, None, 2, state=state)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        pb.solve_enqueue(None, None, bound, state=state)         # resume = 1: continues from the state left above
+    graph.replay()
+    torch.cuda.synchronize()
+    for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
+        assert torch.equal(r[key], ref[key]), key
