@@ -1,12 +1,12 @@
 // riccati_wg.hpp -- K2 for the larger clusters (n_x 24 .. 60): the Riccati backward sweep with ONE WORKGROUP of four
 // wavefronts per sub-problem (ilqrSolver._backward_pass, control.py:116-148).
 //
-// riccati_mfma.hpp gives every sub-problem one wavefront and 20 KB of LDS; that stops at n_x = 20.  A 15-agent
-// unicycle cluster (cfg3) has n_x = 60, n_u = 30: [A|B], [P|p], T, [Q_xx|Q_x], [Q_uu|Q_ux|Q_u] need 147 KB, a whole
-// CU's LDS, and the work of one step (a 30 x 30 pivoted LU with 61 right-hand sides, 0.27 M dense FMAs) is enough
-// for four wavefronts.  Same recursion, same association order as the reference (see riccati.hpp for the equations):
+// riccati_mfma.hpp gives every sub-problem one wavefront and 13.5 KB of LDS; that stops at n_x = 20.  A 15-agent
+// unicycle cluster (cfg3) has n_x = 60, n_u = 30, and the work of one step (a 30 x 30 pivoted LU with 61 right-hand
+// sides, 0.27 M dense FMAs) is enough for four wavefronts.  Same recursion, same association order as the reference
+// (see riccati.hpp for the equations):
 //
-//   S0  [A|B](t) registers -> LDS (requested during the previous step); request this step's l-values
+//   S0  this step's diagonal blocks of [A|B] registers -> LDS (requested during the previous step); request l-values
 //   S1  [T1;T2 | A^T p;B^T p] = [A|B]^T [P|p]  (+ mu B^T on the B rows): block-diagonal [A|B] (the library's own
 //       tiles, see riccati_mfma.hpp), NS terms per output, work items (agent, 2 columns) dealt to the 256 lanes
 //   S2  [T1;T2][A|B] + l-values -> Q_xx, Q_ux, Q_uu: work items (agent, 2 rows)
@@ -15,8 +15,17 @@
 //   S4  T3^T = Q_uu-contracted K            fp64 MFMA tiles dealt round-robin to the wavefronts
 //   S5  a1 = T3 [K|d], a2 = [K|d]^T [Q_ux|Q_u], V = ((Q + a1) + a2) + a2^T          likewise
 //   S6  P <- (V + V^T)/2
-// LDS regions: [A|B] | [Q_xx|Q_x] | R2 = [P|p] -> T -> [K|d] + T3^T -> [P|p] | G = [Q_uu|Q_ux|Q_u] -> a2.  Phases are
-// separated by workgroup barriers (s_barrier behind an LDS-only wait: the global prefetches stay in flight).
+//
+// The kernel is bound by latency, not by a pipe (one step at n_x = 60: 73 k cycles, of which the matrix pipe is busy
+// 4 k), so what it needs is several sub-problems per CU, and what decides that is LDS and registers.  Three regions:
+//   P  n x (n+1):  [P|p] -> T1 = A^T P in place (an S1 work item reads and writes the same rows of its two columns)
+//                  -> [Q_xx|Q_x] in place (an S2 work item reads and writes the same block of its rows) -> V -> [P|p]
+//   G  m x (m + n + 1):  T2 = B^T (P + mu I) at the place of Q_ux -> [Q_uu | Q_ux | Q_u] (S2, in place)
+//   K  [K|d] + T3^T (S3 .. S5 operands); a2 (S5 epilogue, read transposed by S6) takes G and K over once both are dead
+// plus the step's diagonal blocks of [A|B] (k n_s (n_s + n_c) doubles; the dense record rows are never staged).
+// 74 KB at n_x = 60 (two sub-problems per CU; 147 KB and one before), 48 KB at 42 .. 48 (three), 35 KB at 36 (four); the register
+// budget follows (__launch_bounds__).  Phases are separated by workgroup barriers (s_barrier behind an LDS-only wait:
+// the global prefetches stay in flight).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,43 +38,69 @@ constexpr int kWgThreads = 256;
 template <int N, int M, int NS, int NC>
 struct WgCfg {
     static constexpr int NM = N + M, NP = N + 1, MK = round_up(M, 4), KA = N / NS, NSC = NS + NC;
-    static constexpr int LAB = round_up(NM, 2), LP = round_up(NP, 2), LQ = LP, LG = round_up(M + NP, 2), LK = LP;
-    static constexpr int LTB = LP, LM = N, KROWS = MK + 2;
+    static constexpr int LP = round_up(NP, 2), LQ = LP, LK = LP, LM = N, KROWS = MK + 2;
+    static constexpr int MO = round_up(M, 2);                  // column of Q_ux inside a row of G (16-byte aligned)
+    static constexpr int LG = round_up(MO + NP, 2);            // [Q_uu | pad | Q_ux | Q_u]
+    static constexpr int NSCP = round_up(NSC, 2);              // one row of an agent's [A_blk | B_blk]
     static constexpr int T_NP = (NP + 15) / 16, T_N = (N + 15) / 16, T_M = (M + 15) / 16;
-    static constexpr int szAB = N * LAB, szQ = N * LQ;
-    static constexpr int szKT3 = KROWS * LK + MK * N + 16;
-    static constexpr int szR2a = NM * LTB > szKT3 ? NM * LTB : szKT3;
-    static constexpr int szR2 = round_up(szR2a > N * LP ? szR2a : N * LP, 2);
-    static constexpr int szG0 = MK * LG + round_up(N, 2);
-    static constexpr int szG = round_up(szG0 > NP * LM ? szG0 : NP * LM, 2);
-    static constexpr int oAB = 0, oQ = oAB + szAB, oR2 = oQ + szQ, oK = oR2, oT3 = oK + KROWS * LK, oP = oR2, oT = oR2;
-    static constexpr int oG = oR2 + szR2, oQx = oG + MK * LG, oEnd = oG + szG;
+    static constexpr int szP = round_up(N * LP, 2);
+    static constexpr int szG = round_up(MK * LG, 2);
+    // four column tiles (n_x >= 48): wavefront w owns column tile w of T3^T and row tile w of a1, a2, and the fp64 MFMA's
+    // output layout (lane (g, c) holds rows g + 4 v) is its A-operand layout for the reduction rows 4 v .. 4 v + 3, so
+    // T3^T goes from S4's accumulators straight into S5's products: no LDS for it (15 KB at n_x = 60: the difference
+    // between one and two sub-problems per CU), no barrier between S4 and S5
+    static constexpr bool T3REG = (T_NP == 4);
+    static constexpr int szKT3 = KROWS * LK + (T3REG ? 0 : MK * N) + 16;
+    // a2 (n+1 x n, S5 epilogue -> S6) starts at G and runs on into the [K|d] region: both are dead by then
+    static constexpr int szK = round_up(szG + szKT3 >= NP * LM ? szKT3 : NP * LM - szG, 2);
+    static constexpr int szAB = round_up(KA * NS * NSCP, 2);
+    static constexpr int oP = 0, oG = oP + szP, oK = oG + szG, oT3 = oK + KROWS * LK, oAB = oK + szK, oEnd = oAB + szAB;
     static constexpr int total = round_up(oEnd + 64, 2);   // + store target of idle lanes, wrapped tile reads
-    static constexpr bool AL = (NS % 2 == 0) && (NC % 2 == 0);   // every block offset even: 16-byte vector accesses
-    static constexpr bool ALA = (NS % 2 == 0);                   // ... at least the A-column blocks (offsets NS*agent)
+    static constexpr bool ALA = (NS % 2 == 0);                   // an agent's column block starts at an even offset
+    static constexpr bool AL = ALA && (NC % 2 == 0);
     static constexpr int CG = (NP + 1) / 2;                  // S1: column groups of 2 over [P|p]
     static constexpr int NI1 = KA * CG, R1R = (NI1 + kWgThreads - 1) / kWgThreads;
     static constexpr int RPL = 2, RG = (NM + RPL - 1) / RPL;  // S2: row groups
     static constexpr int NI2 = KA * RG, R2R = (NI2 + kWgThreads - 1) / kWgThreads;
-    static constexpr bool ABV = (NM % 2 == 0);                                 // rows of [A|B] split into 16-byte pairs
-    static constexpr int ABE = ABV ? 2 : 1;                                    // doubles per staged element
-    static constexpr int ABR = (N * NM / ABE + kWgThreads - 1) / kWgThreads;   // elements of [A|B] a lane stages
+    static constexpr int ABN = KA * NS * NSC;                                  // doubles in the diagonal blocks of [A|B]
+    static constexpr int ABR = (ABN + kWgThreads - 1) / kWgThreads;            // ... a lane stages
     static constexpr int NT4 = T_M * T_N, TPW4 = (NT4 + 3) / 4;              // S4 tiles, per wavefront
     static constexpr int NT5 = T_NP * T_NP, TPW5 = (NT5 + 3) / 4;            // S5 tiles, per wavefront
+    // sub-problems per CU: what the LDS allows, capped by what the registers allow without spilling (512 / that per lane;
+    // the LU alone holds 4 m of them, the S1 / S2 accumulators 4 (n_s + n_c)).  A spilling build is far slower than a
+    // build with one sub-problem fewer per CU (measured), so the caps follow the compiler's spill-free register counts
+    static constexpr int kLdsFit = (160 * 1024) / (total * 8);
+    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 24 ? 3 : 2)));
+#ifdef DPILQR_WG_OCC   // A/B builds
+    static constexpr int OCC = kLdsFit < DPILQR_WG_OCC ? (kLdsFit < 1 ? 1 : kLdsFit) : DPILQR_WG_OCC;
+#else
+    static constexpr int OCC = kLdsFit < 1 ? 1 : (kLdsFit < kRegFit ? kLdsFit : kRegFit);
+#endif
     static constexpr bool supported = (N % NS == 0) && (M == KA * NC) && (N % 2 == 0) && (M <= 32) && (64 - M > 0) &&
                                       (4 * (64 - M) >= NP) && (total * 8 <= 160 * 1024);
 };
 
+// Pins a phase's accumulators at this point of the program: the multiply-adds that produce them are issued before it, the
+// LDS loads behind it after it.  Without it the instruction selector sinks all multiply-adds of an unrolled reduction
+// behind all of its operand loads (24 n_s registers of loaded rows), and registers decide how many sub-problems share a CU.
+template <int K>
+__device__ __forceinline__ void pin_regs(double (&a)[K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("" : "+v"(a[i]));
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int LEN, bool VEC>
-__device__ __forceinline__ void ld_row(const double* p, double* out) {   // LEN doubles; VEC: p is 16-byte aligned, LEN even
+__device__ __forceinline__ void ld_row(const double* p, double* out) {   // LEN doubles; VEC: p is 16-byte aligned
     if constexpr (VEC) {
 #pragma unroll
         for (int q = 0; q < LEN / 2; ++q) {
             const v2d v = *reinterpret_cast<const v2d*>(p + 2 * q);
             out[2 * q] = v.x; out[2 * q + 1] = v.y;
         }
+        if constexpr (LEN % 2 == 1) out[LEN - 1] = p[LEN - 1];
     } else {
 #pragma unroll
         for (int q = 0; q < LEN; ++q) out[q] = p[q];
@@ -76,6 +111,7 @@ __device__ __forceinline__ void st_row(double* p, const double* v) {
     if constexpr (VEC) {
 #pragma unroll
         for (int q = 0; q < LEN / 2; ++q) *reinterpret_cast<v2d*>(p + 2 * q) = v2d{v[2 * q], v[2 * q + 1]};
+        if constexpr (LEN % 2 == 1) p[LEN - 1] = v[LEN - 1];
     } else {
 #pragma unroll
         for (int q = 0; q < LEN; ++q) p[q] = v[q];
@@ -83,32 +119,38 @@ __device__ __forceinline__ void st_row(double* p, const double* v) {
 }
 
 template <int N, int M, int NS, int NC>
-__global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
+__global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_riccati_wg(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items, int gains_by_item) {
     using C = WgCfg<N, M, NS, NC>;
-    constexpr int NM = C::NM, NP = C::NP, MK = C::MK, KA = C::KA, NSC = C::NSC, LAB = C::LAB, LP = C::LP, LQ = C::LQ;
-    constexpr int LG = C::LG, LK = C::LK, LTB = C::LTB, LM = C::LM, T_NP = C::T_NP, T_N = C::T_N;
+    constexpr int NM = C::NM, NP = C::NP, MK = C::MK, KA = C::KA, NSC = C::NSC, NSCP = C::NSCP, LP = C::LP, LQ = C::LQ;
+    constexpr int LG = C::LG, LK = C::LK, LM = C::LM, MO = C::MO, T_NP = C::T_NP, T_N = C::T_N;
     constexpr bool AL = C::AL, ALA = C::ALA;
     const int slot = blockIdx.x;
     if (slot >= (n_items ? *n_items : B)) return;
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
     const int64_t gslot = gains_by_item ? b : slot;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+    const int tid = threadIdx.x;
     const TileLayout L(N, M);
+    // The lane terms of a phase (tile coordinates, LDS addresses) are recomputed at the phase's start from a thread id the
+    // optimiser cannot see through: hoisted out of the horizon loop they would occupy well over a hundred registers,
+    // which decides how many sub-problems share a CU.
+#define WG_LANE_TERMS()                                                                               \
+    int tid_p = tid;                                                                                  \
+    asm volatile("" : "+v"(tid_p));                                                                   \
+    const int wave = __builtin_amdgcn_readfirstlane(tid_p >> 6), lane = tid_p & 63, g = lane >> 4, c16 = lane & 15; \
+    (void)wave; (void)g; (void)c16;
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* sAB = lds + C::oAB;
-    double* sQ = lds + C::oQ;
-    double* sP = lds + C::oP;
-    double* sT = lds + C::oT;
-    double* sK = lds + C::oK;
+    double* sP = lds + C::oP;          // [P|p] -> T1 -> [Q_xx|Q_x] -> V -> [P|p]
+    double* sQ = sP;
+    double* sG = lds + C::oG;          // T2 (at column MO) -> [Q_uu | Q_ux | Q_u]
+    double* sK = lds + C::oK;          // [K|d]
     double* sT3 = lds + C::oT3;
-    double* sG = lds + C::oG;
-    double* sQx = lds + C::oQx;
-    double* sMt = sG;                  // a2 scratch, after the S5 products
+    double* sMt = sG;                  // a2 scratch, after the S5 products (runs on into the [K|d] region)
+    double* sAB = lds + C::oAB;        // [agent][row of the block][A_blk row | B_blk row], NSCP doubles each
     double* sTrash = lds + C::oEnd;
 
     const double mu = mu_arr[b];
@@ -126,55 +168,62 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
         for (int i = tid; i < N; i += kWgThreads) sP[i * LP + N] = rec[L.oLx + i];
     }
 
-    // ---- S0 staging pattern of [A|B]
+    // ---- S0 staging pattern of the diagonal blocks of [A|B]
     double* ab_dst[C::ABR];
     int ab_src[C::ABR];
 #pragma unroll
     for (int q = 0; q < C::ABR; ++q) {
-        const int e = C::ABE * (tid + kWgThreads * q);
-        const int row = e / NM, col = e - row * NM;
-        ab_dst[q] = (e < N * NM) ? sAB + row * LAB + col : sTrash;
-        ab_src[q] = (e < N * NM) ? L.oA + e : 0;
+        const int e = tid + kWgThreads * q;
+        const int ag = e / (NS * NSC), rem = e - ag * (NS * NSC), l = rem / NSC, c = rem - l * NSC;
+        const int row = NS * ag + l;
+        ab_dst[q] = (e < C::ABN) ? sAB + row * NSCP + c : sTrash + (tid & 1);
+        ab_src[q] = (e < C::ABN) ? L.oA + row * L.ldAB + (c < NS ? NS * ag + c : N + NC * ag + (c - NS)) : 0;
     }
-    double nAB[C::ABR][C::ABE];
+    double nAB[C::ABR];
     auto prefetch_ab = [&](int t) {
         const double* rec = base + (int64_t)t * L.stride;
 #pragma unroll
-        for (int q = 0; q < C::ABR; ++q) ld_row<C::ABE, C::ABV>(rec + ab_src[q], nAB[q]);
+        for (int q = 0; q < C::ABR; ++q) nAB[q] = rec[ab_src[q]];
     };
-    // ---- S1 work items: (agent, 2 columns of [P|p]); S2 work items: (agent, 2 rows of T)
-    int ag1[C::R1R], j01[C::R1R];
-#pragma unroll
-    for (int r = 0; r < C::R1R; ++r) {
-        const int w = min(tid + kWgThreads * r, C::NI1 - 1);
-        ag1[r] = w / C::CG; j01[r] = 2 * (w - ag1[r] * C::CG);
+    // S1 work items: (agent, 2 columns of [P|p]); S2 work items: (agent, 2 rows of T)
+#define WG_ITEMS_S1()                                                                                 \
+    int ag1[C::R1R], j01[C::R1R];                                                                     \
+    _Pragma("unroll") for (int r = 0; r < C::R1R; ++r) {                                              \
+        const int w = min(tid_p + kWgThreads * r, C::NI1 - 1);                                        \
+        ag1[r] = w / C::CG; j01[r] = 2 * (w - ag1[r] * C::CG);                                        \
     }
-    int ag2[C::R2R], ip2[C::R2R][C::RPL];
-#pragma unroll
-    for (int r = 0; r < C::R2R; ++r) {
-        const int w = min(tid + kWgThreads * r, C::NI2 - 1);
-        ag2[r] = w / C::RG;
-        const int rg = w - ag2[r] * C::RG;
-#pragma unroll
-        for (int q = 0; q < C::RPL; ++q) ip2[r][q] = min(C::RPL * rg + q, NM - 1);
+#define WG_ITEMS_S2()                                                                                 \
+    int ag2[C::R2R], ip2[C::R2R][C::RPL];                                                             \
+    _Pragma("unroll") for (int r = 0; r < C::R2R; ++r) {                                              \
+        const int w = min(tid_p + kWgThreads * r, C::NI2 - 1);                                        \
+        ag2[r] = w / C::RG;                                                                           \
+        const int rg = w - ag2[r] * C::RG;                                                            \
+        _Pragma("unroll") for (int q = 0; q < C::RPL; ++q) ip2[r][q] = min(C::RPL * rg + q, NM - 1);  \
     }
-    // ---- S3: lanes 0..M-1 hold Q_uu's columns, lanes M..63 this wavefront's right-hand sides
+    // S3: lanes 0..M-1 hold Q_uu's columns, lanes M..63 this wavefront's right-hand sides
     constexpr int RW = 64 - M;
-    const int s3_q = RW * wave + (lane - M);
-    const bool s3_rhs = lane >= M && s3_q < NP;
-    const int s3_col = lane < M ? lane : M + min(max(s3_q, 0), N);
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + kWgThreads - 1) / kWgThreads;
 
     prefetch_ab(T - 1);
     wg_barrier();
 
+#ifdef DPILQR_PHASE_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define WPHASE(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define WPHASE(i)
+#endif
     for (int t = T - 1; t >= 0; --t) {
         const int tn = t > 0 ? t - 1 : 0;
         const double* rec = base + (int64_t)t * L.stride;
         // ---- S0
 #pragma unroll
-        for (int q = 0; q < C::ABR; ++q) st_row<C::ABE, C::ABV>(ab_dst[q], nAB[q]);
-        // this step's l-values: requested now, used by the S1 / S2 epilogues
+        for (int q = 0; q < C::ABR; ++q) *ab_dst[q] = nAB[q];
+        prefetch_ab(tn);
+        // this step's [l_x | l_u]: requested now, used by the S1 epilogue
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+        WG_ITEMS_S1()
         double nX[C::R1R][NSC];
 #pragma unroll
         for (int r = 0; r < C::R1R; ++r) {
@@ -185,7 +234,60 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                 ld_row<NC, AL>(rec + L.oLu + NC * ag1[r], nX[r] + NS);
             }
         }
+        wg_barrier();
+        WPHASE(0)
+
+        __builtin_amdgcn_s_setprio(1);   // vector-pipe phases win arbitration over another workgroup's MFMA phases
+        // ---- S1: [A|B]^T [P|p], block diagonal.  T1 replaces P in place (this work item is the only reader and the only
+        // writer of its agent's rows of its two columns); T2 goes where S2 will turn it into Q_ux
+#pragma unroll
+        for (int r = 0; r < C::R1R; ++r) {
+            const int ag = ag1[r], j0 = j01[r];
+            double acc[NSC * 2];   // [i][c]
+            double ab[2][NSC], pr[2][2];   // the operand rows of l and l + 1
+            ld_row<NSC, true>(sAB + (NS * ag) * NSCP, ab[0]);
+            ld_row<2, true>(sP + (NS * ag) * LP + j0, pr[0]);
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                if (l + 1 < NS) {
+                    ld_row<NSC, true>(sAB + (NS * ag + l + 1) * NSCP, ab[(l + 1) & 1]);
+                    ld_row<2, true>(sP + (NS * ag + l + 1) * LP + j0, pr[(l + 1) & 1]);
+                }
+#pragma unroll
+                for (int i = 0; i < NSC; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[2 * i + c] = (l == 0) ? ab[l & 1][i] * pr[l & 1][c] : fma(ab[l & 1][i], pr[l & 1][c], acc[2 * i + c]);
+                pin_regs(acc);
+            }
+            // T2 rows: + mu B[j][c]   (quirk Q6: B^T (P + mu I) = B^T P + mu B^T); row j of B is zero outside agent j / NS
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = min(j0 + c, N - 1);
+                double bm[NC];
+                ld_row<NC, AL>(sAB + j * NSCP + NS, bm);
+                const bool on = (j0 + c < N) && (j / NS == ag);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) acc[2 * (NS + i) + c] = fma(mu, on ? bm[i] : 0.0, acc[2 * (NS + i) + c]);
+            }
+            if (tid_p + kWgThreads * r < C::NI1) {
+                if (j0 < N) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) st_row<2, true>(sP + (NS * ag + i) * LP + j0, acc + 2 * i);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) st_row<2, true>(sG + (NC * ag + i) * LG + MO + j0, acc + 2 * (NS + i));
+                } else {   // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) sP[(NS * ag + i) * LP + N] = nX[r][i] + acc[2 * i];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) sG[(NC * ag + i) * LG + MO + N] = nX[r][NS + i] + acc[2 * (NS + i)];
+                }
+            }
+        }
+        // the S2 l-values: requested here (not at the top of the step: they would be held across S1)
         double nL[C::R2R][C::RPL][NSC];
+        {
+        WG_ITEMS_S2()
 #pragma unroll
         for (int r = 0; r < C::R2R; ++r)
 #pragma unroll
@@ -200,91 +302,66 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                     ld_row<NC, AL>(rec + L.oLuu + (ip - N) * L.ldUG + NC * ag2[r], nL[r][q] + NS);
                 }
             }
-        wg_barrier();
-
-        __builtin_amdgcn_s_setprio(1);   // vector-pipe phases win arbitration over another workgroup's MFMA phases
-        // ---- S1: [A|B]^T [P|p], block diagonal
-        {
-            double acc[C::R1R][NSC][2];
-#pragma unroll
-            for (int r = 0; r < C::R1R; ++r) {
-                const int ag = ag1[r], j0 = j01[r];
-#pragma unroll
-                for (int l = 0; l < NS; ++l) {
-                    double ab[NSC], pr[2];
-                    ld_row<NS, ALA>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
-                    ld_row<NC, AL>(sAB + (NS * ag + l) * LAB + N + NC * ag, ab + NS);
-                    ld_row<2, true>(sP + (NS * ag + l) * LP + j0, pr);
-#pragma unroll
-                    for (int i = 0; i < NSC; ++i)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) acc[r][i][c] = (l == 0) ? ab[i] * pr[c] : fma(ab[i], pr[c], acc[r][i][c]);
-                }
-                // T2 rows: + mu B[j][c]   (quirk Q6: B^T (P + mu I) = B^T P + mu B^T)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double bm[NC];
-                    ld_row<NC, AL>(sAB + min(j0 + c, N - 1) * LAB + N + NC * ag, bm);
-#pragma unroll
-                    for (int i = 0; i < NC; ++i) acc[r][NS + i][c] = fma(mu, (j0 + c < N) ? bm[i] : 0.0, acc[r][NS + i][c]);
-                }
-            }
-            wg_barrier();   // every read of [P|p] is done: T takes its place
-#pragma unroll
-            for (int r = 0; r < C::R1R; ++r) {
-                const int ag = ag1[r], j0 = j01[r];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) st_row<2, true>(sT + (NS * ag + i) * LTB + j0, acc[r][i]);
-#pragma unroll
-                for (int i = 0; i < NC; ++i) st_row<2, true>(sT + (N + NC * ag + i) * LTB + j0, acc[r][NS + i]);
-                if (j0 == N) {   // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) sQx[NS * ag + i] = nX[r][i] + acc[r][i][0];
-#pragma unroll
-                    for (int i = 0; i < NC; ++i) sG[(NC * ag + i) * LG + M + N] = nX[r][NS + i] + acc[r][NS + i][0];
-                }
-            }
         }
         wg_barrier();
+        WPHASE(1)
 
-        // ---- S2: [T1;T2][A|B] + l-values -> Q_xx (rows < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped
+        // ---- S2: [T1;T2][A|B] + l-values -> Q_xx (rows < n), [Q_uu | Q_ux] (rows >= n); the T1 B block is dropped.
+        // In place: a work item reads its rows' entries of its agent's column block and writes the same entries
+        {
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+        WG_ITEMS_S2()
 #pragma unroll
         for (int r = 0; r < C::R2R; ++r) {
             const int ag = ag2[r];
-            double acc[C::RPL][NSC], tv[C::RPL][NS];
-#pragma unroll
-            for (int q = 0; q < C::RPL; ++q) ld_row<NS, ALA>(sT + ip2[r][q] * LTB + NS * ag, tv[q]);
-#pragma unroll
-            for (int l = 0; l < NS; ++l) {
-                double ab[NSC];
-                ld_row<NS, ALA>(sAB + (NS * ag + l) * LAB + NS * ag, ab);
-                ld_row<NC, AL>(sAB + (NS * ag + l) * LAB + N + NC * ag, ab + NS);
-#pragma unroll
-                for (int q = 0; q < C::RPL; ++q)
-#pragma unroll
-                    for (int c = 0; c < NSC; ++c) acc[q][c] = (l == 0) ? tv[q][l] * ab[c] : fma(tv[q][l], ab[c], acc[q][c]);
-            }
+            double acc[C::RPL * NSC], tv[C::RPL][NS];   // acc [q][c]
 #pragma unroll
             for (int q = 0; q < C::RPL; ++q) {
                 const int ip = ip2[r][q];
-                double o[NSC];
+                ld_row<NS, ALA>((ip < N ? sP + ip * LP : sG + (ip - N) * LG + MO) + NS * ag, tv[q]);
+            }
+            double ab[2][NSC];
+            ld_row<NSC, true>(sAB + (NS * ag) * NSCP, ab[0]);
 #pragma unroll
-                for (int c = 0; c < NSC; ++c) o[c] = nL[r][q][c] + acc[q][c];
-                if (ip < N) {
-                    st_row<NS, ALA>(sQ + ip * LQ + NS * ag, o);
-                } else {
-                    st_row<NS, AL>(sG + (ip - N) * LG + M + NS * ag, o);
-                    st_row<NC, AL>(sG + (ip - N) * LG + NC * ag, o + NS);
+            for (int l = 0; l < NS; ++l) {
+                if (l + 1 < NS) ld_row<NSC, true>(sAB + (NS * ag + l + 1) * NSCP, ab[(l + 1) & 1]);
+#pragma unroll
+                for (int q = 0; q < C::RPL; ++q)
+#pragma unroll
+                    for (int c = 0; c < NSC; ++c)
+                        acc[q * NSC + c] = (l == 0) ? tv[q][l] * ab[l & 1][c] : fma(tv[q][l], ab[l & 1][c], acc[q * NSC + c]);
+                pin_regs(acc);
+            }
+            if (tid_p + kWgThreads * r < C::NI2) {
+#pragma unroll
+                for (int q = 0; q < C::RPL; ++q) {
+                    const int ip = ip2[r][q];
+                    if (q > 0 && ip == ip2[r][q - 1]) continue;   // the clamped last row of an odd n + m
+                    double o[NSC];
+#pragma unroll
+                    for (int c = 0; c < NSC; ++c) o[c] = nL[r][q][c] + acc[q * NSC + c];
+                    if (ip < N) {
+                        st_row<NS, ALA>(sQ + ip * LQ + NS * ag, o);
+                    } else {
+                        st_row<NS, ALA>(sG + (ip - N) * LG + MO + NS * ag, o);
+                        st_row<NC, AL>(sG + (ip - N) * LG + NC * ag, o + NS);
+                    }
                 }
             }
         }
-        wg_barrier();
-        // T is dead: [K | d] takes its place; its reduction-padding rows must read as zero.  Q_x joins Q_xx.
+        }
+        // [K | d]'s reduction-padding rows must read as zero (the previous step's a2 may have reached them)
         for (int e = tid; e < (C::KROWS - M) * LK; e += kWgThreads) sK[M * LK + e] = 0.0;
-        if (tid < N) sQ[tid * LQ + N] = sQx[tid];
+        wg_barrier();
+        WPHASE(2)
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers, once per wavefront
         {
+            WG_LANE_TERMS()
+            const int s3_q = RW * wave + (lane - M);
+            const bool s3_rhs = lane >= M && s3_q < NP;
+            const int s3_col = lane < M ? lane : MO + min(max(s3_q, 0), N);
             double v[M], invd[M];
 #pragma unroll
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + s3_col];
@@ -311,21 +388,53 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
         }
         wg_barrier();
         {
+            int tid_p = tid;
+            asm volatile("" : "+v"(tid_p));
             double* Kt = Kout + (gslot * T + t) * M * N;
             double* dt_ = dout + (gslot * T + t) * M;
 #pragma unroll
             for (int q = 0; q < K_ROUNDS; ++q) {
-                const int e = 2 * min(tid + kWgThreads * q, K_PAIRS - 1);
+                const int e = 2 * min(tid_p + kWgThreads * q, K_PAIRS - 1);
                 store_v2d_nt(Kt + e, *reinterpret_cast<const v2d*>(sK + (e / N) * LK + (e % N)));
             }
-            const int di = min(tid, M - 1);
+            const int di = min(tid_p, M - 1);
             store_f64_nt(dt_ + di, sK[di * LK + N]);
         }
-        prefetch_ab(tn);
+        WPHASE(3)
 
         __builtin_amdgcn_s_setprio(0);
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
+        // ---- S5: a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] ; V = ((Q + a1) + a2) + a2^T   (rows < n, cols <= n)
+        v4d a1[C::TPW5], a2[C::TPW5];
+        if constexpr (C::T3REG) {
+            WG_LANE_TERMS()
+            static_assert(!C::T3REG || (C::TPW5 == T_NP && C::T_M <= 2), "wavefront w owns row tile w");
+            v4d t3[C::T_M];
+#pragma unroll
+            for (int it = 0; it < C::T_M; ++it) {
+                const double* px = sG + g * LG + c16 + 16 * it;
+                const double* py = sK + g * LK + c16 + 16 * wave;
+                t3[it] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < MK / 4; ++ks) t3[it] = mfma_f64(px[ks * 4 * LG], py[ks * 4 * LK], t3[it]);
+            }
+            WPHASE(4)
+#pragma unroll
+            for (int q = 0; q < C::TPW5; ++q) {   // tile (row tile wave, column tile q)
+                const double* pkj = sK + g * LK + c16 + 16 * q;
+                const double* pki = sK + g * LK + c16 + 16 * wave;
+                const double* pgj = sG + g * LG + MO + c16 + 16 * q;
+                a1[q] = v4d{0.0, 0.0, 0.0, 0.0};
+                a2[q] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < MK / 4; ++ks) {
+                    a1[q] = mfma_f64(t3[ks / 4][ks % 4], pkj[ks * 4 * LK], a1[q]);
+                    a2[q] = mfma_f64(pki[ks * 4 * LK], pgj[ks * 4 * LG], a2[q]);
+                }
+            }
+        } else {
         {
+            WG_LANE_TERMS()
             v4d acc[C::TPW4];
 #pragma unroll
             for (int q = 0; q < C::TPW4; ++q) {
@@ -350,10 +459,9 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
             }
         }
         wg_barrier();
-
-        // ---- S5: a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] ; V = ((Q + a1) + a2) + a2^T   (rows < n, cols <= n)
+        WPHASE(4)
         {
-            v4d a1[C::TPW5], a2[C::TPW5];
+            WG_LANE_TERMS()
 #pragma unroll
             for (int q = 0; q < C::TPW5; ++q) {
                 const int tl = min(wave + 4 * q, C::NT5 - 1);
@@ -361,7 +469,7 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                 const double* pt3 = sT3 + g * N + c16 + 16 * it;
                 const double* pkj = sK + g * LK + c16 + 16 * jt;
                 const double* pki = sK + g * LK + c16 + 16 * it;
-                const double* pgj = sG + g * LG + M + c16 + 16 * jt;
+                const double* pgj = sG + g * LG + MO + c16 + 16 * jt;
                 a1[q] = v4d{0.0, 0.0, 0.0, 0.0};
                 a2[q] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -370,11 +478,15 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                     a2[q] = mfma_f64(pki[ks * 4 * LK], pgj[ks * 4 * LG], a2[q]);
                 }
             }
-            wg_barrier();   // every operand read of G is done: a2 goes there for the transposed read
+        }
+        }
+        {
+            WG_LANE_TERMS()
+            wg_barrier();   // every operand read of G, [K|d], T3^T is done: a2 goes there for the transposed read
             double W[C::TPW5][4];
 #pragma unroll
             for (int q = 0; q < C::TPW5; ++q) {
-                const int tl = wave + 4 * q;
+                const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
                 const int tc = min(tl, C::NT5 - 1);
                 const int it = tc / T_NP, jt = tc - it * T_NP;
                 const int j = 16 * jt + c16;
@@ -392,10 +504,11 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                 }
             }
             wg_barrier();
-            // ---- S6: V = W + a2^T ; V^T from the mirrored pair (same operands, same order) ; P <- (V + V^T)/2
+            // ---- S6: V = W + a2^T ; V^T from the mirrored pair (same operands, same order) ; P <- (V + V^T)/2.
+            // P takes W's place: every transposed read of W happens before the barrier, every store after it
 #pragma unroll
             for (int q = 0; q < C::TPW5; ++q) {
-                const int tl = wave + 4 * q;
+                const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
                 const int tc = min(tl, C::NT5 - 1);
                 const int it = tc / T_NP, jt = tc - it * T_NP;
                 const int j = 16 * jt + c16;
@@ -409,14 +522,32 @@ __global__ __launch_bounds__(kWgThreads) void k_riccati_wg(
                             const double Vt = sQ[j * LQ + i] + a2[q][v];
                             out = 0.5 * (V + Vt);
                         }
-                        sP[i * LP + j] = out;
+                        W[q][v] = out;
                     }
+                }
+            }
+            wg_barrier();
+#pragma unroll
+            for (int q = 0; q < C::TPW5; ++q) {
+                const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
+                const int tc = min(tl, C::NT5 - 1);
+                const int it = tc / T_NP, jt = tc - it * T_NP;
+                const int j = 16 * jt + c16;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * it + g + 4 * v;
+                    if (tl < C::NT5 && i < N && j <= N) sP[i * LP + j] = W[q][v];
                 }
             }
         }
         wg_barrier();
+        WPHASE(5)
     }
     if (singular && sing && tid == 0) singular[b] = 1;
+#ifdef DPILQR_PHASE_STAMPS
+    if (g_stamp_buf && tid == 0)
+        for (int i = 0; i < 7; ++i) g_stamp_buf[4 * B + 8 * slot + i] = ph[i];
+#endif
 }
 
 }  // namespace dpilqr

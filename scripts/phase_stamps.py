@@ -31,6 +31,36 @@ from dpilqr_amd.device import empty, ptr, stream_handle, to_dev  # noqa: E402
 from bench import K_AGENTS, N_U, N_X, T, scenarios  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 fused = "--fused" in sys.argv
+if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/phase_stamps.py --wg B k [quad6|uni4]
+    from dpilqr_amd.util import random_setup
+    B, k = int(args[0]), int(args[1])
+    mdl, ns, nc, nd, Tw = (3, 4, 2, 2, 100) if (len(args) > 2 and args[2] == "uni4") else (4, 6, 3, 3, 75)
+    n, m = k * ns, k * nc
+    x0 = np.zeros((B, n)); xf = np.zeros((B, n))
+    for s_ in range(B):
+        np.random.seed(500 + s_)
+        a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0)
+        x0[s_], xf[s_] = a.ravel(), b.ravel()
+    U0 = np.zeros((B, Tw, m))
+    if mdl == 4:
+        U0[:, :, 0::3] = 9.80665
+    pb = dp.ProblemBatch([mdl] * k, [nd] * k, xf, (50.0 * np.eye(6)) if mdl == 4 else np.diag([1.0, 1, 0, 0]), np.eye(nc), 1000.0 * np.eye(ns), 0.5, 0.1, Tw)
+    r = pb.solve(x0, U0, n_lqr_iter=2)
+    tl = pb.make_tiles(r["X"], r["U"])
+    mu = to_dev(np.full(B, 0.125)); K = empty((B, Tw, m, n)); d = empty((B, Tw, m))
+    lib = _lib.load()
+    buf = torch.zeros((B * 12,), dtype=torch.int64, device="cuda")
+    _lib.check(lib.dpilqr_debug_stamps(ptr(buf)))
+    for rep in range(2):
+        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, Tw, n, m, ns, nc, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+    torch.cuda.synchronize()
+    ph = buf.cpu().numpy()[4 * B:].reshape(B, 8)[:, :7] / Tw
+    names = ["S0 stage AB, request l-values", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6", "-"]
+    tot = ph.sum(1).mean()
+    for nm_, v in zip(names, ph.mean(0)):
+        print(f"{nm_:30s} {v:8.0f} ticks/step  {100 * v / tot:5.1f} %")
+    print(f"k_riccati_wg n_x={n}: total {tot:.0f} ticks/step (s_memtime ticks, 100 MHz)")
+    sys.exit(0)
 B = int(args[0]) if args else 1024
 x0, xf = scenarios(0, B)
 pb = dp.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
