@@ -357,7 +357,12 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
         WPHASE(2)
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers, once per wavefront
-        {
+        // Only as many wavefronts as the right-hand sides need take part (one up to m = 21, two beyond): the others'
+        // copies of the factorisation would only take issue slots from the sub-problems that share the CU.
+        constexpr int NWLU = (NP + RW - 1) / RW;
+        int lu_wave = tid >> 6;
+        asm volatile("" : "+v"(lu_wave));
+        if (__builtin_amdgcn_readfirstlane(lu_wave) < NWLU) {
             WG_LANE_TERMS()
             const int s3_q = RW * wave + (lane - M);
             const bool s3_rhs = lane >= M && s3_q < NP;
