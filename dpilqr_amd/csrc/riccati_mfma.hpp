@@ -169,8 +169,10 @@ __device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool c
 
 // In-register LU of S3: lane = column (of Q_uu or of a right-hand side), v[r] = its entry in row r.  SEARCH: with
 // dgetf2's partial pivoting; without, for matrices that are known not to need a row swap (see S3).
-template <bool SEARCH, int M, bool ROWLU>
-__device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[M], int& sing) {
+// KEEPINV = false: the reciprocal pivots are not kept (invd has one element and is not written): the caller's substitution
+// recomputes them from U's diagonal with the same instructions (same bits), for 2 m registers less.
+template <bool SEARCH, int M, bool ROWLU, bool KEEPINV = true>
+__device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[KEEPINV ? M : 1], int& sing, int* swaps = nullptr) {
     double v[M];   // a local copy: the row swap below must stay a chain of register moves, never an indexed access
 #pragma unroll
     for (int r = 0; r < M; ++r) v[r] = v_io[r];
@@ -185,6 +187,7 @@ __device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[M
             for (int r = kk + 1; r < M; ++r) mx = fmax(mx, fabs(v[r]));
             const unsigned long long need = __builtin_amdgcn_ballot_w64(mx > fabs(v[kk]));
             if ((need >> kk) & 1ull) {
+                if (swaps) *swaps += 1;   // diagnostic builds only
                 int piv = kk;
                 double best = fabs(v[kk]);
 #pragma unroll
@@ -208,7 +211,7 @@ __device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[M
         double inv = __builtin_amdgcn_rcp(pv);
         inv = fma(fma(-pv, inv, 1.0), inv, inv);
         inv = fma(fma(-pv, inv, 1.0), inv, inv);
-        invd[kk] = inv;
+        if constexpr (KEEPINV) invd[kk] = inv;
         if constexpr (ROWLU) {
             // every lane scales its own entries; the one that matters (minus the multiplier, in lane kk of the row)
             // reaches the row inside the fused multiply-add: fma(-l, v[kk], v[r]) with l = v[r]@kk * inv, bit for bit

@@ -54,7 +54,13 @@ struct WgCfg {
     // a2 (n+1 x n, S5 epilogue -> S6) starts at G and runs on into the [K|d] region: both are dead by then
     static constexpr int szK = round_up(szG + szKT3 >= NP * LM ? szKT3 : NP * LM - szG, 2);
     static constexpr int szAB = round_up(KA * NS * NSCP, 2);
-    static constexpr int oP = 0, oG = oP + szP, oK = oG + szG, oT3 = oK + KROWS * LK, oAB = oK + szK, oEnd = oAB + szAB;
+    // S3 by blocks (gj_blocked below) from m = 24 on, where the register budget of two sub-problems per CU holds both it and
+    // the fall-back (below that it spills at three or four per CU, and the LU is a smaller part of the step): 32 x 4 doubles
+    // per wavefront to turn a panel's columns into rows
+    static constexpr bool GJ = (M >= 24);
+    static constexpr int szPan = GJ ? 4 * 128 : 0;
+    static constexpr int oP = 0, oG = oP + szP, oK = oG + szG, oT3 = oK + KROWS * LK, oAB = oK + szK, oPan = oAB + szAB,
+                         oEnd = oPan + szPan;
     static constexpr int total = round_up(oEnd + 64, 2);   // + store target of idle lanes, wrapped tile reads
     static constexpr bool ALA = (NS % 2 == 0);                   // an agent's column block starts at an even offset
     static constexpr bool AL = ALA && (NC % 2 == 0);
@@ -70,7 +76,7 @@ struct WgCfg {
     // the LU alone holds 4 m of them, the S1 / S2 accumulators 4 (n_s + n_c)).  A spilling build is far slower than a
     // build with one sub-problem fewer per CU (measured), so the caps follow the compiler's spill-free register counts
     static constexpr int kLdsFit = (160 * 1024) / (total * 8);
-    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 24 ? 3 : 2)));
+    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 22 ? 3 : 2)));
 #ifdef DPILQR_WG_OCC   // A/B builds
     static constexpr int OCC = kLdsFit < DPILQR_WG_OCC ? (kLdsFit < 1 ? 1 : kLdsFit) : DPILQR_WG_OCC;
 #else
@@ -116,6 +122,137 @@ __device__ __forceinline__ void st_row(double* p, const double* v) {
 #pragma unroll
         for (int q = 0; q < LEN; ++q) p[q] = v[q];
     }
+}
+
+
+// S3 by blocks: [K | d] = -Q_uu^-1 [Q_ux | Q_u] by Gauss-Jordan elimination on 4-column panels, the row operations of a panel
+// applied to everything to its right as ONE fp64 MFMA per 16 x 16 tile.
+//
+// The register LU (lu_eliminate) is a chain of m^2 / 2 broadcast-multiply-add steps, three to four instructions each --
+// 50 k cycles at m = 30, 60 % of a sweep step.  Here a wavefront keeps [Q_uu | its 16 right-hand sides] in the MFMA's
+// output layout (lane (g, c) holds rows 16 it + g + 4 v of column 16 jt + c).  In that layout the four rows of a panel,
+// K .. K + 3 with K = 16 it + 4 v, are ONE register across the lane groups g = 0 .. 3 -- which is exactly the B operand
+// of v_mfma_f64_16x16x4 (lane (g, c) supplies row g of the 4-row reduction block).  So a panel step is:
+//   1. the panel's four columns go through LDS into "row layout" (every 16-lane row holds matrix rows c and 16 + c);
+//   2. Gauss-Jordan on those four columns in registers, multipliers in-lane, pivot-row entries by DPP row broadcast,
+//      applied at the same time to the 4 columns of the identity that belong to the panel's rows: that yields W (m x 4),
+//      the panel's part of the row-operation matrix (pivot rows scaled so that the diagonal becomes 1);
+//   3. [everything right of the panel] = [the same with the panel's rows cleared] + W * [the panel's rows]: one MFMA per tile,
+//      A operand = W (a lane picks column g of its rows), B operand = the accumulator register that holds the panel's rows.
+// After the last panel Q_uu has become I and the right-hand sides hold the solution; no substitution pass.
+//
+// Pivoting: threshold pivoting that prefers the diagonal.  The diagonal entry is the pivot as long as no entry below it in its
+// column is more than 8 times larger (the classical threshold rule of sparse LU, there with 0.1: element growth per step is
+// bounded by 1 + 8 instead of partial pivoting's 2).  Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is
+// NOT always positive definite away from a minimum (half of the steps of a fresh 15-unicycle iterate have a negative pivot),
+// which is why the rule looks at magnitudes.  If the rule fails anywhere, or a pivot is zero / not finite, nothing has been
+// written and the caller runs LAPACK-order partial pivoting (lu_eliminate<true>) instead.  Every wavefront factorises the
+// same Q_uu with the same instructions, so all of them take the same decision.
+template <int M, int MO, int LG, int LK, int NP>
+__device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double* __restrict__ sK, double* __restrict__ sPan,
+                                           int wave, int lane) {
+    constexpr int MK = round_up(M, 4), RT = (M + 15) / 16, CT = RT + 1, NPAN = MK / 4;
+    const int g = lane >> 4, c = lane & 15;
+    v4d acc[RT][CT];
+#pragma unroll
+    for (int it = 0; it < RT; ++it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * it + g + 4 * v;
+#pragma unroll
+            for (int jt = 0; jt < RT; ++jt) {
+                const int col = 16 * jt + c;
+                const double x = sG[min(row, M - 1) * LG + min(col, M - 1)];
+                acc[it][jt][v] = (row < M && col < M) ? x : (row == col ? 1.0 : 0.0);   // identity beyond m
+            }
+            const int q = 16 * wave + c;
+            const double y = sG[min(row, M - 1) * LG + MO + min(q, NP - 1)];
+            acc[it][RT][v] = (row < M && q < NP) ? y : 0.0;
+        }
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < NPAN; ++p) {
+        const int Kp = 4 * p, itp = Kp / 16, vp = (Kp % 16) / 4, cp = Kp % 16;
+        // 1. the panel's columns -> row layout
+        if (c >= cp && c < cp + 4) {
+#pragma unroll
+            for (int it = 0; it < RT; ++it)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sPan[(16 * it + g + 4 * v) * 4 + (c - cp)] = acc[it][itp][v];
+        }
+        DPILQR_LDS_FENCE();
+        double pan[RT][4], W[RT][4];
+#pragma unroll
+        for (int it = 0; it < RT; ++it) {
+            const v2d x = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4);
+            const v2d y = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4 + 2);
+            pan[it][0] = x.x; pan[it][1] = x.y; pan[it][2] = y.x; pan[it][3] = y.y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) W[it][j] = (16 * it + c == Kp + j) ? 1.0 : 0.0;
+        }
+        DPILQR_LDS_FENCE();
+        // 2. Gauss-Jordan on the panel, W alongside
+        double invs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int L = cp + j;
+            const double pv = mov_row(pan[itp][j], L);
+            double inv = __builtin_amdgcn_rcp(pv);
+            inv = fma(fma(-pv, inv, 1.0), inv, inv);
+            inv = fma(fma(-pv, inv, 1.0), inv, inv);
+            invs[j] = inv;
+            bad = bad || !(fabs(pv) > 0.0) || !(fabs(pv) < 1.0e300);
+            const double ninv = -inv;
+            double l[RT];
+#pragma unroll
+            for (int it = 0; it < RT; ++it) {
+                const int row = 16 * it + c;
+                const double a = pan[it][j];
+                bad = bad || (row > Kp + j && 0.125 * fabs(a) > fabs(pv));
+                l[it] = (row != Kp + j) ? a * ninv : 0.0;
+            }
+#pragma unroll
+            for (int jj = j + 1; jj < 4; ++jj)
+#pragma unroll
+                for (int it = 0; it < RT; ++it) pan[it][jj] = fmac_row(pan[it][jj], pan[itp][jj], l[it], L);
+#pragma unroll
+            for (int jp = 0; jp < j; ++jp)
+#pragma unroll
+                for (int it = 0; it < RT; ++it) W[it][jp] = fmac_row(W[it][jp], W[itp][jp], l[it], L);
+#pragma unroll
+            for (int it = 0; it < RT; ++it) W[it][j] = (16 * it + c != Kp + j) ? l[it] : W[it][j];
+        }
+        {   // the pivot rows, scaled: the diagonal becomes 1
+            double sc = 1.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc = (c == cp + j) ? invs[j] : sc;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) W[itp][jp] = W[itp][jp] * sc;
+        }
+        // 3. everything from the panel's tile on: += W * (the panel's rows), the panel's rows themselves replaced
+        double a_op[RT];
+#pragma unroll
+        for (int it = 0; it < RT; ++it) a_op[it] = g == 0 ? W[it][0] : (g == 1 ? W[it][1] : (g == 2 ? W[it][2] : W[it][3]));
+        const int jt_first = (Kp + 4) / 16 < RT ? (Kp + 4) / 16 : itp;   // the tile the next panel's columns are in goes first
+#pragma unroll
+        for (int jo = 0; jo < CT; ++jo) {
+            const int jt = jo == 0 ? jt_first : (jo <= jt_first ? jo - 1 : jo);
+            if (jt < itp) continue;   // columns left of the panel's tile are done (unit columns, zero in the panel's rows)
+            const double b = acc[itp][jt][vp];
+            acc[itp][jt][vp] = 0.0;
+#pragma unroll
+            for (int it = 0; it < RT; ++it) acc[it][jt] = mfma_f64(a_op[it], b, acc[it][jt]);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return true;
+#pragma unroll
+    for (int it = 0; it < RT; ++it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * it + g + 4 * v, q = 16 * wave + c;
+            if (row < M && q < NP) sK[row * LK + q] = -acc[it][RT][v];
+        }
+    return false;
 }
 
 template <int N, int M, int NS, int NC>
@@ -357,17 +494,32 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
         WPHASE(2)
 
         // ---- S3: [K | d] = -Q_uu^-1 [Q_ux | Q_u] : LU with partial pivoting in registers, once per wavefront
-        // Only as many wavefronts as the right-hand sides need take part (one up to m = 21, two beyond): the others'
-        // copies of the factorisation would only take issue slots from the sub-problems that share the CU.
+        // By blocks first (every wavefront that owns a 16-column tile of right-hand sides); if that declines (a diagonal
+        // pivot too small for its column), LAPACK-order partial pivoting in registers, for which only as many wavefronts as
+        // the right-hand sides need take part (one up to m = 21, two beyond): further copies of the factorisation would
+        // only take issue slots from the sub-problems that share the CU.
         constexpr int NWLU = (NP + RW - 1) / RW;
         int lu_wave = tid >> 6;
         asm volatile("" : "+v"(lu_wave));
-        if (__builtin_amdgcn_readfirstlane(lu_wave) < NWLU) {
+        lu_wave = __builtin_amdgcn_readfirstlane(lu_wave);
+        bool lu_needed = lu_wave < NWLU;
+        if constexpr (C::GJ) {
+            static_assert(!C::GJ || NWLU <= T_NP, "the wavefronts of the fall-back must have seen the blocked attempt fail");
+            if (lu_wave < T_NP) {
+                WG_LANE_TERMS()
+                const bool declined = gj_blocked<M, MO, LG, LK, NP>(sG, sK, lds + C::oPan + 128 * wave, wave, lane);
+                lu_needed = lu_needed && declined;
+#ifdef DPILQR_PHASE_STAMPS
+                if (!declined) ph[6] += 1000;   // diagnostic: share of the steps solved by blocks (per mille)
+#endif
+            }
+        }
+        if (lu_needed) {
             WG_LANE_TERMS()
             const int s3_q = RW * wave + (lane - M);
             const bool s3_rhs = lane >= M && s3_q < NP;
             const int s3_col = lane < M ? lane : MO + min(max(s3_q, 0), N);
-            double v[M], invd[M];
+            double v[M], invd[1];   // the reciprocal pivots are recomputed in the substitution: 2 m registers less
 #pragma unroll
             for (int r = 0; r < M; ++r) v[r] = sG[r * LG + s3_col];
             // strictly column-dominant Q_uu: no row moves, the elimination runs without the pivot search
@@ -377,14 +529,27 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
             for (int r = 0; r < M; ++r) colsum = colsum + fabs(v[r]);
             const double dg = fabs(sG[min(lane, M - 1) * (LG + 1)]);
             const bool dominant = lane >= M || dg * (1.0 - 0x1p-20) > colsum - dg;
-            if (__builtin_amdgcn_ballot_w64(!dominant) == 0ull) lu_eliminate<false, M, false>(v, invd, sing);
-            else lu_eliminate<true, M, false>(v, invd, sing);
+            const bool no_swaps = __builtin_amdgcn_ballot_w64(!dominant) == 0ull;
+#ifdef DPILQR_PHASE_STAMPS
+            if (!C::GJ && no_swaps) ph[6] += 1000;   // diagnostic: share of the steps with the search-free elimination
+            int n_swaps = 0;
+            if (no_swaps) lu_eliminate<false, M, false, false>(v, invd, sing);
+            else lu_eliminate<true, M, false, false>(v, invd, sing, &n_swaps);
+            if (n_swaps > 0) ph[7] += 1000;   // ... and of the steps in which partial pivoting moved a row
+#else
+            if (no_swaps) lu_eliminate<false, M, false, false>(v, invd, sing);
+            else lu_eliminate<true, M, false, false>(v, invd, sing);
+#endif
 #pragma unroll
             for (int r = M - 1; r >= 0; --r) {
                 double s = v[r];
 #pragma unroll
                 for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
-                v[r] = s * invd[r];
+                const double pv = readlane_f64(v[r], r);   // U's diagonal: the pivot of step r
+                double inv = __builtin_amdgcn_rcp(pv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                v[r] = s * inv;
             }
             if (s3_rhs) {
 #pragma unroll
@@ -551,7 +716,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
     if (singular && sing && tid == 0) singular[b] = 1;
 #ifdef DPILQR_PHASE_STAMPS
     if (g_stamp_buf && tid == 0)
-        for (int i = 0; i < 7; ++i) g_stamp_buf[4 * B + 8 * slot + i] = ph[i];
+        for (int i = 0; i < 8; ++i) g_stamp_buf[4 * B + 8 * slot + i] = ph[i];
 #endif
 }
 

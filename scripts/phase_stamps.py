@@ -54,8 +54,10 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     for rep in range(2):
         _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, Tw, n, m, ns, nc, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     torch.cuda.synchronize()
-    ph = buf.cpu().numpy()[4 * B:].reshape(B, 8)[:, :7] / Tw
+    ph = buf.cpu().numpy()[4 * B:].reshape(B, 8) / Tw
     names = ["S0 stage AB, request l-values", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6", "-"]
+    print(f"steps with a column-dominant Q_uu (search-free elimination): {ph[:, 6].mean() / 10:.1f} %; steps in which partial pivoting moved a row: {ph[:, 7].mean() / 10:.1f} %")
+    ph = ph[:, :6]
     tot = ph.sum(1).mean()
     for nm_, v in zip(names, ph.mean(0)):
         print(f"{nm_:30s} {v:8.0f} ticks/step  {100 * v / tot:5.1f} %")
