@@ -373,6 +373,52 @@ def test_sweep_dominance_shortcut_boundary(dp, k, blocks):
         assert relerr(K[b], Ko) < 1e-9 and relerr(d[b], do) < 1e-9, (b, kinds[b])
 
 
+@pytest.mark.parametrize("k,blocks", [(12, (4, 2)), (15, (4, 2)), (8, (6, 3)), (10, (6, 3))])
+def test_sweep_blocked_elimination_and_its_fallback(dp, k, blocks):
+    """From n_u = 24 on the mid-size sweep solves Q_uu [K|d] = -[Q_ux|Q_u] by blocks (riccati_wg.hpp, gj_blocked): Gauss-Jordan
+    on 4-column panels with threshold pivoting that keeps the diagonal while no entry below it is more than 8 times larger,
+    and LAPACK-order partial pivoting in registers when that rule fails.  One launch mixes items that take either route --
+    dominant; diagonal the largest of its column; an entry 6 times the diagonal below it (blocks accept, dgesv would swap);
+    an entry 12 times the diagonal (blocks decline); an exactly zero diagonal entry -- and every one must give the oracle's
+    (dgesv-ordered) gains.  B = 0 makes Q_uu = L_uu at every step, so the test controls the matrix exactly."""
+    from oracle import oracle as orc
+    ns, nc = blocks
+    rng = np.random.default_rng(300 + k + ns)
+    n, m, T = ns * k, nc * k, 3
+    kinds = ["dominant", "diag_is_max", "ratio_6", "ratio_12", "zero_diag"] * 2
+    B = len(kinds)
+    A = np.zeros((B, T, n, n)); Bm = np.zeros((B, T, n, m))
+    for a in range(k):
+        A[:, :, ns * a:ns * a + ns, ns * a:ns * a + ns] = np.eye(ns) + 0.1 * rng.normal(size=(B, T, ns, ns))
+    S = rng.normal(size=(B, T + 1, n, n)); Lxx = S @ S.transpose(0, 1, 3, 2) / n + np.eye(n)
+    Luu = np.zeros((B, T + 1, m, m))
+    for b, kind in enumerate(kinds):
+        for t in range(T + 1):
+            off = rng.uniform(0.02, 0.1, size=(m, m)) * rng.choice([-1.0, 1.0], size=(m, m))
+            np.fill_diagonal(off, 0.0)
+            diag = np.full(m, 1.0) * rng.choice([-1.0, 1.0], size=m)
+            if kind == "dominant":
+                diag = 1.5 * np.abs(off).sum(0) * np.sign(diag)
+            elif kind == "diag_is_max":
+                off *= 9.0                                 # |off| up to 0.9 < 1: no swap, far from dominant
+            elif kind == "ratio_6":
+                off[m - 2, 5] = 6.0                        # column 5: 6 x its diagonal, in a later row
+            elif kind == "ratio_12":
+                off[m - 1, m // 2] = 12.0
+            else:
+                diag[7] = 0.0                              # an exactly zero pivot candidate; dgesv brings another row up
+                off[m - 3, 7] = 0.8
+            Luu[b, t] = off + np.diag(diag)
+    Lux = 0.2 * rng.normal(size=(B, T + 1, m, n))
+    Lx = rng.normal(size=(B, T + 1, n)); Lu = rng.normal(size=(B, T + 1, m))
+    tiles = dp.pack_tiles(A, Bm, Lx, Lu, Lxx, Luu, Lux)
+    K, d = dp.backward_pass_tiles(tiles, B, T, n, m, 0.5, blocks=blocks)
+    K, d = K.cpu().numpy(), d.cpu().numpy()
+    for b in range(B):
+        Ko, do = orc.backward_pass_tiles(A[b], Bm[b], Lx[b], Lu[b], Lxx[b], Luu[b], Lux[b], 0.5)
+        assert relerr(K[b], Ko) < 1e-9 and relerr(d[b], do) < 1e-9, (b, kinds[b], relerr(K[b], Ko))
+
+
 @pytest.mark.parametrize("k", [1, 2, 4, 7, 10])
 def test_sweep_six_state_family(dp, k):
     """The 6-state / 3-control family (Quadcopter6D; odd block sizes: no 16-byte alignment to lean on) through the
