@@ -294,12 +294,9 @@ class ProblemBatch:
         tile records, gains and line-search candidates, and several cluster sizes are solved concurrently
         (dispatch.py) -- so that one solve's workspace stays near 12 GB; never below 1024 (four rounds of the
         workgroup-per-item sweep), except on the large-cluster path (one workgroup per item: 256 = one per CU)."""
-        T, n, m = self.T, self.n_x, self.n_u
-        if self.fused_sweep or dtype != torch.float64:
-            per_item = self.workspace_bytes(2, True, dtype) - self.workspace_bytes(1, True, dtype)
-            return int(min(self.B, 6144, max(256, (12 << 30) // max(per_item, 1))))
-        per_item = 8 * ((T + 1) * self.tile_stride + T * m * (n + 1) + 10 * ((T + 1) * n + T * m))
-        return int(min(self.B, 6144, max(1024, (12 << 30) // per_item)))
+        per_item = self.workspace_bytes(2, True, dtype) - self.workspace_bytes(1, True, dtype)
+        floor = 256 if (self.fused_sweep or dtype != torch.float64) else 1024
+        return int(min(self.B, 6144, max(floor, (12 << 30) // max(per_item, 1))))
 
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64):
         """ilqrSolver.solve (control.py:150-225) for all B items.

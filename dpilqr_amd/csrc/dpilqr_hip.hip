@@ -123,6 +123,7 @@ constexpr int kCountRing = 4;
 struct SolveShape {
     bool big;        // the fused workgroup-per-item sweep of tu_big.hip (n_x > 60, or the fp32 arm): no tile records
     size_t elem;     // bytes per element of the trajectories / gains (8: fp64, 4: fp32)
+    bool fused;      // a fused sweep of tu_riccati.hip serves the batch: no tile records, no producer, no workspace for them
 };
 
 struct SolveWorkspace {
@@ -135,7 +136,7 @@ struct SolveWorkspace {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         size_t o = 0;
         tiles = o;    o = al(o + (sh.big ? e * Wn * (size_t)riccati_big_scratch_elems((int)n, (int)m)
-                                         : sizeof(double) * Wn * (T + 1) * L.stride));
+                                         : (sh.fused ? 0 : sizeof(double) * Wn * (T + 1) * L.stride)));
         K = o;        o = al(o + (gains_in_ws ? e * Wn * T * m * n : 0));
         d = o;        o = al(o + (gains_in_ws ? e * Wn * T * m : 0));
         // line-search candidates: every alpha's trajectory, so that accepting one is a copy, not a re-roll
@@ -316,7 +317,8 @@ template <> struct Passes<float> {
 
 template <typename R>
 SolveShape shape_of(const dpilqr_batch_desc& D) {
-    return SolveShape{sizeof(R) == 4 || uses_big_path(D.k * D.n_s), sizeof(R)};
+    const bool big = sizeof(R) == 4 || uses_big_path(D.k * D.n_s);
+    return SolveShape{big, sizeof(R), !big && fused_sweep_applies(D)};
 }
 
 // ilqrSolver.solve for every item of the batch.  solver != NULL: the synchronous, adaptive form (the host follows the
@@ -382,7 +384,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     const int um = hint_model(D);
     // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every item
     // the fused sweep evaluates the plugins itself: no tile producer, no records
-    const bool fused = sizeof(R) == 8 && !sh.big && fused_sweep_applies(D);
+    const bool fused = sh.fused;
     const bool static_part = !fused && !sh.big && !no_static && D.R_bstride == 0 &&
                              (um == kDoubleInt4D || um == kDoubleInt6D || um == kHumanLin6D);
     if (!resume) {
@@ -639,7 +641,7 @@ int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* 
     if (desc->B == 0) return DPILQR_OK;
     if (!X || !U || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_fused: NULL pointer");
     if (!fused_sweep_applies(*desc))
-        return fail(DPILQR_EUNSUPPORTED, "backward_pass_fused: needs DoubleIntDynamics4D agents (<= 5), n_dims = 2 and one Q, R, Q_f "
+        return fail(DPILQR_EUNSUPPORTED, "backward_pass_fused: needs 6..15 four-state or 2..10 six-state agents, or DoubleIntDynamics4D agents (<= 5), n_dims = 2 and one Q, R, Q_f "
                                          "for all agents and items (uniform_model hints)");
     rc = launch_riccati_fused(*desc, X, U, mu, K, d, singular, nullptr, nullptr, desc->B, 0, as_stream(stream));
     return rc == DPILQR_EUNSUPPORTED ? fail(rc, "backward_pass_fused: no instantiation for n_x=%d", desc->k * desc->n_s) : rc;

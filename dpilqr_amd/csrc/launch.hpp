@@ -51,12 +51,22 @@ int device_cus();
 inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
 inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
 inline bool hint_shared_weights(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 16) & 1) != 0; }
-// the fused sweep's condition: DoubleIntDynamics4D agents only, planar proximity cost, one Q / R / Q_f for every agent of
-// every item (the descriptor's hints), at most five agents (the wavefront sweep's sizes)
-inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
+// The fused sweeps (no tile records: linearize / quadraticize evaluated inside the sweep).
+// Wavefront sweep (n_x <= 20, riccati_mfma.hpp): DoubleIntDynamics4D agents only, planar proximity cost, one Q / R / Q_f for
+// every agent of every item (the descriptor's hints), at most five agents.
+inline bool fused_wavefront_sweep_applies(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_FUSED") != nullptr;   // A/B switch: the record-fed sweep
     return !off && hint_model(D) == 0 && hint_n_dims(D) == 2 && hint_shared_weights(D) && D.Q_bstride == 0 && D.R_bstride == 0 &&
            D.Qf_bstride == 0 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
+}
+// Workgroup sweep (riccati_wg.hpp): 6..15 agents of the four-state family or 2..10 of the six-state family -- any models of
+// the family, any per-agent weights, any n_dims.
+inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
+    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_WG") != nullptr;
+    return !off && ((D.n_s == 4 && D.n_c == 2 && D.k >= 6 && D.k <= 15) || (D.n_s == 6 && D.n_c == 3 && D.k >= 2 && D.k <= 10));
+}
+inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
+    return fused_wavefront_sweep_applies(D) || fused_workgroup_sweep_applies(D);
 }
 
 // ---- tu_tiles.hip

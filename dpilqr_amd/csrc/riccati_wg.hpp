@@ -35,7 +35,7 @@ namespace dpilqr {
 
 constexpr int kWgThreads = 256;
 
-template <int N, int M, int NS, int NC>
+template <int N, int M, int NS, int NC, bool FUSED = false>
 struct WgCfg {
     static constexpr int NM = N + M, NP = N + 1, MK = round_up(M, 4), KA = N / NS, NSC = NS + NC;
     static constexpr int LP = round_up(NP, 2), LQ = LP, LK = LP, LM = N, KROWS = MK + 2;
@@ -58,9 +58,18 @@ struct WgCfg {
     // the fall-back (below that it spills at three or four per CU, and the LU is a smaller part of the step): 32 x 4 doubles
     // per wavefront to turn a panel's columns into rows
     static constexpr bool GJ = (M >= 24);
-    static constexpr int szPan = GJ ? 4 * 128 : 0;
+    // ... which take the place of the [A|B] blocks where those are large enough (dead between S2 and the next S0)
+    static constexpr bool PAN_IN_AB = GJ && szAB >= 4 * 128;
+    static constexpr int szPan = (GJ && !PAN_IN_AB) ? 4 * 128 : 0;
+    // FUSED (no tile records, see the kernel): w_ref (Q + Q^T), w_ref-less (R + R^T) of every agent, once per sub-problem.
+    // The step's plugin data -- x, x - x_f, u, pair gradients and Hessians, their per-agent sums -- live in rows < m of the
+    // [K|d] region, which is dead from the end of S6 to S3
+    static constexpr int NPR = KA * (KA - 1) / 2;
+    static constexpr int szW = FUSED ? round_up(KA * (NS * NS + NC * NC), 2) : 0;
+    static constexpr int oFx = 0, oFe = oFx + N, oFu = oFe + N, oFg = oFu + M, oFh = oFg + 3 * NPR, oFd = oFh + 9 * NPR,
+                         oFs = oFd + 9 * KA, oFend = oFs + 3 * KA;
     static constexpr int oP = 0, oG = oP + szP, oK = oG + szG, oT3 = oK + KROWS * LK, oAB = oK + szK, oPan = oAB + szAB,
-                         oEnd = oPan + szPan;
+                         oW = oPan + szPan, oEnd = oW + szW;
     static constexpr int total = round_up(oEnd + 64, 2);   // + store target of idle lanes, wrapped tile reads
     static constexpr bool ALA = (NS % 2 == 0);                   // an agent's column block starts at an even offset
     static constexpr bool AL = ALA && (NC % 2 == 0);
@@ -83,7 +92,8 @@ struct WgCfg {
     static constexpr int OCC = kLdsFit < 1 ? 1 : (kLdsFit < kRegFit ? kLdsFit : kRegFit);
 #endif
     static constexpr bool supported = (N % NS == 0) && (M == KA * NC) && (N % 2 == 0) && (M <= 32) && (64 - M > 0) &&
-                                      (4 * (64 - M) >= NP) && (total * 8 <= 160 * 1024);
+                                      (4 * (64 - M) >= NP) && (total * 8 <= 160 * 1024) &&
+                                      (!FUSED || (oFend <= M * LK && 12 * KA <= kWgThreads && 64 + NPR <= kWgThreads));
 };
 
 // Pins a phase's accumulators at this point of the program: the multiply-adds that produce them are issued before it, the
@@ -255,12 +265,17 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
     return false;
 }
 
-template <int N, int M, int NS, int NC>
-__global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_riccati_wg(
+// FUSED: no tile records.  The sweep evaluates MultiDynamicalModel.linearize and GameCost.quadraticize itself, from
+// (X[t], U[t]) -- n_x + n_u doubles per step, requested a step ahead -- with the tile producer's own expressions and
+// summation orders (tiles.hpp), so the gains are those of the record-fed sweep bit for bit.  A step's S0 becomes: (x, x - x_f,
+// u) -> LDS | agents' [A_i|B_i] (one lane per agent) and the pair derivatives (one lane per pair) | their per-agent sums;
+// the l-values are formed by the S1 / S2 work items that add them.  Any models of the state family, any per-agent weights.
+template <int N, int M, int NS, int NC, bool FUSED = false>
+__global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void k_riccati_wg(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items, int gains_by_item) {
-    using C = WgCfg<N, M, NS, NC>;
+    const int32_t* __restrict__ n_items, int gains_by_item, FusedArgs F) {
+    using C = WgCfg<N, M, NS, NC, FUSED>;
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, KA = C::KA, NSC = C::NSC, NSCP = C::NSCP, LP = C::LP, LQ = C::LQ;
     constexpr int LG = C::LG, LK = C::LK, LM = C::LM, MO = C::MO, T_NP = C::T_NP, T_N = C::T_N;
     constexpr bool AL = C::AL, ALA = C::ALA;
@@ -291,12 +306,159 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
     double* sTrash = lds + C::oEnd;
 
     const double mu = mu_arr[b];
-    const double* base = tiles + (int64_t)slot * (T + 1) * L.stride;
+    const double* base = FUSED ? nullptr : tiles + (int64_t)slot * (T + 1) * L.stride;
     int sing = 0;
+    // FUSED: the step's plugin data (rows < m of the [K|d] region), the weights, this lane's share of (x, u) a step ahead
+    double* sFx = sK + C::oFx;          // x
+    double* sFe = sK + C::oFe;          // x - x_f
+    double* sFu = sK + C::oFu;          // u
+    double* sFg = sK + C::oFg;          // pair gradients [pair][3]
+    double* sFh = sK + C::oFh;          // pair Hessians [pair][9]
+    double* sFd = sK + C::oFd;          // per agent: sum of its pairs' Hessians [agent][9]
+    double* sFs = sK + C::oFs;          // per agent: signed sum of its pairs' gradients [agent][3]
+    double* sQQ = lds + C::oW;          // Q + Q^T [agent][NS][NS]
+    double* sRR = sQQ + KA * NS * NS;   // R + R^T [agent][NC][NC]
+    ItemParams IP{};
+    const double* Xg = nullptr;
+    const double* Ug = nullptr;
+    double pxu = 0.0, f_xf = 0.0;
+    const double wr = FUSED ? F.D.w_ref : 0.0, wp = FUSED ? F.D.w_prox : 0.0;
+    if constexpr (FUSED) {
+        IP = item_params(F.D, b);
+        Xg = F.X + (int64_t)b * (T + 1) * N;
+        Ug = F.U + (int64_t)b * T * M;
+    }
+    // this lane's role in the fused stage, once: agent lanes know their model, pair lanes their pair and its dimension count
+    int f_model = 0, f_pi = 0, f_pj = 1, f_nd = 2;
+    double f_radius = 0.0;
+    if constexpr (FUSED) {
+        if (tid < KA) f_model = IP.model[tid];
+        if (tid >= 64 && tid - 64 < C::NPR) {
+            int i = 0, rem = tid - 64;
+            while (rem >= KA - 1 - i) { rem -= KA - 1 - i; ++i; }
+            f_pi = i; f_pj = i + 1 + rem;
+            f_nd = min(IP.n_dims[f_pi], IP.n_dims[f_pj]);  // cost.py:145
+        }
+        f_radius = IP.radius;
+    }
+    // FUSED, one step's plugin data (tiles.hpp phases 1a, 1b and the sums its phase 2 forms per entry) in two parts, neither
+    // ending with a barrier: (x, x - x_f, u) from this lane's register into LDS -- done at the END of the previous step, next to
+    // the store of P, so that it costs no barrier of its own -- and what is derived from them
+    auto fused_put_xu = [&](bool terminal) {
+        if (tid < N) { sFx[tid] = pxu; sFe[tid] = pxu - f_xf; }
+        else if (tid < N + M) sFu[tid - N] = terminal ? 0.0 : pxu;
+    };
+    auto fused_derive = [&](bool terminal) {
+        if (tid < KA) {
+            if (!terminal) {
+                double x[NS], u[NC], A[NS * NS], Bm[NS * NC];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) x[i] = sFx[tid * NS + i];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) u[i] = sFu[tid * NC + i];
+                linearize_rt<NS>(f_model, x, u, F.D.dt, A, Bm);
+#pragma unroll
+                for (int l = 0; l < NS; ++l) {
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) sAB[(NS * tid + l) * NSCP + c] = A[l * NS + c];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) sAB[(NS * tid + l) * NSCP + NS + c] = Bm[l * NC + c];
+                }
+            }
+        } else if (tid >= 64 && tid - 64 < C::NPR) {
+            const int p = tid - 64;
+            double g[3], H[9];
+            pair_quadraticize(sFx + f_pi * NS, sFx + f_pj * NS, f_nd, f_radius, g, H);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sFg[p * 3 + c] = g[c];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sFh[p * 9 + c] = H[c];
+        }
+        wg_barrier();
+        if (KA > 1) {
+            // per agent: the sums over its pairs, in combinations order (a serial chain of adds, as in the producer; the
+            // loads are all issued first)
+            if (tid < 9 * KA) {
+                const int a = tid / 9, c = tid - 9 * a;
+                double h[KA];
+#pragma unroll
+                for (int o = 0; o < KA; ++o) {
+                    const int oo = (o == a) ? (a == 0 ? 1 : 0) : o;
+                    h[o] = sFh[((oo < a) ? pair_index(oo, a, KA) : pair_index(a, oo, KA)) * 9 + c];
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int o = 0; o < KA; ++o) acc = (o == a) ? acc : acc + h[o];
+                sFd[tid] = acc;
+            } else if (tid < 12 * KA) {
+                const int e = tid - 9 * KA, a = e / 3, c = e - 3 * a;
+                double gg[KA];
+#pragma unroll
+                for (int o = 0; o < KA; ++o) {
+                    const int oo = (o == a) ? (a == 0 ? 1 : 0) : o;
+                    const double v = sFg[((oo < a) ? pair_index(oo, a, KA) : pair_index(a, oo, KA)) * 3 + c];
+                    gg[o] = (oo < a) ? -v : v;
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int o = 0; o < KA; ++o) acc = (o == a) ? acc : acc + gg[o];
+                sFs[e] = acc;
+            }
+        }
+    };
 
     for (int e = tid; e < C::total; e += kWgThreads) lds[e] = 0.0;
     wg_barrier();
-    {
+    if constexpr (FUSED) {
+        // the weights, once; then the terminal condition p = l_x(T), P = l_xx(T) (control.py:125-129) with Q_f
+        for (int e = tid; e < KA * NS * NS; e += kWgThreads) {
+            const int a = e / (NS * NS), r = e - a * NS * NS, li = r / NS, lj = r - li * NS;
+            sQQ[e] = IP.Q[a * NS * NS + li * NS + lj] + IP.Q[a * NS * NS + lj * NS + li];
+        }
+        for (int e = tid; e < KA * NC * NC; e += kWgThreads) {
+            const int a = e / (NC * NC), r = e - a * NC * NC, li = r / NC, lj = r - li * NC;
+            sRR[e] = IP.R[a * NC * NC + li * NC + lj] + IP.R[a * NC * NC + lj * NC + li];
+        }
+        if (tid < N) { f_xf = IP.xf[tid]; pxu = Xg[(int64_t)T * N + tid]; }
+        fused_put_xu(true);
+        wg_barrier();
+        fused_derive(true);
+        wg_barrier();
+        for (int e = tid; e < N * N; e += kWgThreads) {
+            const int i = e / N, j = e - i * N;
+            const int ai = i / NS, aj = j / NS, li = i - ai * NS, lj = j - aj * NS;
+            double v = 0.0;
+            if (ai == aj) {
+                const double* Mf = IP.Qf + ai * NS * NS;
+                v = wr * (Mf[li * NS + lj] + Mf[lj * NS + li]);
+            }
+            if (KA > 1 && li < 3 && lj < 3) {
+                double acc = 0.0;
+                if (ai == aj) acc = sFd[ai * 9 + li * 3 + lj];
+                else acc += -sFh[((ai < aj) ? pair_index(ai, aj, KA) : pair_index(aj, ai, KA)) * 9 + li * 3 + lj];
+                v += wp * acc;
+            }
+            sP[i * LP + j] = v;
+        }
+        for (int j = tid; j < N; j += kWgThreads) {
+            const int a = j / NS, lj = j - a * NS;
+            const double* Mf = IP.Qf + a * NS * NS;
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) v += sFe[a * NS + i] * (Mf[i * NS + lj] + Mf[lj * NS + i]);
+            v = wr * v;
+            if (KA > 1 && lj < 3) v += wp * sFs[a * 3 + lj];
+            sP[j * LP + N] = v;
+        }
+        if (tid < N) pxu = Xg[(int64_t)(T - 1) * N + tid];
+        else if (tid < N + M) pxu = Ug[(int64_t)(T - 1) * M + (tid - N)];
+        wg_barrier();           // the terminal step's x - x_f, sums have been read: step T - 1's (x, u) take their place
+        fused_put_xu(false);
+        if (T > 1) {
+            if (tid < N) pxu = Xg[(int64_t)(T - 2) * N + tid];
+            else if (tid < N + M) pxu = Ug[(int64_t)(T - 2) * M + (tid - N)];
+        }
+    } else {
         const double* rec = base + (int64_t)T * L.stride;
         for (int e = tid; e < N * N; e += kWgThreads) {
             const int i = e / N, j = e - i * N;
@@ -341,7 +503,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
     constexpr int RW = 64 - M;
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + kWgThreads - 1) / kWgThreads;
 
-    prefetch_ab(T - 1);
+    if constexpr (!FUSED) prefetch_ab(T - 1);
     wg_barrier();
 
 #ifdef DPILQR_PHASE_STAMPS
@@ -352,16 +514,19 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
 #endif
     for (int t = T - 1; t >= 0; --t) {
         const int tn = t > 0 ? t - 1 : 0;
-        const double* rec = base + (int64_t)t * L.stride;
+        const double* rec = FUSED ? nullptr : base + (int64_t)t * L.stride;
         // ---- S0
-#pragma unroll
-        for (int q = 0; q < C::ABR; ++q) *ab_dst[q] = nAB[q];
-        prefetch_ab(tn);
-        // this step's [l_x | l_u]: requested now, used by the S1 epilogue
         int tid_p = tid;
         asm volatile("" : "+v"(tid_p));
         WG_ITEMS_S1()
         double nX[C::R1R][NSC];
+        if constexpr (FUSED) {
+            fused_derive(false);    // (x, u) of this step were put in place at the end of the previous one
+        } else {
+#pragma unroll
+        for (int q = 0; q < C::ABR; ++q) *ab_dst[q] = nAB[q];
+        prefetch_ab(tn);
+        // this step's [l_x | l_u]: requested now, used by the S1 epilogue
 #pragma unroll
         for (int r = 0; r < C::R1R; ++r) {
 #pragma unroll
@@ -370,6 +535,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
                 ld_row<NS, AL>(rec + L.oLx + NS * ag1[r], nX[r]);
                 ld_row<NC, AL>(rec + L.oLu + NC * ag1[r], nX[r] + NS);
             }
+        }
         }
         wg_barrier();
         WPHASE(0)
@@ -414,6 +580,24 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
 #pragma unroll
                     for (int i = 0; i < NC; ++i) st_row<2, true>(sG + (NC * ag + i) * LG + MO + j0, acc + 2 * (NS + i));
                 } else {   // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
+                    if constexpr (FUSED) {   // l_x = w_ref e^T (Q + Q^T) + w_prox sum_pairs(+-g) ; l_u = w_ref u^T (R + R^T)
+#pragma unroll
+                        for (int lj = 0; lj < NS; ++lj) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) v += sFe[ag * NS + i] * sQQ[(ag * NS + i) * NS + lj];
+                            v = wr * v;
+                            if (KA > 1 && lj < 3) v += wp * sFs[ag * 3 + lj];
+                            nX[r][lj] = v;
+                        }
+#pragma unroll
+                        for (int lj = 0; lj < NC; ++lj) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NC; ++i) v += sFu[ag * NC + i] * sRR[(ag * NC + i) * NC + lj];
+                            nX[r][NS + lj] = wr * v;
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < NS; ++i) sP[(NS * ag + i) * LP + N] = nX[r][i] + acc[2 * i];
 #pragma unroll
@@ -421,9 +605,9 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
                 }
             }
         }
-        // the S2 l-values: requested here (not at the top of the step: they would be held across S1)
+        // the S2 l-values: requested here (not at the top of the step: they would be held across S1); FUSED: formed in S2
         double nL[C::R2R][C::RPL][NSC];
-        {
+        if constexpr (!FUSED) {
         WG_ITEMS_S2()
 #pragma unroll
         for (int r = 0; r < C::R2R; ++r)
@@ -457,6 +641,44 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
             for (int q = 0; q < C::RPL; ++q) {
                 const int ip = ip2[r][q];
                 ld_row<NS, ALA>((ip < N ? sP + ip * LP : sG + (ip - N) * LG + MO) + NS * ag, tv[q]);
+            }
+            if constexpr (FUSED) {
+                // this work item's l-values, formed here (their LDS reads run under the reduction below):
+                // L_xx = w_ref blockdiag(Q + Q^T) + w_prox sum_pairs(+-H) (cost.py:228-237, 160-169), L_ux = 0,
+                // L_uu = w_ref blockdiag(R + R^T) -- its rows, its agent's column block
+#pragma unroll
+                for (int q = 0; q < C::RPL; ++q) {
+                    const int ip = ip2[r][q];
+                    const bool xrow = ip < N;
+                    const int ai = xrow ? ip / NS : (ip - N) / NC, li = xrow ? ip - ai * NS : (ip - N) - ai * NC;
+                    const bool own = ai == ag;
+                    // the weights' row (Q + Q^T for a state row, R + R^T for a control row) and the Hessian row that goes with it
+                    const double* wrow = xrow ? sQQ + (ag * NS + li) * NS : sRR + (ag * NC + li) * NC;
+                    const int pidx = own ? 0 : ((ai < ag) ? pair_index(ai, ag, KA) : pair_index(ag, ai, KA));
+                    const double* hrow = (own ? sFd + ag * 9 : sFh + pidx * 9) + min(li, 2) * 3;
+                    const bool prox = KA > 1 && xrow && li < 3;
+                    double w[NS], h[3];
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) w[c] = wrow[min(c, xrow ? NS - 1 : NC - 1)];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) h[c] = hrow[c];
+#pragma unroll
+                    for (int c = 0; c < NSC; ++c) nL[r][q][c] = 0.0;
+#pragma unroll
+                    for (int lj = 0; lj < NS; ++lj) {
+                        double v = 0.0;
+                        if (xrow && own) v = wr * w[lj];
+                        if (lj < 3 && prox) {
+                            double pa = 0.0;
+                            if (own) pa = h[lj]; else pa += -h[lj];
+                            v += wp * pa;
+                        }
+                        if (xrow) nL[r][q][lj] = v;
+                    }
+#pragma unroll
+                    for (int lj = 0; lj < NC; ++lj)
+                        if (!xrow && own) nL[r][q][NS + lj] = wr * w[lj];
+                }
             }
             double ab[2][NSC];
             ld_row<NSC, true>(sAB + (NS * ag) * NSCP, ab[0]);
@@ -507,7 +729,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
             static_assert(!C::GJ || NWLU <= T_NP, "the wavefronts of the fall-back must have seen the blocked attempt fail");
             if (lu_wave < T_NP) {
                 WG_LANE_TERMS()
-                const bool declined = gj_blocked<M, MO, LG, LK, NP>(sG, sK, lds + C::oPan + 128 * wave, wave, lane);
+                const bool declined = gj_blocked<M, MO, LG, LK, NP>(sG, sK, lds + (C::PAN_IN_AB ? C::oAB : C::oPan) + 128 * wave, wave, lane);
                 lu_needed = lu_needed && declined;
 #ifdef DPILQR_PHASE_STAMPS
                 if (!declined) ph[6] += 1000;   // diagnostic: share of the steps solved by blocks (per mille)
@@ -707,6 +929,15 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC>::OCC)) void k_ricc
                 for (int v = 0; v < 4; ++v) {
                     const int i = 16 * it + g + 4 * v;
                     if (tl < C::NT5 && i < N && j <= N) sP[i * LP + j] = W[q][v];
+                }
+            }
+        }
+        if constexpr (FUSED) {
+            if (t > 0) {            // the next step's (x, u): a2 has been read, rows < m of the [K|d] region are free
+                fused_put_xu(false);
+                if (t > 1) {
+                    if (tid < N) pxu = Xg[(int64_t)(t - 2) * N + tid];
+                    else if (tid < N + M) pxu = Ug[(int64_t)(t - 2) * M + (tid - N)];
                 }
             }
         }

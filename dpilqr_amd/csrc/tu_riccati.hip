@@ -71,7 +71,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         int32_t rc_w = allow_lds(k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>, lds_w);                                \
         if (rc_w) return rc_w;                                                                                      \
         hipLaunchKernelGGL((k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_>), dim3(grid_items), dim3(kWgThreads), lds_w, \
-                           st, B, T, tiles, mu, K, d, singular, items, n_items, gains_by_item);                     \
+                           st, B, T, tiles, mu, K, d, singular, items, n_items, gains_by_item, FusedArgs{});        \
         HIP_TRY(hipGetLastError());                                                                                 \
         return DPILQR_OK;                                                                                           \
     }
@@ -141,8 +141,31 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
-    DPILQR_TILED_SIZES(DPILQR_TRY_FUSED)
+    if (fused_wavefront_sweep_applies(D)) {
+        DPILQR_TILED_SIZES(DPILQR_TRY_FUSED)
+    }
 #undef DPILQR_TRY_FUSED
+    // larger clusters: the workgroup sweep, fused (riccati_wg.hpp): any models of the four- or six-state family
+#define DPILQR_TRY_WGF(KK, NS_, NC_)                                                                                \
+    if (D.n_s == NS_ && D.n_c == NC_ && D.k == KK) {                                                                \
+        using WC = WgCfg<KK * NS_, KK * NC_, NS_, NC_, true>;                                                       \
+        static_assert(WC::supported, "fused workgroup sweep not available for this size");                          \
+        const size_t lds_w = sizeof(double) * WC::total;                                                            \
+        int32_t rc_w = allow_lds(k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_, true>, lds_w);                          \
+        if (rc_w) return rc_w;                                                                                      \
+        hipLaunchKernelGGL((k_riccati_wg<KK * NS_, KK * NC_, NS_, NC_, true>), dim3(grid_items), dim3(kWgThreads),  \
+                           lds_w, st, D.B, D.T, nullptr, mu, K, d, singular, items, n_items, gains_by_item,         \
+                           FusedArgs{D, X, U});                                                                     \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return DPILQR_OK;                                                                                           \
+    }
+    if (fused_workgroup_sweep_applies(D)) {
+        DPILQR_TRY_WGF(6, 4, 2) DPILQR_TRY_WGF(7, 4, 2) DPILQR_TRY_WGF(8, 4, 2) DPILQR_TRY_WGF(9, 4, 2) DPILQR_TRY_WGF(10, 4, 2)
+        DPILQR_TRY_WGF(11, 4, 2) DPILQR_TRY_WGF(12, 4, 2) DPILQR_TRY_WGF(13, 4, 2) DPILQR_TRY_WGF(14, 4, 2) DPILQR_TRY_WGF(15, 4, 2)
+        DPILQR_TRY_WGF(2, 6, 3) DPILQR_TRY_WGF(3, 6, 3) DPILQR_TRY_WGF(4, 6, 3) DPILQR_TRY_WGF(5, 6, 3) DPILQR_TRY_WGF(6, 6, 3)
+        DPILQR_TRY_WGF(7, 6, 3) DPILQR_TRY_WGF(8, 6, 3) DPILQR_TRY_WGF(9, 6, 3) DPILQR_TRY_WGF(10, 6, 3)
+    }
+#undef DPILQR_TRY_WGF
     return DPILQR_EUNSUPPORTED;
 }
 

@@ -166,11 +166,12 @@ int32_t dpilqr_backward_pass_tiles_blocks(int32_t B, int32_t T, int32_t n_x, int
 int64_t dpilqr_tiles_bytes(int32_t B, int32_t T, int32_t n_x, int32_t n_u);
 int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu,
                              double* K, double* d, double* tiles_workspace, void* stream);
-/* The same backward pass without tile records ("fused variant"): for batches whose descriptor hints say
- * "DoubleIntDynamics4D agents only (at most five), n_dims = 2 everywhere, one Q, R, Q_f for every agent of every item" the
- * sweep evaluates linearize / quadraticize itself and reads only (X, U): 12 KB instead of 535 KB per cfg2 pass.  Gains
- * are bit-identical to dpilqr_backward_pass.  DPILQR_EUNSUPPORTED for any other batch.  dpilqr_solve_batch picks it by
- * itself. */
+/* The same backward pass without tile records ("fused variant"): the sweep evaluates linearize / quadraticize
+ * itself and reads only (X, U).  Gains are bit-identical to dpilqr_backward_pass.  Served: (a) batches whose descriptor hints
+ * say "DoubleIntDynamics4D agents only (at most five), n_dims = 2 everywhere, one Q, R, Q_f for every agent of every item"
+ * (12 KB instead of 535 KB per cfg2 pass); (b) 6..15 agents of the four-state family or 2..10 of the six-state family, any
+ * models of the family, any weights (cfg3 / cfg4 clusters: 90 doubles instead of a 94 KB record per step at n_x = 60).
+ * DPILQR_EUNSUPPORTED for any other batch.  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
 int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
                                    double* d, int32_t* singular, void* stream);
 /* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:

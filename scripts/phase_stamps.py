@@ -52,7 +52,10 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     buf = torch.zeros((B * 12,), dtype=torch.int64, device="cuda")
     _lib.check(lib.dpilqr_debug_stamps(ptr(buf)))
     for rep in range(2):
-        _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, Tw, n, m, ns, nc, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
+        if fused:
+            _lib.check(lib.dpilqr_backward_pass_fused(pb._d, ptr(r["X"]), ptr(r["U"]), ptr(mu), ptr(K), ptr(d), None, stream_handle()))
+        else:
+            _lib.check(lib.dpilqr_backward_pass_tiles_blocks(B, Tw, n, m, ns, nc, ptr(tl), ptr(mu), ptr(K), ptr(d), None, None, None, stream_handle()))
     torch.cuda.synchronize()
     ph = buf.cpu().numpy()[4 * B:].reshape(B, 8) / Tw
     names = ["S0 stage AB, request l-values", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6", "-"]
@@ -62,7 +65,7 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     tot = ph.sum(1).mean()
     for nm_, v in zip(names, ph.mean(0)):
         print(f"{nm_:30s} {v:8.0f} ticks/step  {100 * v / tot:5.1f} %")
-    print(f"k_riccati_wg n_x={n}: total {tot:.0f} ticks/step (s_memtime ticks, 100 MHz)")
+    print(f"k_riccati_wg{' (fused)' if fused else ''} n_x={n}: total {tot:.0f} ticks/step (s_memtime ticks, 100 MHz)")
     sys.exit(0)
 B = int(args[0]) if args else 1024
 x0, xf = scenarios(0, B)

@@ -584,6 +584,42 @@ def test_fused_sweep_is_bit_identical_to_the_record_fed_sweep(dp, k, B):
             pb2.backward_pass_fused(X, U0, mu)
 
 
+@pytest.mark.parametrize("family,k,B", [(4, 6, 300), (4, 9, 700), (4, 12, 260), (4, 15, 520), (6, 2, 300), (6, 5, 900), (6, 8, 260),
+                                        (6, 10, 520)])
+def test_fused_workgroup_sweep_is_bit_identical_to_the_record_fed_sweep(dp, family, k, B):
+    """The mid-size sweep without tile records (riccati_wg.hpp, FUSED: linearize / quadraticize evaluated inside the sweep from
+    (X, U)) against the same sweep fed with the tile producer's records: same gains bit for bit.  Mixed models of the state
+    family, per-agent non-symmetric weights, mixed n_dims, per-item radii and mu, states where agents are inside each other's
+    radius; enough items for several workgroups per CU."""
+    import torch
+    from dpilqr_amd.device import to_dev
+    T = 12
+    rng = np.random.default_rng(900 + 10 * family + k)
+    if family == 4:
+        ns, nc = 4, 2
+        models = [(0 if a % 3 == 0 else 3) for a in range(k)]            # DoubleInt4D and Unicycle4D
+        n_dims = [2] * k
+    else:
+        ns, nc = 6, 3
+        models = [[4, 1, 5, 6][a % 4] for a in range(k)]                  # Quadcopter6D, DoubleInt6D, Human6D, HumanLin6D
+        n_dims = [(3 if a % 2 == 0 else 2) for a in range(k)]
+    n, m = ns * k, nc * k
+    x0 = rng.normal(size=(B, n)) * 0.5; xf = rng.normal(size=(B, n))
+    if family == 6:
+        x0[:, 3::6] *= 0.2; x0[:, 4::6] *= 0.2; x0[:, 5::6] *= 0.2
+    U0 = rng.normal(size=(B, T, m)) * 0.3
+    Q = np.stack([np.diag(rng.uniform(0.2, 2.0, size=ns)) + 0.1 * rng.normal(size=(ns, ns)) for _ in range(k)])
+    R = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nc)) + 0.1 * rng.normal(size=(nc, nc)) for _ in range(k)])
+    Qf = np.stack([30.0 * np.eye(ns) + rng.normal(size=(ns, ns)) for _ in range(k)])
+    pb = dp.ProblemBatch(models, n_dims, xf, Q, R, Qf, rng.uniform(0.3, 0.9, size=B), 0.1, T)
+    X, _ = pb.rollout(x0, U0)
+    mu = to_dev(rng.choice([0.0, 0.125, 1.0], size=B))
+    K0, d0 = pb.backward_pass(X, U0, mu)
+    K1, d1 = pb.backward_pass_fused(X, U0, mu)
+    assert bool(torch.isfinite(K0).all())
+    assert torch.equal(K0, K1) and torch.equal(d0, d1), (float((K0 - K1).abs().max()), float((d0 - d1).abs().max()))
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
 def test_sweep_three_state_family(dp, k):
     """CarDynamics3D (3 states / 2 controls): even agent counts take the workgroup-per-item sweep, odd ones the size-generic
