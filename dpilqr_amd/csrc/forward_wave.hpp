@@ -110,7 +110,15 @@ struct WaveFwdLds {
     static constexpr int NW = (KA * DPILQR_N_ALPHA + 63) / 64;     // wavefronts per sub-problem
     static constexpr int IPB = NW == 1 ? 4 : 1;                    // sub-problems per workgroup
     static constexpr int octl = oJ + DPILQR_N_ALPHA;
-    static constexpr int total = (octl + 2 + 1) & ~1;
+    // items of more than one wavefront (7+ agents) and six- / twelve-state agents keep the per-agent constants Q, R, x_f in
+    // LDS: in registers (48 for a four-state agent, 104 for a six-state one, next to the pair tables) those kernels spill
+    // up to 550 bytes -- Quadcopter12D: 2 KB -- per lane into the horizon loop.  (One to six four-state agents: registers are
+    // the faster place, measured.)
+    static constexpr bool CONST_LDS = NW > 1 || NS >= 6;
+    static constexpr int oQ = (octl + 2 + 1) & ~1;                 // Q [agent][NS*NS]
+    static constexpr int oR = oQ + (CONST_LDS ? KA * NS * NS : 0); // R [agent][NC*NC]
+    static constexpr int oXf = oR + (CONST_LDS ? KA * NC * NC : 0);
+    static constexpr int total = (oXf + (CONST_LDS ? n : 0) + 1) & ~1;
 };
 
 // NW = 1 (k * 10 <= 64 lanes): four sub-problems per workgroup, one wavefront each, no barriers.  NW = 2, 3 (7..15
@@ -160,26 +168,34 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 
     // ---- per-item constants, read once
     const ItemParams P = item_params(D, b);
-    double xf[NS], Q[NS * NS], R[NC * NC];
+    constexpr bool CL = W::CONST_LDS;
+    double xf_r[CL ? 1 : NS], Q_r[CL ? 1 : NS * NS], R_r[CL ? 1 : NC * NC];
+    const double* xf = xf_r; const double* Q = Q_r; const double* R = R_r;
+    if constexpr (CL) {
+        for (int e = tid; e < KA * NS * NS; e += NTH) lds[W::oQ + e] = P.Q[e];
+        for (int e = tid; e < KA * NC * NC; e += NTH) lds[W::oR + e] = P.R[e];
+        for (int e = tid; e < n; e += NTH) lds[W::oXf + e] = P.xf[e];
+        xf = lds + W::oXf + a * NS; Q = lds + W::oQ + a * NS * NS; R = lds + W::oR + a * NC * NC;
+    } else {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) xf[i] = P.xf[a * NS + i];
+        for (int i = 0; i < NS; ++i) xf_r[i] = P.xf[a * NS + i];
 #pragma unroll
-    for (int i = 0; i < NS * NS; ++i) Q[i] = P.Q[a * NS * NS + i];
+        for (int i = 0; i < NS * NS; ++i) Q_r[i] = P.Q[a * NS * NS + i];
 #pragma unroll
-    for (int i = 0; i < NC * NC; ++i) R[i] = P.R[a * NC * NC + i];
+        for (int i = 0; i < NC * NC; ++i) R_r[i] = P.R[a * NC * NC + i];
+    }
     const double radius = P.radius;
     bool homog = true;
 #pragma unroll
     for (int i = 1; i < KA; ++i) homog = homog && (P.n_dims[i] == P.n_dims[0]);
-    int pi[PPL > 0 ? PPL : 1], pj[PPL > 0 ? PPL : 1], pnd[PPL > 0 ? PPL : 1];   // this lane's pairs: p = a + q * KA
+    int pp[PPL > 0 ? PPL : 1];   // this lane's pairs, p = a + q * KA: i | j << 8 | n_dims << 16
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
         const int p = min(a + q * KA, NP1 - 1);
         int ii = 0, rem = p;                              // p-th pair of itertools.combinations(range(KA), 2)
         while (rem >= KA - 1 - ii) { rem -= KA - 1 - ii; ++ii; }
         const int jj = ii + 1 + rem;
-        pi[q] = ii; pj[q] = jj;
-        pnd[q] = homog ? 2 : min(P.n_dims[ii], P.n_dims[jj]);
+        pp[q] = ii | (jj << 8) | ((homog ? 2 : min(P.n_dims[ii], P.n_dims[jj])) << 16);
     }
 
     double* sK = lds + W::oK;
@@ -313,7 +329,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         const double cr = ref_cost<NS, NC>(x, ut, xf, Q, R, false);
         double cp[PPL > 0 ? PPL : 1];
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + (pp[q] & 255) * NS, sxs + ((pp[q] >> 8) & 255) * NS, pp[q] >> 16, radius);
         DPILQR_LDS_FENCE();
         post_costs(cr, cp, t & 1);
         double xn[NS];
@@ -348,7 +364,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         const double cr = ref_cost<NS, NC>(x, uz, xf, Qf, R, true);
         double cp[PPL > 0 ? PPL : 1];
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + pi[q] * NS, sxs + pj[q] * NS, pnd[q], radius);
+        for (int q = 0; q < PPL; ++q) cp[q] = pair_cost_nd<NS>(sxs + (pp[q] & 255) * NS, sxs + ((pp[q] >> 8) & 255) * NS, pp[q] >> 16, radius);
         DPILQR_LDS_FENCE();
         post_costs(cr, cp, T & 1);
         wave_sync<NW>();
