@@ -49,7 +49,7 @@ class _WorkspacePool:
     buffer when dpilqr_solve_batch has synchronised.  The pool is bounded by COUNT and by BYTES (a quarter of the
     device's memory): the buffers are live tensors, which the allocator's own out-of-memory recovery cannot reclaim."""
     GRANULE = 1 << 28
-    MAX_FREE = 12
+    MAX_FREE = 24
     MAX_FRACTION = 0.25
 
     def __init__(self):
@@ -290,13 +290,15 @@ class ProblemBatch:
 
     def default_window(self, dtype=torch.float64):
         """Items in flight when the caller does not say: 6144 (two rounds of three sweep wavefronts per SIMD on an
-        MI355X) for small clusters, fewer where the per-item buffers are large -- a 10-quadcopter item owns 8.8 MB of
-        tile records, gains and line-search candidates, and several cluster sizes are solved concurrently
-        (dispatch.py) -- so that one solve's workspace stays near 12 GB; never below 1024 (four rounds of the
-        workgroup-per-item sweep), except on the large-cluster path (one workgroup per item: 256 = one per CU)."""
+        MI355X) for small clusters, fewer where the per-item buffers (gains, line-search candidates; tile records where a
+        record-fed sweep serves the batch) are large, so that one solve's workspace stays near 4 GB: several cluster sizes
+        are solved concurrently (dispatch.py), and workspaces of 10 GB each did not fit the pool of reusable buffers --
+        the fresh multi-GB allocations that followed cost a many-scenario call up to half a second, at random.  The
+        workgroup-per-item sweeps hold 2-4 sub-problems per CU, so a thousand in flight fill the device: never below
+        1024, except on the large-cluster path (one workgroup per item: 256 = one per CU)."""
         per_item = self.workspace_bytes(2, True, dtype) - self.workspace_bytes(1, True, dtype)
         floor = 256 if (self.fused_sweep or dtype != torch.float64) else 1024
-        return int(min(self.B, 6144, max(floor, (12 << 30) // max(per_item, 1))))
+        return int(min(self.B, 6144, max(floor, (4 << 30) // max(per_item, 1))))
 
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64):
         """ilqrSolver.solve (control.py:150-225) for all B items.
