@@ -66,8 +66,12 @@ struct WgCfg {
     // [K|d] region, which is dead from the end of S6 to S3
     static constexpr int NPR = KA * (KA - 1) / 2;
     static constexpr int szW = FUSED ? round_up(KA * (NS * NS + NC * NC), 2) : 0;
-    static constexpr int oFx = 0, oFe = oFx + N, oFu = oFe + N, oFg = oFu + M, oFh = oFg + 3 * NPR, oFd = oFh + 9 * NPR,
-                         oFs = oFd + 9 * KA, oFend = oFs + 3 * KA;
+    // (offsets from the start of [K|d]; where T3^T has an LDS region of its own -- dead until S4 -- x, x - x_f, u go there)
+    static constexpr int oFg = 0, oFh = oFg + 3 * NPR, oFd = oFh + 9 * NPR, oFs = oFd + 9 * KA, oFend0 = oFs + 3 * KA;
+    static constexpr bool XU_IN_T3 = !T3REG;
+    static constexpr int oFx = XU_IN_T3 ? KROWS * LK : oFend0, oFe = oFx + N, oFu = oFe + N;
+    static constexpr int oFend = XU_IN_T3 ? oFend0 : oFu + M;
+    static constexpr bool fused_fits = oFend <= M * LK && (!XU_IN_T3 || 2 * N + M <= MK * N);
     static constexpr int oP = 0, oG = oP + szP, oK = oG + szG, oT3 = oK + KROWS * LK, oAB = oK + szK, oPan = oAB + szAB,
                          oW = oPan + szPan, oEnd = oW + szW;
     static constexpr int total = round_up(oEnd + 64, 2);   // + store target of idle lanes, wrapped tile reads
@@ -93,7 +97,7 @@ struct WgCfg {
 #endif
     static constexpr bool supported = (N % NS == 0) && (M == KA * NC) && (N % 2 == 0) && (M <= 32) && (64 - M > 0) &&
                                       (4 * (64 - M) >= NP) && (total * 8 <= 160 * 1024) &&
-                                      (!FUSED || (oFend <= M * LK && 12 * KA <= kWgThreads && 64 + NPR <= kWgThreads));
+                                      (!FUSED || (fused_fits && 12 * KA <= kWgThreads && 64 + NPR <= kWgThreads));
 };
 
 // Pins a phase's accumulators at this point of the program: the multiply-adds that produce them are issued before it, the
