@@ -54,10 +54,11 @@ struct WgCfg {
     // a2 (n+1 x n, S5 epilogue -> S6) starts at G and runs on into the [K|d] region: both are dead by then
     static constexpr int szK = round_up(szG + szKT3 >= NP * LM ? szKT3 : NP * LM - szG, 2);
     static constexpr int szAB = round_up(KA * NS * NSCP, 2);
-    // S3 by blocks (gj_blocked below) from m = 24 on, where the register budget of two sub-problems per CU holds both it and
-    // the fall-back (below that it spills at three or four per CU, and the LU is a smaller part of the step): 32 x 4 doubles
-    // per wavefront to turn a panel's columns into rows
-    static constexpr bool GJ = (M >= 24);
+    // S3 by blocks (gj_blocked below) for m = 13 .. 16 (one row tile: 16 registers of accumulators) and from m = 24 on (where
+    // the register budget of two sub-problems per CU holds both it and the fall-back); at m = 17 .. 23 it spills at three and
+    // four sub-problems per CU and those sizes keep the register LU.  32 x 4 doubles per wavefront to turn a panel's columns
+    // into rows
+    static constexpr bool GJ = (M >= 24) || (M >= 13 && M <= 16);
     // ... which take the place of the [A|B] blocks where those are large enough (dead between S2 and the next S0)
     static constexpr bool PAN_IN_AB = GJ && szAB >= 4 * 128;
     static constexpr int szPan = (GJ && !PAN_IN_AB) ? 4 * 128 : 0;

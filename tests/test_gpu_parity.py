@@ -462,8 +462,8 @@ def test_sweep_twelve_state_family(dp, k):
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
 
 
-@pytest.mark.parametrize("model,k,T", [(0, 7, 50), (0, 13, 50), (0, 15, 50), (3, 7, 100), (3, 12, 100), (3, 13, 100), (3, 14, 100),
-                                       (3, 15, 100), (4, 8, 75), (4, 10, 75)])
+@pytest.mark.parametrize("model,k,T", [(0, 7, 50), (0, 13, 50), (0, 15, 50), (3, 7, 100), (3, 8, 100), (3, 12, 100), (3, 13, 100),
+                                       (3, 14, 100), (3, 15, 100), (4, 5, 75), (4, 8, 75), (4, 10, 75)])
 def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     """Whole solves of 7..15-agent clusters at the configs' horizons (cfg3: unicycles T = 100, cfg4: quadcopters T = 75) and
     the reference's n_lqr_iter = 50: the workgroup-per-item sweep and the two / three-wavefront line search against the
@@ -491,8 +491,9 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     rep = parity.report(r, o, op)
     assert rep["summary"]["all_ok"], (rep["summary"], [w for w in rep["why"] if w])
     plain = rep["same"] & ~rep["unstable"] & (rep["chaotic_from"] < 0)
-    # (ten quadcopters solved centrally from hover are chaotic in the oracle on most seeds: the bound above still holds)
-    assert plain.sum() >= (1 if (model, k) == (4, 10) else 3), rep["summary"]
+    # (ten quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the oracle itself on most seeds:
+    # the bound above still holds for every item)
+    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8)) else 3), rep["summary"]
     for i in np.where(plain)[0]:
         assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i
         assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i
