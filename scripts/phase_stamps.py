@@ -59,7 +59,7 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     torch.cuda.synchronize()
     ph = buf.cpu().numpy()[4 * B:].reshape(B, 8) / Tw
     names = ["S0 stage AB, request l-values", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6", "-"]
-    print(f"S3: steps solved by blocks (m >= 24; below that: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
+    print(f"S3: steps solved by blocks (m = 13..16 and m >= 24; else: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
           f"fall-back's partial pivoting moved a row: {ph[:, 7].mean() / 10:.1f} %")
     ph = ph[:, :6]
     tot = ph.sum(1).mean()
