@@ -58,7 +58,11 @@ struct WgCfg {
     // the register budget of two sub-problems per CU holds both it and the fall-back); at m = 17 .. 23 it spills at three and
     // four sub-problems per CU and those sizes keep the register LU.  32 x 4 doubles per wavefront to turn a panel's columns
     // into rows
+#ifdef DPILQR_GJ_ALL   // A/B builds
+    static constexpr bool GJ = (M >= 13);
+#else
     static constexpr bool GJ = (M >= 24) || (M >= 13 && M <= 16);
+#endif
     // ... which take the place of the [A|B] blocks where those are large enough (dead between S2 and the next S0)
     static constexpr bool PAN_IN_AB = GJ && szAB >= 4 * 128;
     static constexpr int szPan = (GJ && !PAN_IN_AB) ? 4 * 128 : 0;
@@ -90,7 +94,11 @@ struct WgCfg {
     // the LU alone holds 4 m of them, the S1 / S2 accumulators 4 (n_s + n_c)).  A spilling build is far slower than a
     // build with one sub-problem fewer per CU (measured), so the caps follow the compiler's spill-free register counts
     static constexpr int kLdsFit = (160 * 1024) / (total * 8);
+#ifdef DPILQR_GJ_ALL
+    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 16 ? 3 : 2) : (M <= 16 ? 4 : 2));
+#else
     static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 22 ? 3 : 2)));
+#endif
 #ifdef DPILQR_WG_OCC   // A/B builds
     static constexpr int OCC = kLdsFit < DPILQR_WG_OCC ? (kLdsFit < 1 ? 1 : kLdsFit) : DPILQR_WG_OCC;
 #else
