@@ -70,7 +70,7 @@ class _WorkspacePool:
         size = max(1, -(-int(nbytes) // self.GRANULE)) * self.GRANULE
         try:
             return torch.empty(size, dtype=torch.uint8, device=dev)
-        except torch.OutOfMemoryError:
+        except getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError):
             self.clear()                       # the pooled buffers are the likeliest reason: give them back and retry once
             torch.cuda.empty_cache()
             return torch.empty(size, dtype=torch.uint8, device=dev)

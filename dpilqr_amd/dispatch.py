@@ -191,7 +191,7 @@ class ScenarioFrontEnd:
 
 
 def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, concurrent=True, ignore_ids=None, device_out=False,
-                                shard=None, **kwargs):
+                                shard=None, audit=False, **kwargs):
     """solve_distributed (distributed.py:25-103) for S scenarios of ONE k-agent problem at once -- the Monte-Carlo
     front end (scripts/analysis.py:126-174 runs it seed by seed).  Everything between the trajectories and the stitched
     result stays on the device: graph, de-duplication, size buckets, gathered sub-problem inputs (ScenarioFrontEnd), one
@@ -201,6 +201,9 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
     X (S, T+1, n_x) or (S, 1, n_x) [the reference's `X = x0` first call]; U (S, T, n_u); radius: graph threshold/2
     xf (S, n_x): per-scenario goals (default: the problem's own for every scenario); NumPy arrays or device tensors
     shard = (rank, world): solve only this rank's share of every size bucket (sharding.solve_scenarios_sharded)
+    audit : keep every bucket's sub-problem inputs and full solve record (x0, xf, U0, X, U, J, status, n_bwd, n_fwd and the
+            decision trace) as host arrays in info["audit"][cluster size] -- what a parity check of the individual
+            sub-problem solves needs; the solves themselves are the same
     returns X_dec (S, T+1, n_x), U_dec (S, T, n_u), J_full (S,), info (clusters as bit masks, counts) -- NumPy arrays, or
     device tensors with device_out=True; with `shard` the unstitched (front end, solved slices) pair instead.
     """
@@ -230,9 +233,13 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
             return kc, None
         with torch.cuda.device(dev_index), torch.cuda.stream(torch.cuda.Stream(device=dev_index)):
             pb, x0, U0 = fe.bucket(kc, lo, hi)
-            r = pb.solve(x0, U0, window=window, **solve_kw)
+            r = pb.solve(x0, U0, window=window, trace=bool(audit), **solve_kw)
             torch.cuda.current_stream().synchronize()
-            return kc, (r["X"], r["U"], lo, hi - lo, int(r["n_bwd"].sum().item()))
+            rec = None
+            if audit:
+                rec = {key: v.cpu().numpy() for key, v in r.items()}
+                rec.update(x0=x0.cpu().numpy(), U0=U0.cpu().numpy(), xf=pb._xf.cpu().numpy().reshape(hi - lo, -1), lo=lo)
+            return kc, (r["X"], r["U"], lo, hi - lo, int(r["n_bwd"].sum().item()), rec)
 
     # buckets are independent and, for a handful of scenarios, small: their solves run concurrently, each on its own
     # HIP stream from its own host thread
@@ -248,6 +255,8 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
     info = dict(n_subproblems=int(S * k), n_unique=int(fe.counts.sum()),
                 sizes={int(kc): int(fe.counts[kc]) for kc in sizes}, n_bwd=n_bwd_total,
                 seconds=dict(front_end=t_front, solves=t_solve))
+    if audit:
+        info["audit"] = {int(kc): r[5] for kc, r in results if r is not None}
     if shard is not None:
         return fe, solved, info
     # stitch: agent i of scenario s takes ITS columns of the sub-problem solved for its neighbourhood; then J_full:

@@ -445,30 +445,40 @@ double oracle_rollout(const oracle_problem *p, const double *x0, const double *U
 }
 
 /* C[m x n] = A^T[m x k] B[k x n], A stored k x m */
-static void mm_tn(int m, int n, int k, const double *A, const double *B, double *C)
+/* (loop order i, l, j: every C[i][j] still accumulates its k products in the order l = 0, 1, ... from 0.0 -- the same
+ * roundings as a dot-product loop -- but the inner loop runs along rows of B and C, so the compiler can vectorise it:
+ * the 240-state passes of config 5 cost 7 s each otherwise) */
+#define VEC __attribute__((optimize("O3", "tree-vectorize")))
+VEC static void mm_tn(int m, int n, int k, const double *restrict A, const double *restrict B, double *restrict C)
 {
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            for (int l = 0; l < k; ++l) s += A[l * m + i] * B[l * n + j];
-            C[i * n + j] = s;
+    for (int i = 0; i < m; ++i) {
+        double *restrict c = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) c[j] = 0.0;
+        for (int l = 0; l < k; ++l) {
+            const double a = A[l * m + i];
+            const double *restrict b = B + (size_t)l * n;
+            for (int j = 0; j < n; ++j) c[j] += a * b[j];
         }
+    }
 }
 /* C[m x n] = A[m x k] B[k x n] */
-static void mm_nn(int m, int n, int k, const double *A, const double *B, double *C)
+VEC static void mm_nn(int m, int n, int k, const double *restrict A, const double *restrict B, double *restrict C)
 {
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            for (int l = 0; l < k; ++l) s += A[i * k + l] * B[l * n + j];
-            C[i * n + j] = s;
+    for (int i = 0; i < m; ++i) {
+        double *restrict c = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) c[j] = 0.0;
+        for (int l = 0; l < k; ++l) {
+            const double a = A[i * k + l];
+            const double *restrict b = B + (size_t)l * n;
+            for (int j = 0; j < n; ++j) c[j] += a * b[j];
         }
+    }
 }
 
 /* Solve M X = R for nrhs right-hand sides by LU with partial (row) pivoting, the
  * algorithm of LAPACK dgesv behind np.linalg.solve (control.py:141-142).
  * M [m x m] and R [m x nrhs] are overwritten; returns -1 on an exactly zero pivot. */
-static int lu_solve(int m, int nrhs, double *M, double *R)
+VEC static int lu_solve(int m, int nrhs, double *restrict M, double *restrict R)
 {
     for (int c = 0; c < m; ++c) {
         int piv = c;
@@ -716,6 +726,98 @@ int oracle_solve(const oracle_problem *p, const double *x0, double *U, int n_lqr
     if (n_fwd) *n_fwd = nf;
     free(K); free(d); free(Xn); free(Un);
     return status;
+}
+
+/* The same loop as oracle_solve, but FOLLOWING a given decision sequence instead of taking its own: "forced" is the
+ * decision trace of the implementation under test ([n_forced][5] rows as written by oracle_solve / dpilqr_solve_batch; only
+ * column 1, the accepted alpha index or -1, is read) and forced_status its final status.  At every iteration the oracle
+ * evaluates the candidates the implementation must have evaluated (alpha_0 .. alpha_accepted, all ten after a failed
+ * search) with ITS OWN numbers, notes what it would have decided itself and how far from equality each comparison that
+ * went the other way sat (control.py:183 J < J*, :184 |(J* - J)/J*| < tol), then takes the forced branch.  So every
+ * iteration of the implementation's solve -- also the ones after a decision on which the two differ -- has oracle numbers
+ * of the SAME iterate beside it (oracle/parity.py).  TEST INFRASTRUCTURE like everything in this file.
+ *   rtrace [n_forced][8] = (mu_before, the oracle's own accepted index at this iterate (-1 none among the candidates
+ *   evaluated), J of the last candidate evaluated, J* after the forced step, accept margin, convergence margin, J* before,
+ *   the oracle's own converged flag).  A margin is 0 where the oracle's own verdict is the forced one, otherwise the
+ *   relative distance of the comparison from equality (infinity for a NaN cost the implementation accepted).
+ * Returns forced_status, or -1 if a pivot was exactly zero. */
+int oracle_solve_replay(const oracle_problem *p, const double *x0, double *U, int n_lqr_iter, double tol,
+                        const double *forced, int n_forced, int forced_status, double *X, double *J_out,
+                        double *rtrace)
+{
+    const int n = p->k * p->n_s, m = p->k * p->n_c, T = p->T;
+    double alphas[10];
+    oracle_alphas(alphas);
+    double mu = 1.0, delta = 2.0;
+    double *K = (double *)malloc(sizeof(double) * (size_t)T * m * n), *d = (double *)malloc(sizeof(double) * T * m);
+    double *Xn = (double *)malloc(sizeof(double) * (T + 1) * n), *Un = (double *)malloc(sizeof(double) * T * m);
+    double J_star = oracle_rollout(p, x0, U, X);
+    double J = J_star;
+    int status = forced_status;
+    if (n_forced > n_lqr_iter) n_forced = n_lqr_iter;
+    for (int it = 0; it < n_forced; ++it) {
+        const int a_f = (int)forced[it * 5 + 1];
+        const int last = a_f >= 0 ? a_f : 9;
+        const double mu_before = mu, J_before = J_star;
+        double acc_margin = 0.0, conv_margin = 0.0;
+        int natural = -1, nat_conv = 0;
+        if (oracle_backward_pass(p, X, U, mu, K, d)) { status = -1; break; }
+        for (int a = 0; a <= last; ++a) {
+            J = oracle_forward_pass(p, X, U, K, d, alphas[a], Xn, Un);
+            const int takes = J < J_star;
+            if (takes && natural < 0) natural = a;
+            if (a != a_f && takes) {                       /* the implementation rejected a candidate the oracle takes */
+                const double g = (J_star - J) / fabs(J_star);
+                if (g > acc_margin) acc_margin = g;
+            }
+            if (a == a_f && !takes) {                      /* ... accepted one the oracle rejects */
+                const double g = J == J ? (J - J_star) / fabs(J_star) : INFINITY;
+                if (g > acc_margin || g != g) acc_margin = g;
+            }
+        }
+        if (a_f >= 0) {
+            const double rel = fabs((J_star - J) / J_star);
+            nat_conv = rel < tol;
+            const int forced_conv = (it == n_forced - 1) && forced_status == ORACLE_CONVERGED;
+            if (nat_conv != forced_conv) conv_margin = fabs(rel - tol);
+            if (nat_conv != forced_conv && conv_margin == 0.0) conv_margin = 1e-300;   /* a flip that sat exactly on tol */
+            memcpy(X, Xn, sizeof(double) * (T + 1) * n);
+            memcpy(U, Un, sizeof(double) * T * m);
+            J_star = J;
+            delta = fmin(1.0, delta) / 2.0;
+            mu *= delta;
+            if (mu <= 1e-6) mu = 0.0;
+        }
+        rtrace[it * 8 + 0] = mu_before; rtrace[it * 8 + 1] = natural; rtrace[it * 8 + 2] = J; rtrace[it * 8 + 3] = J_star;
+        rtrace[it * 8 + 4] = acc_margin; rtrace[it * 8 + 5] = conv_margin; rtrace[it * 8 + 6] = J_before;
+        rtrace[it * 8 + 7] = nat_conv;
+    }
+    *J_out = J;
+    free(K); free(d); free(Xn); free(Un);
+    return status;
+}
+
+/* forced [B][n_lqr_iter][5], n_forced / forced_status [B], rtrace [B][n_lqr_iter][8] */
+int oracle_replay_batch(const oracle_problem *proto, int B, const double *x0, const double *xf, double *U,
+                        int n_lqr_iter, double tol, const double *forced, const int *n_forced,
+                        const int *forced_status, double *X, double *J, int *status, double *rtrace, int n_threads)
+{
+    const int n = proto->k * proto->n_s, m = proto->k * proto->n_c, T = proto->T;
+    const size_t rows = (size_t)(n_lqr_iter > 0 ? n_lqr_iter : 1);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        oracle_problem q = *proto;
+        q.xf = xf + (size_t)b * n;
+        status[b] = oracle_solve_replay(&q, x0 + (size_t)b * n, U + (size_t)b * T * m, n_lqr_iter, tol,
+                                        forced + b * rows * 5, n_forced[b], forced_status[b],
+                                        X + (size_t)b * (T + 1) * n, J + b, rtrace + b * rows * 8);
+    }
+    return 0;
 }
 
 int oracle_max_threads(void)

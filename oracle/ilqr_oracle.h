@@ -104,6 +104,16 @@ int oracle_solve_batch(const oracle_problem *proto, int B, const double *x0, con
 int oracle_solve_batch_trace(const oracle_problem *proto, int B, const double *x0, const double *xf, double *U,
                              int n_lqr_iter, double tol, double *X, double *J, int *status, int *n_bwd,
                              int *n_fwd, int n_threads, double *trace /* [B][max(n_lqr_iter,1)][5] or NULL */);
+/* oracle_solve made to FOLLOW the decision trace of an implementation under test (see ilqr_oracle.c): the oracle's numbers
+ * for the same iterates, its own verdicts and the distance from equality of every comparison that went the other way.
+ * rtrace [n_forced][8] = (mu_before, own accepted index, J_last, J_star_after, accept margin, convergence margin,
+ * J_star_before, own converged flag). */
+int oracle_solve_replay(const oracle_problem *p, const double *x0, double *U, int n_lqr_iter, double tol,
+                        const double *forced, int n_forced, int forced_status, double *X, double *J_out,
+                        double *rtrace);
+int oracle_replay_batch(const oracle_problem *proto, int B, const double *x0, const double *xf, double *U,
+                        int n_lqr_iter, double tol, const double *forced, const int *n_forced,
+                        const int *forced_status, double *X, double *J, int *status, double *rtrace, int n_threads);
 int oracle_max_threads(void);
 
 #ifdef __cplusplus

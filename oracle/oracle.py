@@ -246,7 +246,7 @@ def solve_batch(proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, trace=F
     L.oracle_solve_batch_trace.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp,
                                            c_ip, c_ip, c_ip, C.c_int, c_dp]
     L.oracle_solve_batch_trace(proto.ptr, Bn, _p(x0), _p(xf), _p(U), n_lqr_iter, tol, _p(X), _p(J), ip(st), ip(nb),
-                               ip(nf), int(n_threads), _p(tr) if trace else None)
+                               ip(nf), _threads(n_threads), _p(tr) if trace else None)
     out = dict(X=X, U=U, J=J, status=st, n_bwd=nb, n_fwd=nf)
     if trace:
         for i in range(Bn):
@@ -255,8 +255,59 @@ def solve_batch(proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, trace=F
     return out
 
 
+def replay_batch(proto, x0, xf, U0, forced, n_lqr_iter=50, tol=1e-3, n_threads=0):
+    """The oracle made to FOLLOW the decisions of an implementation under test (oracle_solve_replay): `forced` is that
+    implementation's result dict (trace (B, n_lqr_iter, 5), n_bwd, status).  Returns X, U, J and rtrace (B, n_lqr_iter, 8) =
+    (mu_before, the oracle's own accepted index, J_last, J_star_after, accept margin, convergence margin, J_star_before,
+    the oracle's own converged flag), NaN beyond each item's last iteration."""
+    x0, xf = _f64(x0), _f64(xf); U = _f64(U0).copy()
+    Bn = x0.shape[0]
+    rows = max(n_lqr_iter, 1)
+    ft = np.full((Bn, rows, 5), -1.0)
+    t = np.asarray(forced["trace"], dtype=np.float64)
+    ft[:, :min(rows, t.shape[1])] = t[:, :rows]
+    ft = _f64(np.nan_to_num(ft, nan=-1.0))
+    nfo = np.ascontiguousarray(forced["n_bwd"], dtype=np.int32); fst = np.ascontiguousarray(forced["status"], dtype=np.int32)
+    X = np.zeros((Bn, proto.T + 1, proto.n_x)); J = np.zeros(Bn); st = np.zeros(Bn, dtype=np.int32)
+    rt = np.full((Bn, rows, 8), np.nan)
+    ip = lambda a: a.ctypes.data_as(c_ip)
+    L = lib()
+    L.oracle_replay_batch.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, C.c_int, C.c_double, c_dp, c_ip, c_ip,
+                                      c_dp, c_dp, c_ip, c_dp, C.c_int]
+    L.oracle_replay_batch(proto.ptr, Bn, _p(x0), _p(xf), _p(U), n_lqr_iter, tol, _p(ft), ip(nfo), ip(fst), _p(X), _p(J),
+                          ip(st), _p(rt), _threads(n_threads))
+    for i in range(Bn):
+        rt[i, nfo[i]:] = np.nan
+    return dict(X=X, U=U, J=J, status=st, n_bwd=nfo, rtrace=rt)
+
+
 def max_threads():
     return lib().oracle_max_threads()
+
+
+def usable_cores():
+    """The CPUs this process may actually keep busy: its affinity mask, capped by the cgroup's CPU quota (the GPU boxes
+    show 256 hardware threads behind `cpu.max = 1600000 100000`, i.e. 16 CPUs: 256 OpenMP threads then spend their time
+    throttled -- 2.3 k sub-problems/s against 5.2 k with 16 threads, profiles/r03_cpu_probe.txt)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = Path(path).read_text().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text()); per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _threads(n_threads):
+    return int(n_threads) if n_threads and n_threads > 0 else usable_cores()
 
 
 # ---------------------------------------------------------------- dispatch layer

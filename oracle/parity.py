@@ -1,140 +1,204 @@
-"""All-items parity report of a batch of whole solves against the oracle -- TEST INFRASTRUCTURE ONLY (used by tests/ and
-by bench.py's untimed parity_vs_oracle leg; the product never imports it).
+"""All-items parity of a batch of whole solves against the oracle -- TEST INFRASTRUCTURE ONLY (used by tests/ and by
+bench.py's untimed parity_vs_oracle leg; the product never imports it).
 
 The final trajectory of an iLQR solve depends on discrete decisions (line-search acceptance J < J*, control.py:183, and
 the convergence test |(J* - J) / J*| < tol, :184) and on a recursion that amplifies a 1e-13 perturbation of x0 by
 1e5..1e6 and, on a few per cent of cfg2 scenarios, by far more: there the REFERENCE'S OWN accepted costs drift apart
 by 1e-4..1e-1 over a few iterations before any decision changes (measured with the real reference).
-A fixed tolerance cannot hold for those items in any implementation; exempting them would let them be arbitrarily
-wrong.  So every item is held to a bound scaled by the sensitivity the oracle itself shows on that item:
+A fixed tolerance cannot hold for those items in any implementation, and exempting them (round 2 required only
+finiteness once the oracle's sensitivity left the linear regime: 9.7 % of cfg2) lets them be arbitrarily wrong.  Round 3
+holds EVERY item, through EVERY iteration of its solve, to an envelope the oracle itself draws on that item:
 
-  o  = oracle from x0,   p = oracle from x0 (1 + 1e-13),   g = the implementation under test
-  i_g, i_p = first iteration whose decision (accepted alpha, number of forward passes; after the last iteration: the
-             final status / iteration count) differs from o's, for g and for p (inf if none)
+  g    = the implementation under test: X, U, J, status, n_bwd and its decision trace (accepted alpha per iteration)
+  r    = the oracle REPLAYED along g's decisions from x0 (oracle_solve_replay): the oracle's numbers for the same
+         iterates -- also after a decision on which g and the oracle's own choice differ -- plus, per iteration, the
+         oracle's own verdict and how far from equality every comparison that went the other way sat
+  r_e  = the same replay from x0 (1 + delta_e), e = 1..8, delta = +-1e-13, +-2e-13, +-3e-13, +-5e-13: the ensemble
+  spread_J[j] = max over e and over iterations <= j of |J*_e - J*_r| / |J*_r| (accepted costs and the last evaluated
+                candidate's cost);  spread_X = max_e relerr(X_e, X_r), spread_U likewise
 
-  (1) accepted costs: for every iteration j < min(i_g, i_p)
-          |J*_g[j] - J*_o[j]| <= C max(FLOOR, |J*_p[j] - J*_o[j]|)        (relative to |J*_o[j]|, C = 100, FLOOR = 1e-11)
-  (2) same decisions (i_g = inf): final states   err(g, o) <= C max(FLOOR, err(p, o))
-  (3) a decision differs at i_g:  either the oracle's own decisions change at or before i_g under the 1e-13
-      perturbation (i_p <= i_g: that decision is not determined at fp64 resolution in the reference either), or the
-      comparison that went the other way was within  eps = C max(FLOOR, max_{j < i_g} |J*_p[j] - J*_o[j]| / |J*_o[j]|)
-      of equality: J_candidate ~ J* for an acceptance flip, |dJ / J*| ~ tol for a convergence flip.
-  (4) the linear bounds stop where the oracle's own sensitivity leaves the linear regime: from the first iteration j_c
-      at which |J*_p - J*_o| / |J*_o| > S_CHAOS = 1e-7 (the 1e-13 perturbation amplified a million times; growth is
-      super-linear from there -- measured: a 5e-13 perturbation then moves J* 100x more than a 1e-13 one) the item
-      counts as "chaotic in the oracle from j_c on": everything BEFORE j_c is still held to (1) and (3), what follows
-      is only required to be finite.  The summary reports how many items that concerns and from which iteration.
+  (1) every iteration j of g's solve:  |J*_g[j] - J*_r[j]| / |J*_r[j]| <= C max(FLOOR, spread_J[j])      (also J_last)
+  (2) the result:   relerr(X_g, X_r) <= C max(FLOOR, spread_X),  relerr(U_g, U_r) <= C max(FLOOR, spread_U),
+                    |J_g - J_r| / |J_r| <= C max(FLOOR, spread_J[last])
+  (3) every decision of g that is not the oracle's own verdict on the same iterate (an acceptance or convergence
+      "flip"; iteration 0 included: the replay knows the initial rollout's cost) must be one the reference itself does
+      not determine at fp64 resolution: a member of the ensemble takes g's decision there, or the members' own verdicts
+      on that iterate differ from r's (the line search is a lottery there: on cfg2 seed 1324 the replay and three
+      members accept alpha_2, alpha_1, alpha_0, alpha_0 at iteration 4, with candidate costs 33 % apart), or the
+      comparison sat within C max(FLOOR, spread_J[j]) of equality
+  (4) mu before every iteration is the oracle's (the schedule is a function of the decisions), everything is finite
 
-Anything else is a violation.
+with C = 10, FLOOR = 1e-11.  An item that misses a bound is looked at again with a 64-member ensemble (deltas log-spaced
+over the same 1e-13..5e-13, both signs) before it counts as a violation: where the ensemble's outcomes have spread to
+O(1) -- 4 % of cfg2 items end there -- eight samples of a heavy-tailed distribution do not bound a ninth to a factor 10
+(measured: the oracle from x0 (1 + 3e-14), itself inside the ensemble's range, misses on 2 of 1024 items with eight members
+and on none with 64).  Nothing is exempt and nothing ends early; where the ensemble itself spreads by more than
+1e-5 the bound is weak and the summary says for how many items (bound_above_1e5_frac) -- that is the reference's own
+indeterminacy, measured, not a class of items that are waved through.  Calibration (tests/test_parity_envelope.py, CPU):
+the oracle built with fused multiply-adds (a legitimately different rounding of every product) passes on every item; the
+oracle from x0 (1 + 1e-9) or with tol = 1.01e-3 fails.
 """
 import numpy as np
 
-C_SENS = 100.0
+C_ENV = 10.0
 FLOOR = 1e-11
-S_CHAOS = 1e-7
-INF = 1 << 30
+DELTAS = (1e-13, -1e-13, 2e-13, -2e-13, 3e-13, -3e-13, 5e-13, -5e-13)
+TINY = 1e-300
 
 
 def _rel(a, b):
     a = a.reshape(a.shape[0], -1); b = b.reshape(b.shape[0], -1)
-    return np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-300)
+    with np.errstate(invalid="ignore"):
+        e = np.abs(a - b).max(axis=1) / np.maximum(np.nanmax(np.abs(np.where(np.isfinite(b), b, 0.0)), axis=1), TINY)
+    return np.where(np.isnan(e), np.inf, e)       # a NaN on either side (tan() blow-ups of the quadcopter models): infinitely far
 
 
-def _first_difference(ta, na, sa, tb, nb, sb):
-    """First iteration at which two decision traces part (INF if they are the same solve)."""
-    n = min(na, nb)
-    for j in range(n):
-        if ta[j, 1] != tb[j, 1] or ta[j, 4] != tb[j, 4]:
-            return j
-    if na != nb or sa != sb:
-        return max(n - 1, 0)      # same steps, one of the two stopped here: the verdict after iteration n - 1 differs
-    return INF
+def _reldiff(a, b):
+    """|a - b| / |b| element-wise; 0 where both are NaN, inf where exactly one is (or the difference is not finite)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = np.abs(a - b) / np.maximum(np.abs(b), TINY)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.where(both_nan, 0.0, d)
+    return np.where(np.isnan(d), np.inf, d)
 
 
-def report(got, oracle, oracle_perturbed, tol=1e-3):
-    """got / oracle / oracle_perturbed: dicts with X (B,T+1,n), status, n_bwd (B,), trace (B,iters,5) as written by
-    dpilqr_solve_batch and oracle.solve_batch(trace=True).  Returns per-item arrays (ok, same, err, sens, why) and a
-    summary; ok[i] says that item i satisfies the bounds above."""
-    X, Xo, Xp = (np.asarray(d["X"], dtype=np.float64) for d in (got, oracle, oracle_perturbed))
-    B = X.shape[0]
-    err, sens = _rel(X, Xo), _rel(Xp, Xo)
-    tg, to, tp = (np.asarray(d["trace"]) for d in (got, oracle, oracle_perturbed))
-    nb = lambda d, i: int(d["n_bwd"][i])
-    st = lambda d, i: int(d["status"][i])
-    same = np.zeros(B, dtype=bool); ok = np.zeros(B, dtype=bool); explained = np.zeros(B, dtype=bool)
-    unstable = np.zeros(B, dtype=bool); chaotic_from = np.full(B, -1)
-    why = [""] * B
+def _envelope_once(got, proto, x0, xf, U0, n_lqr_iter, tol, n_threads, deltas, C):
+    """got: dict with X (B,T+1,n), U (B,T,m), J, status, n_bwd (B,), trace (B,iters,5) as written by dpilqr_solve_batch
+    (or oracle.solve_batch(trace=True)); proto, x0, xf, U0: the oracle-side description of the same batch.  Returns
+    per-item arrays; ok[i] says that item i satisfies (1)-(4) above against this ensemble."""
+    from . import oracle as orc
+    x0 = np.asarray(x0, dtype=np.float64); xf = np.asarray(xf, dtype=np.float64); U0 = np.asarray(U0, dtype=np.float64)
+    g = {k: np.asarray(v) for k, v in got.items()}
+    B = x0.shape[0]
+    tg = np.asarray(g["trace"], dtype=np.float64)
+    if tg.shape[1] < n_lqr_iter:
+        tg = np.concatenate([tg, np.full((B, n_lqr_iter - tg.shape[1], 5), np.nan)], axis=1)
+    ng = g["n_bwd"].astype(int)
+    # the replay and its ensemble as ONE batch (the OpenMP loop of the oracle runs over items: (1 + E) B of them)
+    E = len(deltas)
+    scale = np.concatenate([[0.0], np.asarray(deltas, dtype=np.float64)])
+    forced = {k: np.concatenate([np.asarray(g[k])] * (E + 1)) for k in ("trace", "n_bwd", "status")}
+    allr = orc.replay_batch(proto, np.concatenate([x0 * (1.0 + dl) for dl in scale]), np.concatenate([xf] * (E + 1)),
+                            np.concatenate([U0] * (E + 1)), forced, n_lqr_iter, tol, n_threads)
+    part = lambda e: {k: v[e * B:(e + 1) * B] for k, v in allr.items()}
+    r = part(0)
+    ens = [part(e) for e in range(1, E + 1)]
+    rt = r["rtrace"]
+    rows = rt.shape[1]
+    live = np.arange(rows)[None, :] < ng[:, None]
+
+    # the ensemble's spread of the accepted cost / the last candidate's cost per iteration, running maximum along the solve
+    sJ = np.zeros((B, rows))
+    for e in ens:
+        for col in (3, 2):
+            sJ = np.maximum(sJ, np.where(live, _reldiff(e["rtrace"][:, :, col], rt[:, :, col]), 0.0))
+    sJ = np.maximum.accumulate(sJ, axis=1)
+    sX = np.max([_rel(e["X"], r["X"]) for e in ens], axis=0)
+    sU = np.max([_rel(e["U"], r["U"]) for e in ens], axis=0)
+    sX = np.where(np.isnan(sX), np.inf, sX); sU = np.where(np.isnan(sU), np.inf, sU)
+    bJ = C * np.maximum(FLOOR, sJ)
+
+    ok = np.ones(B, dtype=bool); why = [""] * B
+
+    def fail(i, msg):
+        if ok[i]:
+            ok[i] = False; why[i] = msg
+
+    # (1) costs, iteration by iteration, to the end of the solve
+    for col, name in ((3, "accepted cost"), (2, "last evaluated cost")):
+        dg = np.where(live, _reldiff(tg[:, :rows, col], rt[:, :, col]), 0.0)
+        bad = dg > bJ
+        for i in np.where(bad.any(axis=1))[0]:
+            j = int(np.argmax(bad[i]))
+            fail(i, f"{name} of iteration {j} off by {dg[i, j]:.2e}; the ensemble spreads by {sJ[i, j]:.2e} there")
+    # (4) the regularisation schedule and finiteness
+    mu_bad = live & (tg[:, :rows, 0] != rt[:, :, 0])
+    for i in np.where(mu_bad.any(axis=1))[0]:
+        fail(i, f"mu before iteration {int(np.argmax(mu_bad[i]))} is not the schedule's")
+    X, U = np.asarray(g["X"], dtype=np.float64), np.asarray(g["U"], dtype=np.float64)
+    for i in np.where(~(np.isfinite(X).reshape(B, -1).all(axis=1) & np.isfinite(U).reshape(B, -1).all(axis=1)))[0]:
+        fail(i, "non-finite result")
+    # (2) the result
+    errX, errU = _rel(X, r["X"]), _rel(U, r["U"])
+    lastJ = bJ[np.arange(B), np.maximum(ng - 1, 0)]
+    errJ = _reldiff(np.asarray(g["J"], dtype=np.float64), r["J"])
     for i in range(B):
-        i_g = _first_difference(tg[i], nb(got, i), st(got, i), to[i], nb(oracle, i), st(oracle, i))
-        i_p = _first_difference(tp[i], nb(oracle_perturbed, i), st(oracle_perturbed, i), to[i], nb(oracle, i), st(oracle, i))
-        same[i] = i_g == INF
-        unstable[i] = i_p != INF
-        lim = min(i_g, i_p, nb(oracle, i))
-        s_max = 0.0
-        bad = None
-        for j in range(lim):
-            den = max(abs(to[i, j, 3]), 1e-300)
-            dg, dpj = abs(tg[i, j, 3] - to[i, j, 3]) / den, abs(tp[i, j, 3] - to[i, j, 3]) / den
-            if dpj > S_CHAOS:
-                chaotic_from[i] = j
-                break
-            s_max = max(s_max, dpj)
-            if dg > C_SENS * max(FLOOR, dpj) and bad is None:
-                bad = f"accepted cost of iteration {j} off by {dg:.2e}, oracle's own sensitivity there {dpj:.2e}"
-        if bad:
-            why[i] = bad
-            continue
-        if chaotic_from[i] >= 0:           # (4): the prefix has been verified; the rest must only be finite
-            ok[i] = bool(np.isfinite(X[i]).all())
-            if not ok[i]:
-                why[i] = "non-finite states"
-            continue
-        if i_g == INF:
-            bound = C_SENS * max(FLOOR, sens[i])
-            ok[i] = err[i] <= bound
-            if not ok[i]:
-                why[i] = f"same decisions but final states off by {err[i]:.2e} > {C_SENS:g} * max({FLOOR:g}, oracle's own {sens[i]:.2e})"
-            continue
-        if i_p <= i_g:
-            ok[i] = explained[i] = True     # the reference's own decision there is not determined at fp64 resolution
-            continue
-        eps = C_SENS * max(FLOOR, s_max)
-        Jstar = to[i, i_g - 1, 3] if i_g > 0 else None
-        ag, ao = tg[i, i_g, 1], to[i, i_g, 1]
-        if i_g < min(nb(got, i), nb(oracle, i)) and (ag != ao or tg[i, i_g, 4] != to[i, i_g, 4]):
-            # acceptance flip: the side that accepted earlier (or at all) holds the cost of the candidate in question
-            first = tg if (ao < 0 or (0 <= ag < ao)) else to
-            Jc = first[i, i_g, 2]
-            if Jstar is None:               # iteration 0: J* is the initial rollout's cost, which the trace does not hold;
-                Jstar = Jc                  # the other side's rejection of the same candidate is then the only evidence
-                other = to if first is tg else tg
-                gap = abs(other[i, i_g, 2] - Jc) / max(abs(Jc), 1e-300) if other[i, i_g, 1] >= 0 else 0.0
-                gap = min(gap, eps)          # cannot be bounded from the traces alone; accept and flag as explained
-            else:
-                gap = abs(Jc - Jstar) / max(abs(Jstar), 1e-300)
-            ok[i] = explained[i] = gap <= eps
-            if not ok[i]:
-                why[i] = f"acceptance flip at iteration {i_g}: candidate {gap:.2e} away from J*, allowed {eps:.1e}"
-        else:
-            # same steps, different verdict after iteration i_g: the convergence test sat on its threshold
-            Jc = to[i, i_g, 2]
-            Jprev = Jstar if Jstar is not None else None
-            if Jprev is None:
-                ok[i] = explained[i] = True
-                continue
-            gap = abs(abs((Jprev - Jc) / Jprev) - tol)
-            ok[i] = explained[i] = gap <= eps
-            if not ok[i]:
-                why[i] = f"convergence flip after iteration {i_g}: |dJ/J*| {gap:.2e} away from tol, allowed {eps:.1e}"
-    both = same & ~unstable
-    return dict(ok=ok, same=same, explained=explained, unstable=unstable, chaotic_from=chaotic_from, err=err, sens=sens, why=why,
-                summary=dict(items=int(B), all_ok=bool(ok.all()), violations=int((~ok).sum()),
-                             identical_decision_trace_frac=float(same.mean()),
-                             explained_flip_frac=float(explained.mean()),
-                             oracle_unstable_under_1e13_frac=float(unstable.mean()),
-                             chaotic_in_oracle_frac=float((chaotic_from >= 0).mean()),
-                             chaotic_from_iteration_min=int(chaotic_from[chaotic_from >= 0].min()) if (chaotic_from >= 0).any() else None,
-                             states_within_1e5_frac=float((err < 1e-5).mean()),
-                             states_within_1e5_frac_of_stable=float((err[both] < 1e-5).mean()) if both.any() else None,
-                             max_err_over_bound=float(np.max(err[same] / (C_SENS * np.maximum(FLOOR, sens[same])))) if same.any() else None,
-                             median_err=float(np.median(err)), median_sens=float(np.median(sens))))
+        if not errX[i] <= C * max(FLOOR, sX[i]):
+            fail(i, f"final states off by {errX[i]:.2e} > {C:g} * max({FLOOR:g}, ensemble spread {sX[i]:.2e})")
+        if not errU[i] <= C * max(FLOOR, sU[i]):
+            fail(i, f"final controls off by {errU[i]:.2e} > {C:g} * max({FLOOR:g}, ensemble spread {sU[i]:.2e})")
+        if ng[i] > 0 and not errJ[i] <= lastJ[i]:
+            fail(i, f"returned J off by {errJ[i]:.2e}, allowed {lastJ[i]:.1e}")
+    # (3) decisions that are not the oracle's own verdict on the same iterate
+    forced_idx = np.where(live, np.nan_to_num(tg[:, :rows, 1], nan=-1.0), -1.0)
+    acc_flip = live & (rt[:, :, 1] != forced_idx)
+    conv_flip = live & (np.nan_to_num(rt[:, :, 5]) > 0)
+    flip = acc_flip | conv_flip
+    margin = np.where(flip, np.maximum(np.nan_to_num(rt[:, :, 4], nan=np.inf), np.nan_to_num(rt[:, :, 5], nan=np.inf)), 0.0)
+    member_agrees = np.zeros((B, rows), dtype=bool)      # a member of the ensemble takes the implementation's decision
+    members_differ = np.zeros((B, rows), dtype=bool)     # the members' own verdicts on this iterate are not the replay's
+    for e in ens:
+        et = e["rtrace"]
+        member_agrees |= (et[:, :, 1] == forced_idx) & ~(np.nan_to_num(et[:, :, 5]) > 0)
+        members_differ |= live & ((et[:, :, 1] != rt[:, :, 1]) | (et[:, :, 7] != rt[:, :, 7]))
+    explained_at = ~flip | member_agrees | members_differ | (margin <= bJ)
+    flipped = flip.any(axis=1)
+    explained = flipped & explained_at.all(axis=1)
+    for i in np.where(flipped & ~explained)[0]:
+        j = int(np.argmax(~explained_at[i]))
+        kind = "acceptance" if acc_flip[i, j] else "convergence"
+        fail(i, f"{kind} flip at iteration {j}: the oracle's comparison sat {margin[i, j]:.2e} from equality, allowed "
+                f"{bJ[i, j]:.1e}, and no member of the ensemble decides like the implementation")
+
+    return dict(ok=ok, why=why, flipped=flipped, explained=explained, errX=errX, errU=errU, spreadX=sX, spreadU=sU,
+                spreadJ=sJ, flip=flip, member_agrees=member_agrees, X_replay=r["X"], U_replay=r["U"], J_replay=r["J"],
+                rtrace=rt)
+
+
+DELTAS_WIDE = tuple(sg * v for v in np.geomspace(1e-13, 5e-13, 32) for sg in (1.0, -1.0))
+
+
+def envelope(got, proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, deltas=DELTAS, natural=None, C=C_ENV,
+             escalate=DELTAS_WIDE):
+    """The all-items check described at the top of this file.  got: the implementation's result dict (X, U, J, status,
+    n_bwd, trace); proto, x0, xf, U0: the oracle-side description of the same batch; natural (optional): the oracle's own
+    solve of the batch, only used for the *_of_oracle statistics.  Items that miss a bound against the 8-member ensemble
+    are re-examined against the `escalate` ensemble (None: not).  Returns per-item arrays and a summary."""
+    x0 = np.asarray(x0, dtype=np.float64); xf = np.asarray(xf, dtype=np.float64); U0 = np.asarray(U0, dtype=np.float64)
+    g = {k: np.asarray(v) for k, v in got.items() if k in ("X", "U", "J", "status", "n_bwd", "trace")}
+    rep = _envelope_once(g, proto, x0, xf, U0, n_lqr_iter, tol, n_threads, deltas, C)
+    B = x0.shape[0]
+    again = np.where(~rep["ok"])[0]
+    first_why = {int(i): rep["why"][i] for i in again}
+    if len(again) and escalate is not None:
+        sub = _envelope_once({k: v[again] for k, v in g.items()}, proto, x0[again], xf[again], U0[again], n_lqr_iter, tol,
+                             n_threads, escalate, C)
+        for key in ("ok", "flipped", "explained", "spreadX", "spreadU", "spreadJ", "flip", "member_agrees"):
+            rep[key][again] = sub[key]
+        for a, i in enumerate(again):
+            rep["why"][i] = sub["why"][a]
+    ok, why, flipped, explained, errX, errU, sX = (rep[k] for k in ("ok", "why", "flipped", "explained", "errX", "errU", "spreadX"))
+    flip, member_agrees = rep["flip"], rep["member_agrees"]
+    bound_X = C * np.maximum(FLOOR, sX)
+    summ = dict(items=int(B), all_ok=bool(ok.all()), violations=int((~ok).sum()), C=C, floor=FLOOR, ensemble=len(deltas),
+                re_examined_with_wide_ensemble=int(len(again)), wide_ensemble=len(escalate) if escalate is not None else 0,
+                identical_decision_trace_frac=float((~flipped).mean()),
+                flipped_frac=float(flipped.mean()),
+                explained_flip_frac_of_flipped=float(explained[flipped].mean()) if flipped.any() else None,
+                flips_decided_by_an_ensemble_member_frac=float((flip & member_agrees).any(axis=1)[flipped].mean()) if flipped.any() else None,
+                first_flip_iteration_min=int(np.argmax(flip[flipped], axis=1).min()) if flipped.any() else None,
+                states_within_1e5_of_replay_frac=float((errX < 1e-5).mean()),
+                controls_within_1e5_of_replay_frac=float((errU < 1e-5).mean()),
+                bound_above_1e5_frac=float((bound_X > 1e-5).mean()),
+                ensemble_spread_above_1e5_frac=float((sX > 1e-5).mean()),
+                max_err_over_bound=float(np.max(np.where(np.isinf(bound_X), 0.0, errX / np.where(np.isinf(bound_X), 1.0, bound_X)))),
+                median_err=float(np.median(errX)), median_spread=float(np.median(sX)),
+                reference_result_undetermined_frac=float(np.isinf(sX).mean()))
+    if natural is not None:
+        eo = _rel(np.asarray(g["X"], dtype=np.float64), np.asarray(natural["X"], dtype=np.float64))
+        same = ~flipped
+        summ["states_within_1e5_of_oracle_frac"] = float((eo < 1e-5).mean())
+        summ["states_within_1e5_of_oracle_frac_of_identical"] = float((eo[same] < 1e-5).mean()) if same.any() else None
+    rep["summary"] = summ
+    rep["first_why"] = first_why
+    return rep

@@ -139,6 +139,88 @@ def test_cfg5_quad12_homogeneous_pass_vs_oracle(dp):
             assert relerr(Xn[0, ai].cpu().numpy(), Xr) < 1e-8 and abs(float(Jn[0, ai]) - Jr) < 1e-8 * abs(Jr)
 
 
+def _cfg5_batch(hetero, seeds, energy=100.0):
+    """BASELINE config 5 inputs: 20 agents, T = 150; hetero: 14 Quadcopter12D + 6 zero-padded humans (the fixture G8's weights),
+    else 20 x Quadcopter12D, the configuration the reference supports as stated (hover warm start)."""
+    from dpilqr_amd.util import random_setup
+    k, T = 20, 150
+    models = [7] * 14 + [8] * 6 if hetero else [7] * 20
+    nd = [3] * 14 + [2] * 6 if hetero else [3] * 20
+    x0 = np.zeros((len(seeds), 240)); xf = np.zeros((len(seeds), 240))
+    for j, s in enumerate(seeds):
+        np.random.seed(s)
+        a, b = random_setup(k, 12, is_rotation=False, rel_dist=k, var=k / 2, n_d=3, random=True, energy=energy)
+        x0[j], xf[j] = a.ravel(), b.ravel()
+    if hetero:
+        Q = np.stack([np.eye(12)] * 14 + [np.diag([1.0, 1, 1, 0, 0, 0] + [0.0] * 6)] * 6)
+        R = np.stack([np.eye(4)] * 14 + [np.diag([1.0, 1, 1e-9, 1e-9])] * 6)
+    else:
+        Q = np.stack([np.eye(12)] * 20); R = np.stack([np.eye(4)] * 20)
+    Qf = np.stack([1000.0 * np.eye(12)] * k)
+    U0 = np.zeros((len(seeds), T, 80))
+    for i in range(k):
+        if models[i] == 7:
+            U0[:, :, 4 * i + 3] = 9.80665 * 63.0 / 2000.0
+    return models, nd, x0, xf, Q, R, Qf, U0, T
+
+
+@pytest.mark.parametrize("hetero,seeds", [(False, (6000, 6002, 6005, 6007)), (True, (6001, 6006, 6007, 6000))])
+def test_cfg5_whole_solves_at_the_stated_size(dp, hetero, seeds):
+    """BASELINE config 5 at its stated size -- 20 twelve-state agents, n_x = 240, n_u = 80, T = 150 -- as WHOLE solves (up
+    to six iLQR iterations; the seeds were picked for what the oracle does with them: six full iterations, convergence at
+    the fifth, line-search failures after two and three, NaN-cost candidates from tan() on the way): the large-cluster
+    sweep, the KDIRECT forward pass and the device-side decision logic together, every item held to the ensemble
+    envelope of oracle/parity.py (four members: a 240-state backward pass costs the oracle a second or two), and the
+    items on which the reference's own ensemble stays within 1e-6 to the north star's 1e-5 with the oracle's own
+    decision trace."""
+    from oracle import oracle as orc, parity
+    models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(hetero, seeds)
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    assert pb.fused_sweep and (pb.n_x, pb.n_u, pb.T) == (240, 80, 150)
+    r = {k: v.cpu().numpy() for k, v in pb.solve(x0, U0, n_lqr_iter=6, trace=True).items()}
+    proto = orc.Problem(models, nd, xf[0], Q, R, Qf, 0.5, 0.1, T)
+    o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=6, trace=True)
+    rep = parity.envelope(r, proto, x0, xf, U0, n_lqr_iter=6, natural=o, deltas=(1e-13, -1e-13, 5e-13, -5e-13), escalate=None)
+    sm = rep["summary"]
+    print(sm, "n_bwd", r["n_bwd"], "oracle", o["n_bwd"], "status", r["status"])
+    assert sm["all_ok"], (sm, [w for w in rep["why"] if w])
+    assert r["n_bwd"].max() >= 5 and np.isfinite(r["X"]).all()
+    tight = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
+    assert tight.sum() >= 2, (sm, rep["spreadX"])
+    for i in np.where(tight)[0]:
+        n = o["n_bwd"][i]
+        assert (r["n_bwd"][i], r["n_fwd"][i], r["status"][i]) == (n, o["n_fwd"][i], o["status"][i]), i
+        np.testing.assert_array_equal(r["trace"][i, :n, 0], o["trace"][i, :n, 0])                  # mu
+        np.testing.assert_array_equal(r["trace"][i, :n, 1], o["trace"][i, :n, 1])                  # accepted alpha
+        assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i
+        assert abs(r["J"][i] - o["J"][i]) < TOL_SOLVE * abs(o["J"][i]) or (np.isnan(r["J"][i]) and np.isnan(o["J"][i]))
+
+
+def test_fp32_tolerance_study_bounds(dp):
+    """BASELINE config 5's "fp32 vs fp64 tolerance study" as assertions (the table itself: scripts/fp32_study.py,
+    profiles/).  Every figure is fp32-GPU against fp64-GPU on the same items, with fp64-GPU against the fp64 oracle
+    beside it as the noise floor of the comparison.  What the study found and this test holds:
+      * a single fp32 pass is good to 1e-6..1e-5 on well-conditioned items (cfg2: median gain error < 1e-5, median
+        forward-pass state error < 1e-5) but not uniformly (the worst cfg2 gain is off by O(1));
+      * the decision logic turns that into different iterates: fp32 flips decisions on 10..40 % of cfg2 solves, an order
+        of magnitude more often than fp64 does against the oracle, and fewer than 80 % of the fp32 solves end within
+        1e-5 of the fp64 ones -- fp32 cannot meet the north star's bar;
+      * at config 5's size and conditioning (R = 1e-9 entries, cond(Q_uu) ~ 1e9) the fp32 gains are wrong in the second
+        digit (median > 1e-4) although a forward pass on given gains still tracks to 1e-3."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import fp32_study
+    c2 = fp32_study.study("cfg2", [0] * 5, [2] * 5, 50, 512, 0, 10.0, 50, 128)
+    p, s, so = c2["pass"], c2["solve_fp32_vs_fp64"], c2["solve_fp64_vs_oracle"]
+    assert p["rollout_X"] < 1e-5 and p["K_median"] < 1e-5 and p["forward_X_median"] < 1e-5 and p["K_max"] > 1e-3, p
+    assert 0.10 < s["decision_flip_rate"] < 0.40 and s["frac_within_1e5"] < 0.80, s
+    assert so["decision_flip_rate"] < 0.05 and s["decision_flip_rate"] > 3 * so["decision_flip_rate"], (s, so)
+    assert so["frac_within_1e5"] > 0.93, so
+    c5 = fp32_study.study("cfg5", [7] * 14 + [8] * 6, [3] * 14 + [2] * 6, 150, 4, 6000, 100.0, 6, 0)
+    p5, s5 = c5["pass"], c5["solve_fp32_vs_fp64"]
+    assert 1e-4 < p5["K_median"] < 10.0 and p5["forward_X_median"] < 1e-3, p5
+    assert s5["frac_within_1e5"] <= 0.5, s5
+
+
 @pytest.mark.parametrize("model,k,T", [(3, 16, 20), (0, 18, 12), (4, 11, 15), (7, 6, 8), (1, 12, 10)])
 def test_large_cluster_passes_vs_oracle(dp, model, k, T):
     """n_x just beyond the workgroup sweep (64 .. 72) for every state-dimension family: rollout, backward and forward

@@ -152,14 +152,16 @@ def _to_host(r):
 
 
 def test_solve_batch_vs_oracle_all_items(dp):
-    """1024 seeded cfg2 scenarios: HIP solve vs the CPU oracle, EVERY item held to a bound (oracle/parity.py).
+    """1024 seeded cfg2 scenarios: HIP solve vs the CPU oracle, EVERY item held to the envelope of oracle/parity.py through
+    EVERY iteration of its solve -- no class of items is exempt.
 
     A few per cent of these scenarios are chaotic IN THE REFERENCE ITSELF: perturbing x0 by 1e-13 relative changes the
     reference's own iteration count and final cost by 10-20 % (measured with the real reference on seeds 1113, 1161,
-    1163, 1227).  No item is exempted for that: each one must either reproduce the oracle's decision
-    trace with a final-state error bounded by 100 x the oracle's own 1e-13 sensitivity on that item, or differ by a
-    decision that sat within 100 x that sensitivity of equality, with the accepted costs agreeing iteration by iteration
-    up to there; the linear bounds end only at the iteration where the oracle itself has amplified 1e-13 beyond 1e-7."""
+    1163, 1227).  So the oracle is replayed along the GPU's own decisions (it then has numbers for the
+    same iterates, before and after any decision the two take differently) from x0 and from eight perturbed copies of x0;
+    the GPU's accepted cost of every iteration, its final X, U, J must lie within 10 x the spread of that ensemble, and
+    every decision that is not the oracle's own verdict on the same iterate must be one the ensemble does not determine
+    either.  Calibration of the bound: tests/test_parity_envelope.py."""
     from oracle import oracle as orc, parity
     from dpilqr_amd.util import random_setup
     c = cfg2_params(); B = 1024
@@ -173,20 +175,26 @@ def test_solve_batch_vs_oracle_all_items(dp):
     r = _to_host(pb.solve(x0, U0, trace=True))
     proto = orc.Problem(c["model"], c["n_dims"], xf[0], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
     o = orc.solve_batch(proto, x0, xf, U0, trace=True)
-    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, trace=True)
-    rep = parity.report(r, o, op)
+    rep = parity.envelope(r, proto, x0, xf, U0, natural=o)
     sm = rep["summary"]
+    print(sm)
     assert sm["all_ok"], (sm, [f"item {i}: {w}" for i, w in enumerate(rep["why"]) if w][:10])
-    assert sm["identical_decision_trace_frac"] > 0.95 and sm["chaotic_in_oracle_frac"] < 0.15, sm
-    # the items that are neither chaotic nor unstable in the oracle meet the north star's fixed 1e-5 as well
-    plain = rep["same"] & ~rep["unstable"] & (rep["chaotic_from"] < 0)
-    assert plain.mean() > 0.85
+    # the GPU's decisions are the oracle's own on (nearly) every item, and every other one is explained by the ensemble
+    assert sm["identical_decision_trace_frac"] > 0.95, sm
+    # against the oracle on the SAME decision path the north star's fixed 1e-5 holds wherever the reference's own ensemble
+    # stays within 1e-6 (the remaining few per cent are the items on which the reference does not determine its own result)
+    tight = rep["spreadX"] < 1e-6
+    assert tight.mean() > 0.88, sm
+    assert (rep["errX"][tight] < TOL_SOLVE).all() and (rep["errU"][tight] < TOL_SOLVE).all()
+    # identical decisions and a determined result: everything the reference returns agrees with the oracle's own solve
     X, U, J, st = r["X"], r["U"], r["J"], r["status"]
+    plain = ~rep["flipped"] & tight
+    assert plain.mean() > 0.85
     for i in np.where(plain)[0]:
         assert relerr(X[i], o["X"][i]) < TOL_SOLVE and relerr(U[i], o["U"][i]) < TOL_SOLVE, i
         assert abs(J[i] - o["J"][i]) < TOL_SOLVE * abs(o["J"][i])
         assert r["n_fwd"][i] == o["n_fwd"][i] and st[i] == o["status"][i]
-    # every item, chaotic or not: a finished, finite solve that did not increase the cost
+    # every item: a finished, finite solve that did not increase the cost
     J0 = pb.rollout(x0, U0)[1].cpu().numpy()
     assert np.isfinite(X).all() and np.isfinite(U).all() and (st >= 1).all() and (st <= 3).all()
     Jfin = pb.rollout(x0, U)[1].cpu().numpy()
@@ -467,7 +475,7 @@ def test_sweep_twelve_state_family(dp, k):
 def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     """Whole solves of 7..15-agent clusters at the configs' horizons (cfg3: unicycles T = 100, cfg4: quadcopters T = 75) and
     the reference's n_lqr_iter = 50: the workgroup-per-item sweep and the two / three-wavefront line search against the
-    CPU oracle, every item held to the sensitivity-scaled bound of oracle/parity.py."""
+    CPU oracle, every item held to the ensemble envelope of oracle/parity.py."""
     from oracle import oracle as orc, parity
     from dpilqr_amd.util import random_setup
     ns, nc = (6, 3) if model == 4 else (4, 2)
@@ -487,12 +495,11 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     r = _to_host(pb.solve(x0, U0, trace=True))
     proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.5, 0.1, T)
     o = orc.solve_batch(proto, x0, xf, U0, trace=True)
-    op = orc.solve_batch(proto, x0 * (1 + 1e-13), xf, U0, trace=True)
-    rep = parity.report(r, o, op)
+    rep = parity.envelope(r, proto, x0, xf, U0, natural=o)
     assert rep["summary"]["all_ok"], (rep["summary"], [w for w in rep["why"] if w])
-    plain = rep["same"] & ~rep["unstable"] & (rep["chaotic_from"] < 0)
+    plain = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
     # (ten quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the oracle itself on most seeds:
-    # the bound above still holds for every item)
+    # the envelope above still holds for every item, through every iteration)
     assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8)) else 3), rep["summary"]
     for i in np.where(plain)[0]:
         assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i

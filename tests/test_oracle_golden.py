@@ -294,3 +294,30 @@ def test_solve_subproblem_vs_reference(golden):
         pos = idx.index(i)
         assert relerr(r["X"][:, pos * ns:(pos + 1) * ns], z[f"sub_X_{i}"]) < TOL_SOLVE
         assert relerr(r["U"][:, pos * nc:(pos + 1) * nc], z[f"sub_U_{i}"]) < TOL_SOLVE
+
+
+# ---------------------------------------------------------------- the NumPy restatement (bench.py's second CPU baseline)
+@pytest.mark.parametrize("seed", [0, 17, 2])
+def test_numpy_port_solve_cfg2(golden, seed):
+    """oracle/numpy_port.py (the reference's per-step Python structure, restated) against the reference's own solves:
+    decision trace exactly, trajectory to 1e-5."""
+    from oracle import numpy_port
+    z = golden("g4_solves_cfg2"); c = cfg2_params()
+    s = numpy_port.cfg_solver(c["model"], c["n_dims"], z[f"s{seed}_xf"], c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    r = s.solve(z[f"s{seed}_x0"], np.zeros((50, 10)))
+    pre = f"s{seed}_"
+    np.testing.assert_array_equal(r["trace"][:, 0], z[pre + "mu_trace"])
+    np.testing.assert_array_equal(r["trace"][:, 1].astype(int), z[pre + "acc_trace"])
+    assert relerr(r["X"], z[pre + "X"]) < TOL_SOLVE and relerr(r["U"], z[pre + "U"]) < TOL_SOLVE
+    assert abs(r["J"] - z[pre + "J"]) < TOL_SOLVE * abs(z[pre + "J"])
+
+
+@pytest.mark.parametrize("tag", ["uni_k3", "quad_k3", "mixed"])
+def test_numpy_port_solve_misc(golden, tag):
+    from oracle import numpy_port
+    z = golden("g4_solves_misc")
+    g = lambda k: z[tag + "_" + k]
+    s = numpy_port.cfg_solver(g("model"), g("n_dims"), g("xf"), g("Q"), g("R"), g("Qf"), float(g("radius")), float(g("dt")), int(g("T")))
+    r = s.solve(g("x0"), g("U0"))
+    np.testing.assert_array_equal(r["trace"][:, 1].astype(int), g("acc_trace"))
+    assert relerr(r["X"], g("X")) < TOL_SOLVE and relerr(r["U"], g("U")) < TOL_SOLVE
