@@ -11,7 +11,12 @@ GPU) are handed to the solver together, the way a Monte-Carlo driver would, and 
 sub-problems in flight: sub-problems need 1..25 iLQR iterations, so finished ones are retired on the device
 and replaced by not-yet-started ones, and every launch of the hot kernels works on ~6144 sub-problems (two rounds of three sweep wavefronts per SIMD).  All
 K x 1024 solves complete inside the timed region.  For N>1 the region also contains the path's one
-collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) of all ranks.
+collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) of all ranks, issued chunk by chunk
+on a side stream while the rest of the job still solves (dpilqr_amd/sharding.py ResultBuffers; buffers pre-allocated
+and the collective warmed on them outside the clock).
+
+The timed K-step job is REPEATED --reps times (default 5) on disjoint seeds inside one invocation; `value` and
+`ms_per_step` are the MEDIAN repetition (max over ranks each), the spread is reported beside them (`repetitions`).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -52,6 +57,39 @@ BWD_FLOPS = T * (4 * N_X ** 3 + 8 * N_X ** 2 * N_U + 6 * N_X * N_U ** 2 + 2.0 * 
 FP64_PEAK_TFLOPS = 78.6
 
 
+def useful_flops_per_step(n, m, ns, k):
+    """Flops of one Riccati step ON DATA when [A|B] is block diagonal with k blocks of n_s rows (MultiDynamicalModel.linearize,
+    dynamics.py:173-186) -- the products the sweep actually has to form; the dense count above also prices the
+    multiplications by structural zeros, which the kernel (correctly) skips, and so overstates pipe utilisation (round-2
+    advice).  Per step, with the reference's association (control.py:131-146):
+      S1  A^T P, A^T p, B^T (P + mu I), B^T p      n_s terms per output:  2 n_s (n^2 + n + m n + m)
+      S2  (A^T P) A, (B^T P') B, (B^T P') A        n_s terms per output:  2 n_s (n^2 + m^2 + m n)   + n^2 + m^2 + m n adds
+      S3  LU of Q_uu and n + 1 solves:             2/3 m^3 + 2 m^2 (n + 1)
+      S4  K^T Q_uu:                                2 n m^2
+      S5  (K^T Q_uu)[K|d], K^T [Q_ux|Q_u] (its transpose supplies Q_ux^T K, Q_ux^T d):  2 * 2 n m (n + 1)   + 3 n (n + 1) adds
+      S6  P <- (P + P^T)/2:                        2 n^2"""
+    s1 = 2 * ns * (n * n + n + m * n + m)
+    s2 = 2 * ns * (n * n + m * m + m * n) + n * n + m * m + m * n
+    s3 = 2.0 * m ** 3 / 3.0 + 2 * m * m * (n + 1)
+    s4 = 2 * n * m * m
+    s5 = 2 * 2 * n * m * (n + 1) + 3 * n * (n + 1)
+    s6 = 2 * n * n
+    return s1 + s2 + s3 + s4 + s5 + s6
+
+
+BWD_USEFUL_FLOPS = T * useful_flops_per_step(N_X, N_U, N_S, K_AGENTS)     # 1.93 Mflop at cfg2 (dense count: 3.83)
+
+
+def kernel_source_sha16():
+    """Identifies the sweep's source: profiles/riccati_traffic.json (the PMC pass behind roofline.traffic) names the source it
+    was measured on, and a stale file is reported as traffic = null instead of silently describing another kernel."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("riccati_mfma.hpp", "riccati_mfma_lane.inc", "tu_riccati.hip"):
+        h.update((ROOT / "dpilqr_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def scenarios(seed0, B):
     from dpilqr_amd.util import random_setup
     x0 = np.zeros((B, N_X)); xf = np.zeros((B, N_X))
@@ -66,18 +104,46 @@ def scenarios(seed0, B):
 
 
 def cpu_baseline(x0, xf, sample):
-    """The CPU restatement (oracle/, OpenMP over the batch) on the host cores of this box."""
+    """The CPU restatement (oracle/, OpenMP over the batch) on the host cores this process may actually use: the affinity
+    mask capped by the cgroup's CPU quota (the GPU boxes show 256 hardware threads behind a quota of 16 CPUs; 256 OpenMP
+    threads then run throttled at 2.3 k sub-problems/s against 5.2 k with 16 -- profiles/r03_cpu_probe.txt)."""
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0))
+    cores = orc.usable_cores()
     Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
     proto = orc.Problem([0] * K_AGENTS, [2] * K_AGENTS, xf[0], Q, R, Qf, 0.5, 0.1, T)
-    orc.solve_batch(proto, x0[:cores], xf[:cores], np.zeros((cores, T, N_U)), n_threads=cores)  # warm
+    orc.solve_batch(proto, x0[:4 * cores], xf[:4 * cores], np.zeros((4 * cores, T, N_U)), n_threads=cores)  # warm
     t0 = time.perf_counter()
     o = orc.solve_batch(proto, x0[:sample], xf[:sample], np.zeros((sample, T, N_U)), n_threads=cores)
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="subproblems/s", cores=cores, kind="port",
-                sample=f"first {sample} sub-problems of the rank-0 batch, oracle/ilqr_oracle.c with OpenMP on {cores} "
-                       f"threads, {dt:.2f} s wall"), o
+                sample=f"first {sample} sub-problems of the rank-0 job, oracle/ilqr_oracle.c with OpenMP on {cores} threads "
+                       f"(affinity {len(os.sched_getaffinity(0))} hardware threads, cgroup cpu.max "
+                       f"{_read('/sys/fs/cgroup/cpu.max')}), {dt:.2f} s wall = {dt * cores:.0f} core-seconds"), o
+
+
+def cpu_baseline_numpy(x0, xf, o, n=24):
+    """SURVEY 8(d)'s other CPU baseline: the NumPy restatement with the reference's own per-step Python structure
+    (oracle/numpy_port.py, pinned on the reference's golden solves), single process -- the reference's speed class
+    (the reference itself does 6-7.5 sub-problems/s per core in the build container)."""
+    from oracle import numpy_port
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
+    t0 = time.perf_counter()
+    same = 0
+    for i in range(n):
+        r = numpy_port.cfg_solver([0] * K_AGENTS, [2] * K_AGENTS, xf[i], Q, R, Qf, 0.5, 0.1, T).solve(x0[i])
+        same += int(len(r["trace"]) == o["n_bwd"][i])
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="subproblems/s", cores=1, kind="port",
+                sample=f"first {n} sub-problems of the rank-0 job, oracle/numpy_port.py (per-step Python + NumPy + np.linalg.solve, "
+                       f"per-agent dynamics through ctypes), one process, {dt:.2f} s; iteration counts equal to the C port's on "
+                       f"{same}/{n}")
+
+
+def _read(path):
+    try:
+        return Path(path).read_text().strip()
+    except OSError:
+        return "n/a"
 
 
 def main():
@@ -85,8 +151,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step job (disjoint seeds); the median is reported")
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
     ap.add_argument("--window", type=int, default=6144, help="sub-problems in flight per GPU (a multiple of 3072 = three sweep wavefronts per SIMD)")
+    ap.add_argument("--gather-chunk", type=int, default=2048, help="N > 1: items per chunk of the overlapped all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events in the timed run "
                     "(per-kernel breakdown; costs ~4 %% of throughput in dispatch gaps) instead of the Riccati sweep only")
@@ -106,32 +174,36 @@ def main():
 
     import dpilqr_amd
     from dpilqr_amd import _lib
-    from dpilqr_amd.device import to_dev
-    from dpilqr_amd.sharding import gather_results
+    from dpilqr_amd.sharding import ResultBuffers
     _lib.require_gpu()
 
-    B = args.batch
+    B, reps = args.batch, max(1, args.reps)
+    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
 
-    def make_job(n_steps, seed0):
-        """n_steps batches of B scenarios each, resident in HBM; seeds are disjoint across ranks and steps.  The scenarios
-        are generated on the device (dpilqr_random_setup: bit for bit np.random.seed(s); random_setup(...), checked against
-        the reference's own outputs in tests/test_gpu_api.py); the host copies feed the CPU baseline."""
+    def make_job(n_steps, seed0, host=False):
+        """n_steps batches of B scenarios each, resident in HBM; seeds are disjoint across ranks, repetitions and steps.  The
+        scenarios are generated on the device (dpilqr_random_setup: bit for bit np.random.seed(s); random_setup(...), checked
+        against the reference's own outputs in tests/test_gpu_api.py); host copies (rank 0, first job) feed the CPU baseline."""
         from dpilqr_amd.util import random_setup_batch
         x0, xf = random_setup_batch((seed0, n_steps * B), K_AGENTS, N_S, var=K_AGENTS / 2, n_d=2, energy=10.0)
         pb = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, Q, R, Qf, 0.5, 0.1, T)
-        return pb, x0, torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda"), x0.cpu().numpy(), xf.cpu().numpy()
+        U0 = torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda")
+        return dict(pb=pb, x0=x0, U0=U0, x0_h=x0.cpu().numpy() if host else None, xf_h=xf.cpu().numpy() if host else None)
 
-    Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
-    seeds_per_rank = (args.steps + args.warmup) * B
-    job = make_job(args.steps, rank * seeds_per_rank)                     # weak scaling: every rank its own seeds
-    warm = make_job(args.warmup, rank * seeds_per_rank + args.steps * B) if args.warmup > 0 else None
+    seeds_per_rank = (reps * args.steps + args.warmup) * B
+    seed_base = rank * seeds_per_rank                                    # weak scaling: every rank its own seeds
+    jobs = [make_job(args.steps, seed_base + r * args.steps * B, host=(r == 0 and rank == 0)) for r in range(reps)]
+    warm = make_job(args.warmup, seed_base + reps * args.steps * B) if args.warmup > 0 else None
+    # N > 1: the results' home and the gathered results of all ranks, allocated once for the job's shape
+    rb = ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank)) if world > 1 else None
 
-    def run(j):
-        pb, x0, U0 = j[0], j[1], j[2]
-        r = pb.solve(x0, U0, n_lqr_iter=50, tol=1e-3, window=args.window)
-        if world > 1:
-            r = gather_results(r, pad_to=r["J"].shape[0])   # the one collective of the path (equal shards: no count exchange)
-        return r
+    def run(j, gather):
+        if gather is not None:
+            gather.begin()
+            r = j["pb"].solve(j["x0"], j["U0"], n_lqr_iter=50, tol=1e-3, window=args.window, out=gather.out, progress=gather.progress)
+            gather.finish()             # the one collective of the path: what the solve's progress reports did not already send
+            return r
+        return j["pb"].solve(j["x0"], j["U0"], n_lqr_iter=50, tol=1e-3, window=args.window)
 
     def fence():
         torch.cuda.synchronize()
@@ -140,23 +212,33 @@ def main():
         torch.cuda.synchronize()
 
     if warm is not None:
-        run(warm)
+        run(warm, None)                 # W untimed steps: every kernel variant loaded, workspace pool filled
+    if rb is not None:
+        rb.warm()                       # the collective on the timed job's own buffers and message sizes, outside the clock
     _lib.profile_enable(True, classes=None if args.profile_all else ["riccati"]); _lib.profile_read(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    r = run(job)
-    fence()
-    elapsed = time.perf_counter() - t0
+    for w in (12, 8, 4):
+        _lib.profile_read_sweep(w, reset=True)
+    times = []
+    r0 = None
+    for rep in range(reps):
+        fence()
+        t0 = time.perf_counter()
+        r = run(jobs[rep], rb)
+        fence()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        times.append(float(dt.item()))
+        if rep == 0:
+            r0 = {k: v.clone() for k, v in r.items()} if rb is not None else r      # the parity leg looks at repetition 0
+        nb_mean = float(r["n_bwd"].double().mean()); nf_mean = float(r["n_fwd"].double().mean())
+        del r
     prof = _lib.profile_read(reset=True)
     sweep_variants = {w: _lib.profile_read_sweep(w, reset=True) for w in (12, 8, 4)}
     _lib.profile_enable(False)
-    x0_h, xf_h = job[3], job[4]
-    x0 = job[1]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=x0.device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    order = sorted(range(reps), key=lambda i: times[i])
+    elapsed = times[order[(reps - 1) // 2]] if reps % 2 else 0.5 * (times[order[reps // 2 - 1]] + times[order[reps // 2]])
     total_units = B * world * args.steps
     value = total_units / elapsed
 
@@ -173,28 +255,39 @@ def main():
         pass_bytes = FUSED_BYTES if fused else BWD_READ_BYTES + BWD_WRITE_BYTES
         sec = ric["ms"] * 1e-3
         gbs = ric["items"] * pass_bytes / sec / 1e9 if sec > 0 else 0.0
-        tflops = ric["items"] * BWD_FLOPS / sec / 1e12 if sec > 0 else 0.0
+        tflops = ric["items"] * BWD_USEFUL_FLOPS / sec / 1e12 if sec > 0 else 0.0
+        tflops_dense = ric["items"] * BWD_FLOPS / sec / 1e12 if sec > 0 else 0.0
         all_sec = all_ric["ms"] * 1e-3
         all_gbs = all_ric["items"] * pass_bytes / all_sec / 1e9 if all_sec > 0 else 0.0
-        all_tflops = all_ric["items"] * BWD_FLOPS / all_sec / 1e12 if all_sec > 0 else 0.0
-        traffic = None
+        all_tflops = all_ric["items"] * BWD_USEFUL_FLOPS / all_sec / 1e12 if all_sec > 0 else 0.0
+        traffic, traffic_note = None, None
         tf = ROOT / "profiles" / "riccati_traffic.json"   # PMC pass (rocprofv3 --pmc), see profiles/README.md
         if tf.exists() and ric["launches"]:   # measured HBM bytes per sub-problem pass x the items of an average launch
+            tj = json.loads(tf.read_text())
             key = "hbm_bytes_per_subproblem_pass_fused" if fused else "hbm_bytes_per_subproblem_pass"
-            per_pass = json.loads(tf.read_text()).get(key)
-            traffic = per_pass * ric["items"] / ric["launches"] if per_pass else None
+            per_pass = tj.get(key)
+            if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                traffic = per_pass * ric["items"] / ric["launches"] if per_pass else None
+                traffic_note = f"PMC pass on this source ({tj.get('kernel_source_sha16')}), {tj.get('fused', {}).get('source', tj.get('source'))}"
+            else:
+                traffic_note = (f"profiles/riccati_traffic.json was measured on another version of the sweep "
+                                f"({tj.get('kernel_source_sha16')} != {kernel_source_sha16()}): re-run scripts/profile_round.sh")
         launches = max(ric["launches"], 1)
         if fused:
             roofline = {"bound": "fp64", "kernel": kernel_name, "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
-                        "flops_per_subproblem_pass": BWD_FLOPS, "algorithmic_flops_per_launch": ric["items"] * BWD_FLOPS / launches,
+                        "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                        "flops_per_subproblem_pass": BWD_USEFUL_FLOPS, "flops_per_launch": ric["items"] * BWD_USEFUL_FLOPS / launches,
+                        "dense_count": {"flops_per_subproblem_pass": BWD_FLOPS, "achieved": tflops_dense, "frac": tflops_dense / FP64_PEAK_TFLOPS,
+                                        "note": "SURVEY 8(d)'s dense flop count, which also prices the multiplications by the structural zeros of "
+                                                "block-diagonal [A|B] that the kernel skips: an algorithmic figure, not pipe utilisation"},
                         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                 "bytes_per_subproblem_pass": pass_bytes},
-                        "note": "fused sweep: SURVEY 8(d) dense flop count over the kernel's launch time against the fp64 pipe "
-                                "(vector ALU and fp64 MFMA share it); its HBM traffic is the fused byte count"}
+                        "note": "fused sweep: flops on data (block-diagonal [A|B], the reference's association; bench.py "
+                                "useful_flops_per_step) over the kernel's launch time against the fp64 pipe (vector ALU and fp64 MFMA "
+                                "share it); its HBM traffic is the fused byte count"}
         else:
             roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_subproblem_pass": pass_bytes,
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_subproblem_pass": pass_bytes,
                         "algorithmic_bytes_per_launch": ric["items"] * pass_bytes / launches}
         roofline.update({"launches": ric["launches"], "subproblem_passes": ric["items"], "avg_launch_ms": ric["ms"] / launches,
                          "all_sweep_launches": {"launches": all_ric["launches"], "subproblem_passes": all_ric["items"],
@@ -203,71 +296,93 @@ def main():
                                                 "frac": all_tflops / FP64_PEAK_TFLOPS if fused else all_gbs / HBM_PEAK_GBS}})
         # the tiles-through-HBM form of the same sweep (the plugin boundary, and the kernel the north star's "40 % of the HBM
         # roofline" refers to): one full window of this job's final iterates, records made once, the sweep timed alone
-        nw = min(args.window, r["X"].shape[0])
-        pbw = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, job[4][:nw], Q, R, Qf, 0.5, 0.1, T)
-        tiles_w = pbw.make_tiles(r["X"][:nw], r["U"][:nw])
+        j0 = jobs[0]
+        nw = min(args.window, r0["X"].shape[0])
+        pbw = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, j0["pb"]._xf[:nw], Q, R, Qf, 0.5, 0.1, T)
+        tiles_w = pbw.make_tiles(r0["X"][:nw], r0["U"][:nw])
         mu_w = torch.full((nw,), 0.125, dtype=torch.float64, device="cuda")
-        reps = 5
+        sweep_reps = 7
         dpilqr_amd.backward_pass_tiles(tiles_w, nw, T, N_X, N_U, mu_w, blocks=(N_S, N_C))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(reps):
+        ms_list = []
+        for _ in range(sweep_reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
             dpilqr_amd.backward_pass_tiles(tiles_w, nw, T, N_X, N_U, mu_w, blocks=(N_S, N_C))
-        e1.record(); torch.cuda.synchronize()
-        ms_t = e0.elapsed_time(e1) / reps
+            e1.record(); torch.cuda.synchronize()
+            ms_list.append(e0.elapsed_time(e1))
+        ms_t = float(np.median(ms_list))
         gbs_t = nw * (BWD_READ_BYTES + BWD_WRITE_BYTES) / (ms_t * 1e-3) / 1e9
+        gbs_r = nw * BWD_READ_BYTES / (ms_t * 1e-3) / 1e9
         tiled = {"bound": "hbm", "kernel": f"k_riccati_mfma<{N_X},{N_U},{12 if nw > 2048 else (8 if nw > 1024 else 4)},4,2,false>",
-                 "achieved": gbs_t, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_t / HBM_PEAK_GBS, "items": nw,
-                 "launch_ms": ms_t, "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
-                 "note": "record-fed sweep (dpilqr_backward_pass_tiles_blocks) on one window of this job's final iterates, "
-                         "timed alone after the timed region"}
+                 "achieved": gbs_t, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_t / HBM_PEAK_GBS,
+                 "read_only": {"achieved": gbs_r, "frac": gbs_r / HBM_PEAK_GBS, "bytes_per_subproblem_pass": BWD_READ_BYTES,
+                               "note": "the north star's '>= 40 % HBM-read roofline' counts the tile reads alone"},
+                 "items": nw, "launch_ms": ms_t, "launch_ms_min_max": [min(ms_list), max(ms_list)],
+                 "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
+                 "note": f"record-fed sweep (dpilqr_backward_pass_tiles_blocks) on one window of this job's final iterates, "
+                         f"timed alone after the timed region, median of {sweep_reps} launches"}
         del tiles_w
-        nb = r["n_bwd"].cpu().numpy(); nf = r["n_fwd"].cpu().numpy(); st = r["status"].cpu().numpy()
+        # BASELINE configs[1] read literally: ONE batch of 1024 sub-problems solved on its own (latency of a single batch)
+        pb1 = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, j0["pb"]._xf[:B], Q, R, Qf, 0.5, 0.1, T)
+        x1, U1 = j0["x0"][:B], j0["U0"][:B]
+        pb1.solve(x1, U1, window=B)
+        t1 = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r1 = pb1.solve(x1, U1, window=B)
+            torch.cuda.synchronize(); t1.append(time.perf_counter() - t0)
+        single = {"items": B, "ms": float(np.median(t1)) * 1e3, "ms_min_max": [min(t1) * 1e3, max(t1) * 1e3],
+                  "subproblems_per_s": B / float(np.median(t1)), "global_iterations": int(r1["n_bwd"].max().item()),
+                  "note": "one 1024-item batch solved alone (median of 5): bounded by the batch's longest item, "
+                          "max(n_bwd) dependent iterations of one sweep + one line search each"}
+        nb = r0["n_bwd"].cpu().numpy(); nf = r0["n_fwd"].cpu().numpy(); st = r0["status"].cpu().numpy()
         out = {
             "metric": "ilqr_subproblems_per_sec", "value": value, "unit": "subproblems/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repetitions": {"n": reps, "statistic": "median", "ms_per_step": [t / args.steps * 1e3 for t in times],
+                            "value_min_max": [total_units / max(times), total_units / min(times)]},
             "config": {"workload": f"cfg2: batches of {B} independent 5-agent DoubleIntDynamics4D iLQR sub-problems per GPU "
                                    "per step, T=50, scripts/analysis.py scenario distribution, tol=1e-3, n_lqr_iter=50; "
-                                   f"{args.steps} steps = {args.steps * B} distinct seeds per GPU, window of {args.window} in flight",
+                                   f"{args.steps} steps = {args.steps * B} distinct seeds per GPU, window of {args.window} in flight; "
+                                   f"the job is repeated {reps} times on disjoint seeds and the median is reported",
                        "batch_per_gpu": B, "window": args.window, "n_x": N_X, "n_u": N_U, "horizon": T,
                        "mean_backward_passes": float(nb.mean()), "mean_forward_passes": float(nf.mean()),
                        "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
-                       "parallelism": f"batch-sharded x{world}, one all-gather" if world > 1 else "single GPU"},
-            "roofline": roofline, "roofline_tiles_through_hbm": tiled,
-            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+                       "parallelism": (f"batch-sharded x{world}, one all-gather in chunks of {args.gather_chunk} items overlapped with the solve"
+                                       if world > 1 else "single GPU")},
+            "roofline": roofline, "roofline_tiles_through_hbm": tiled, "single_batch_1024": single,
+            "kernel_ms_per_step": {k: v["ms"] / (args.steps * reps) for k, v in prof.items() if v["launches"]},
         }
         if world == 1 and not args.no_cpu_baseline:
+            x0_h, xf_h = j0["x0_h"], j0["xf_h"]
             ns = min(args.cpu_sample, x0_h.shape[0])
             out["cpu_baseline"], o = cpu_baseline(x0_h, xf_h, ns)
-            # The oracle's solves of the same items double as a live parity check of this very run (untimed).  About
-            # 2-4 % of cfg2 scenarios are ill-conditioned IN THE REFERENCE ITSELF: the check
-            # classifies a sub-sample by the oracle's own sensitivity to a 1e-13 relative perturbation of x0.
-            # every item of a sub-sample is held to the sensitivity-scaled bound of oracle/parity.py (no item is exempt):
-            # an untimed GPU solve of the same items with the decision trace switched on (bit-identical to the timed one:
-            # scheduling does not change an item's arithmetic), the oracle with traces, and the oracle from x0 (1 + 1e-13)
+            out["cpu_baseline_numpy"] = cpu_baseline_numpy(x0_h, xf_h, o)
+            # The oracle doubles as a live parity check of this very run (untimed): every item of a sub-sample is held to the
+            # ensemble envelope of oracle/parity.py -- an untimed GPU solve of the same items with the decision trace
+            # switched on (bit-identical to the timed one: scheduling does not change an item's arithmetic), the oracle
+            # replayed along the GPU's decisions from x0 and from eight perturbed copies of x0 -- nothing is exempt
             from oracle import oracle as orc, parity
             nc = min(ns, 2048)
-            cores = out["cpu_baseline"]["cores"]
             pbs = dpilqr_amd.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf_h[:nc], Q, R, Qf, 0.5, 0.1, T)
             g = {k_: v.cpu().numpy() for k_, v in pbs.solve(x0_h[:nc], np.zeros((nc, T, N_U)), trace=True, window=args.window).items()}
-            assert np.array_equal(g["X"], r["X"][:nc].cpu().numpy()), "traced re-solve differs from the timed solve"
+            assert np.array_equal(g["X"], r0["X"][:nc].cpu().numpy()), "traced re-solve differs from the timed solve"
             proto = orc.Problem([0] * K_AGENTS, [2] * K_AGENTS, xf_h[0], Q, R, Qf, 0.5, 0.1, T)
-            oo = orc.solve_batch(proto, x0_h[:nc], xf_h[:nc], np.zeros((nc, T, N_U)), n_threads=cores, trace=True)
-            op = orc.solve_batch(proto, x0_h[:nc] * (1 + 1e-13), xf_h[:nc], np.zeros((nc, T, N_U)), n_threads=cores, trace=True)
-            rep = parity.report(g, oo, op)
-            Xg = r["X"][:ns].cpu().numpy()
+            on = {k_: v[:nc] for k_, v in o.items()}
+            rep = parity.envelope(g, proto, x0_h[:nc], xf_h[:nc], np.zeros((nc, T, N_U)), natural=on)
+            Xg = r0["X"][:ns].cpu().numpy()
             err = np.abs(Xg - o["X"]).reshape(ns, -1).max(axis=1) / np.maximum(np.abs(o["X"]).reshape(ns, -1).max(axis=1), 1e-300)
             same_trace = (nb[:ns] == o["n_bwd"]) & (nf[:ns] == o["n_fwd"]) & (st[:ns] == o["status"])
             out["parity_vs_oracle"] = {
                 "items": int(ns), "identical_decision_trace_frac": float(same_trace.mean()),
                 "states_within_1e-5_frac": float((err < 1e-5).mean()),
-                "all_items_bound": dict(rep["summary"], violating_items=[int(i) for i in np.where(~rep["ok"])[0][:8]],
-                                        reasons=[w for w in rep["why"] if w][:4]),
-                "note": "all_items_bound: every item of the first 2048 is held to oracle/parity.py -- identical decisions with a "
-                        "final-state error <= 100 x the oracle's own movement under a 1e-13 perturbation of x0, or a decision flip "
-                        "that sat within 100 x that sensitivity of equality, accepted costs agreeing iteration by iteration; the "
-                        "linear bounds end where the oracle itself has amplified 1e-13 beyond 1e-7 (chaotic_in_oracle_frac)"}
+                "all_items_envelope": dict(rep["summary"], violating_items=[int(i) for i in np.where(~rep["ok"])[0][:8]],
+                                           reasons=[w for w in rep["why"] if w][:4]),
+                "note": "all_items_envelope: every item of the first 2048, through every iteration of its solve, against the oracle "
+                        "replayed along the GPU's own decisions from x0 and from 8 perturbed copies of x0 (+-1e-13..5e-13): accepted costs, "
+                        "final X, U, J within 10 x the ensemble's spread, every decision that is not the oracle's own verdict on the "
+                        "same iterate undetermined in the ensemble too (oracle/parity.py; calibrated in tests/test_parity_envelope.py)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

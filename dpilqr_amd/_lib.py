@@ -56,6 +56,7 @@ SIGNATURES = {
     "dpilqr_solve_workspace_bytes": (i64, [_DP, i32, i32]),
     "dpilqr_solver_create": (i32, [C.POINTER(vp)]),
     "dpilqr_solver_destroy": (i32, [vp]),
+    "dpilqr_solver_set_progress": (i32, [vp, vp, vp]),
     "dpilqr_solve_batch": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_solve_enqueue": (i32, [_DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "dpilqr_solve_iterations_bound": (i64, [_DP, i32, i32]),
@@ -168,11 +169,42 @@ def solver():
     table = getattr(_solvers, "table", None)
     if table is None:
         table = _solvers.table = {}
+        import atexit
+        atexit.register(_destroy_solvers, table)     # the pinned mailbox and events of this thread's solvers
     if dev not in table:
         h = vp()
         check(load().dpilqr_solver_create(C.byref(h)))
         table[dev] = h
     return table[dev]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, vp, i32, i32)
+
+
+class progress_callback:
+    """with progress_callback(fn): ... -- fn(n_finished, n_items) is called from inside this thread's synchronous solves as
+    a prefix of the batch finishes (dpilqr_solver_set_progress)."""
+
+    def __init__(self, fn):
+        self._c = PROGRESS_FN(lambda user, done, total: fn(int(done), int(total))) if fn is not None else None
+
+    def __enter__(self):
+        if self._c is not None:
+            check(load().dpilqr_solver_set_progress(solver(), C.cast(self._c, vp), None))
+        return self
+
+    def __exit__(self, *exc):
+        if self._c is not None:
+            check(load().dpilqr_solver_set_progress(solver(), None, None))
+        return False
+
+
+def _destroy_solvers(table):
+    lib = _lib
+    if lib is not None:
+        for h in table.values():
+            lib.dpilqr_solver_destroy(h)
+    table.clear()
 
 
 _device_ok = None

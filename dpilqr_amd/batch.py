@@ -300,19 +300,32 @@ class ProblemBatch:
         floor = 256 if (self.fused_sweep or dtype != torch.float64) else 1024
         return int(min(self.B, 6144, max(floor, (4 << 30) // max(per_item, 1))))
 
-    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64):
+    def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64, out=None,
+              progress=None):
         """ilqrSolver.solve (control.py:150-225) for all B items.
 
         window: most items in flight at once (default: default_window()); finished items are retired on the device and
         replaced by not-yet-started ones, so launches stay full and memory is bounded.
+        out: dict of pre-allocated device tensors X (B,T+1,n_x), U (B,T,n_u), J (B,), status, n_bwd, n_fwd (B,) int32 to
+        write the results into (sharding.ResultBuffers: the solve then writes straight into the collective's send buffer).
+        progress: callable(n_finished, n_items), called from inside the solve as a PREFIX of the batch finishes (X, U,
+        status, n_bwd, n_fwd of items below n_finished are final; see dpilqr_solver_set_progress).
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
         window = self.default_window(dtype) if window is None else int(window)
         x0 = self._in(x0, (B, n), dtype)
-        U = self._in(U0, (B, T, m), dtype).clone()
-        X = empty((B, T + 1, n), dtype); J = empty((B,))
-        status = empty((B,), torch.int32); n_bwd = empty((B,), torch.int32); n_fwd = empty((B,), torch.int32)
+        if out is not None:
+            U = out["U"]; U.copy_(self._in(U0, (B, T, m), dtype))
+            X, J, status, n_bwd, n_fwd = out["X"], out["J"], out["status"], out["n_bwd"], out["n_fwd"]
+            for t_, shp, dt_ in ((X, (B, T + 1, n), dtype), (U, (B, T, m), dtype), (J, (B,), torch.float64),
+                                 (status, (B,), torch.int32), (n_bwd, (B,), torch.int32), (n_fwd, (B,), torch.int32)):
+                if tuple(t_.shape) != shp or t_.dtype != dt_ or not t_.is_contiguous():
+                    raise ValueError(f"out tensor of shape {tuple(t_.shape)} / {t_.dtype}: expected contiguous {shp} {dt_}")
+        else:
+            U = self._in(U0, (B, T, m), dtype).clone()
+            X = empty((B, T + 1, n), dtype); J = empty((B,))
+            status = empty((B,), torch.int32); n_bwd = empty((B,), torch.int32); n_fwd = empty((B,), torch.int32)
         tr = torch.full((B, max(n_lqr_iter, 1), 5), float("nan"), dtype=torch.float64, device=device()) if trace else None
         K = empty((B, T, m, n), dtype) if gains else None
         d = empty((B, T, m), dtype) if gains else None
@@ -320,8 +333,9 @@ class ProblemBatch:
         fn = self._lib.dpilqr_solve_batch if dtype == torch.float64 else self._lib.dpilqr_solve_batch_f32
         ok = False
         try:
-            _lib.check(fn(_lib.solver(), self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws), ws.numel(),
-                          ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd), ptr(tr), ptr(K), ptr(d), stream_handle()))
+            with _lib.progress_callback(progress):
+                _lib.check(fn(_lib.solver(), self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws), ws.numel(),
+                              ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd), ptr(tr), ptr(K), ptr(d), stream_handle()))
             ok = True
         finally:
             if ok:

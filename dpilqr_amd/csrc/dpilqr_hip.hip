@@ -95,15 +95,26 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
 // Admission, decided on the device where the exact number of survivors is known: behind the survivors
 // that the previous iteration's line search pushed, append as many not-yet-started items as fit in the
 // window, and clear the counter the NEXT iteration will push into.  ctl = {count, admitted} mailbox copy.
+// mail[2] = the finished PREFIX: items are admitted in index order, so every item below the smallest index still on the
+// list has finished and its results are final in memory (the progress callback of dpilqr_solver_set_progress).
 __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window,
                         int32_t* mail) {
     const int base = *count, first = *admitted;
     const int n_new = min(B - first, window - base);
+    __shared__ int lowest;
+    if (threadIdx.x == 0) lowest = first;
     __syncthreads();
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
+    if (mail) {
+        int lo = first;
+        for (int i = threadIdx.x; i < base; i += blockDim.x) lo = min(lo, list[i]);
+        for (int off = 32; off > 0; off >>= 1) lo = min(lo, __shfl_down(lo, off));
+        if ((threadIdx.x & 63) == 0) atomicMin(&lowest, lo);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         *count = base + n_new; *admitted = first + n_new; *next_count = 0;
-        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; }   // pinned host memory: the host reads it after the event
+        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; mail[2] = lowest; }   // pinned host memory: the host reads it after the event
     }
 }
 
@@ -161,7 +172,7 @@ int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || w
 // The host reads the device-side counters kHostLag iterations late: that many iterations of launches are always
 // queued behind the one the GPU is running, so a host thread that loses its core for a millisecond (a loaded box)
 // does not leave the GPU idle.  The price is kHostLag empty iterations (a dozen tiny launches) at the end of a solve.
-constexpr int kHostLag = 3, kMailRing = kHostLag + 1;
+constexpr int kHostLag = 3, kMailRing = kHostLag + 1, kMailWords = 4;   // {active, admitted, finished prefix, -}
 
 // opt-in per-kernel timing (dpilqr_profile_*): event pairs recorded on the solve's own stream
 struct Profiler {
@@ -235,9 +246,11 @@ struct dpilqr_solver {
     std::vector<int32_t> hist;   // exact active-list length of every global iteration of the last solve
     hipEvent_t ev[kMailRing] = {};
     Profiler prof;
+    dpilqr_progress_fn progress = nullptr;   // dpilqr_solver_set_progress
+    void* progress_user = nullptr;
     int32_t init() {
         HIP_TRY(hipGetDevice(&device));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(int32_t) * 2 * kMailRing, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), sizeof(int32_t) * kMailWords * kMailRing, hipHostMallocDefault));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0));
         for (auto& e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return DPILQR_OK;
@@ -425,7 +438,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         int32_t* cur = lists + (size_t)(it & 1) * Wn;
         int32_t* cur_n = counts + (it % kCountRing);
         int32_t* nxt_n = counts + ((it + 1) % kCountRing);
-        int32_t* mail = solver ? solver->dev + 2 * (it % kMailRing) : nullptr;
+        int32_t* mail = solver ? solver->dev + kMailWords * (it % kMailRing) : nullptr;
         hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail);
         if (solver) HIP_TRY(hipEventRecord(solver->ev[it % kMailRing], st));
         S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
@@ -465,6 +478,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         // the host reads {active, admitted} kHostLag iterations late -- that many iterations of launches are always
         // queued while it waits -- to learn when everything has been started and nothing is left active
         int upper = Wn;
+        int32_t reported = 0;
         for (int it = 0; it < kMaxGlobalIter; ++it) {
             n_iterations = (size_t)it + 1;
             if ((rc = enqueue_iteration(it, upper))) return bail(rc);
@@ -472,8 +486,12 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
             if (it >= kHostLag) {  // {active, admitted} of iteration it - kHostLag
                 const int slot = (it - kHostLag) % kMailRing;
                 if (hipEventSynchronize(solver->ev[slot]) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipEventSynchronize failed"));
-                const int32_t act = solver->host[2 * slot], adm = solver->host[2 * slot + 1];
+                const int32_t act = solver->host[kMailWords * slot], adm = solver->host[kMailWords * slot + 1];
+                const int32_t prefix = solver->host[kMailWords * slot + 2];
                 solver->hist.push_back(act);
+                // items below `prefix` had finished when that iteration began, and the event says its launches have been
+                // reached: their results are final in memory -- the caller may start moving them (on another stream)
+                if (solver->progress && prefix > reported) { reported = prefix; solver->progress(solver->progress_user, prefix, D.B); }
                 // everything started and the list already empty back then: the iterations since were no-ops
                 done = (adm >= D.B && act == 0);
                 // once everything is admitted the list can only shrink: tighten the grid
@@ -495,9 +513,10 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(DPILQR_EHIP, "hipStreamSynchronize failed"));
     if (n_lqr_iter > 0) {
         // the last iterations' exact lengths were posted but not yet consumed
-        for (size_t j = solver->hist.size(); j < n_iterations; ++j) solver->hist.push_back(solver->host[2 * (j % kMailRing)]);
+        for (size_t j = solver->hist.size(); j < n_iterations; ++j) solver->hist.push_back(solver->host[kMailWords * (j % kMailRing)]);
     }
     prof.collect(solver->hist, D.B);
+    if (solver->progress) solver->progress(solver->progress_user, D.B, D.B);   // the stream has been waited for: everything is final
     return DPILQR_OK;
 }
 
@@ -718,6 +737,15 @@ int32_t dpilqr_solver_create(dpilqr_solver** out) {
 }
 int32_t dpilqr_solver_destroy(dpilqr_solver* solver) {
     delete solver;
+    return DPILQR_OK;
+}
+int32_t dpilqr_solver_set_progress(dpilqr_solver* solver, dpilqr_progress_fn fn, void* user) {
+    if (!solver) {
+        const int32_t rc = default_solver(&solver);
+        if (rc) return rc;
+    }
+    solver->progress = fn;
+    solver->progress_user = user;
     return DPILQR_OK;
 }
 

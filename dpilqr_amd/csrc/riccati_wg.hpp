@@ -148,6 +148,50 @@ __device__ __forceinline__ void st_row(double* p, const double* v) {
 }
 
 
+// S3's fall-back (and, where gj_blocked is not used, S3 itself): LU with LAPACK-order partial pivoting in registers.  Lanes
+// 0..M-1 hold Q_uu's columns, lanes M..63 this wavefront's right-hand sides; [K|d] columns of this wavefront -> sK.
+// Returns bit 0: an exactly zero pivot; bit 1: the search-free elimination ran (strictly column-dominant Q_uu); bit 2: partial
+// pivoting moved a row.  NOT inlined (see the call).
+template <int M, int N, int NP, int MO, int LG, int LK, int RW>
+__device__ __attribute__((noinline)) int lu_fallback_wg(const double* __restrict__ sG, double* __restrict__ sK, int wave, int lane) {
+    int sing = 0;
+    const int s3_q = RW * wave + (lane - M);
+    const bool s3_rhs = lane >= M && s3_q < NP;
+    const int s3_col = lane < M ? lane : MO + min(max(s3_q, 0), N);
+    double v[M], invd[1];   // the reciprocal pivots are recomputed in the substitution: 2 m registers less
+#pragma unroll
+    for (int r = 0; r < M; ++r) v[r] = sG[r * LG + s3_col];
+    // strictly column-dominant Q_uu: no row moves, the elimination runs without the pivot search
+    // (see S3 of k_riccati_mfma for the argument and the margin)
+    double colsum = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) colsum = colsum + fabs(v[r]);
+    const double dg = fabs(sG[min(lane, M - 1) * (LG + 1)]);
+    const bool dominant = lane >= M || dg * (1.0 - 0x1p-20) > colsum - dg;
+    const bool no_swaps = __builtin_amdgcn_ballot_w64(!dominant) == 0ull;
+    int n_swaps = 0;
+    if (no_swaps) lu_eliminate<false, M, false, false>(v, invd, sing);
+    else lu_eliminate<true, M, false, false>(v, invd, sing, &n_swaps);
+#pragma unroll
+    for (int r = M - 1; r >= 0; --r) {
+        double s = v[r];
+#pragma unroll
+        for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
+        const double pv = readlane_f64(v[r], r);   // U's diagonal: the pivot of step r
+        double inv = __builtin_amdgcn_rcp(pv);
+        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+        v[r] = s * inv;
+    }
+    if (s3_rhs) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) sK[a * LK + s3_q] = -v[a];
+    }
+    return (sing ? 1 : 0) | (no_swaps ? 2 : 0) | (n_swaps > 0 ? 4 : 0);
+}
+
+
+
 // S3 by blocks: [K | d] = -Q_uu^-1 [Q_ux | Q_u] by Gauss-Jordan elimination on 4-column panels, the row operations of a panel
 // applied to everything to its right as ONE fp64 MFMA per 16 x 16 tile.
 //
@@ -751,45 +795,15 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         }
         if (lu_needed) {
             WG_LANE_TERMS()
-            const int s3_q = RW * wave + (lane - M);
-            const bool s3_rhs = lane >= M && s3_q < NP;
-            const int s3_col = lane < M ? lane : MO + min(max(s3_q, 0), N);
-            double v[M], invd[1];   // the reciprocal pivots are recomputed in the substitution: 2 m registers less
-#pragma unroll
-            for (int r = 0; r < M; ++r) v[r] = sG[r * LG + s3_col];
-            // strictly column-dominant Q_uu: no row moves, the elimination runs without the pivot search
-            // (see S3 of k_riccati_mfma for the argument and the margin)
-            double colsum = 0.0;
-#pragma unroll
-            for (int r = 0; r < M; ++r) colsum = colsum + fabs(v[r]);
-            const double dg = fabs(sG[min(lane, M - 1) * (LG + 1)]);
-            const bool dominant = lane >= M || dg * (1.0 - 0x1p-20) > colsum - dg;
-            const bool no_swaps = __builtin_amdgcn_ballot_w64(!dominant) == 0ull;
+            // out of line: the register LU holds m columns + its broadcasts (250 registers, hundreds of scalar temporaries at
+            // m = 30) and, where the blocked elimination serves the size, runs on a few per cent of the steps only -- inlined
+            // it set the register allocation of the whole kernel (round 2: every fused instantiation spilled)
+            const int flags = lu_fallback_wg<M, N, NP, MO, LG, LK, RW>(sG, sK, wave, lane);
+            if (flags & 1) sing = 1;
 #ifdef DPILQR_PHASE_STAMPS
-            if (!C::GJ && no_swaps) ph[6] += 1000;   // diagnostic: share of the steps with the search-free elimination
-            int n_swaps = 0;
-            if (no_swaps) lu_eliminate<false, M, false, false>(v, invd, sing);
-            else lu_eliminate<true, M, false, false>(v, invd, sing, &n_swaps);
-            if (n_swaps > 0) ph[7] += 1000;   // ... and of the steps in which partial pivoting moved a row
-#else
-            if (no_swaps) lu_eliminate<false, M, false, false>(v, invd, sing);
-            else lu_eliminate<true, M, false, false>(v, invd, sing);
+            if (!C::GJ && (flags & 2)) ph[6] += 1000;   // diagnostic: share of the steps with the search-free elimination
+            if (flags & 4) ph[7] += 1000;               // ... and of the steps in which partial pivoting moved a row
 #endif
-#pragma unroll
-            for (int r = M - 1; r >= 0; --r) {
-                double s = v[r];
-#pragma unroll
-                for (int c = r + 1; c < M; ++c) s = fma(-readlane_f64(v[r], c), v[c], s);
-                const double pv = readlane_f64(v[r], r);   // U's diagonal: the pivot of step r
-                double inv = __builtin_amdgcn_rcp(pv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                v[r] = s * inv;
-            }
-            if (s3_rhs) {
-#pragma unroll
-                for (int a = 0; a < M; ++a) sK[a * LK + s3_q] = -v[a];
-            }
         }
         wg_barrier();
         {

@@ -37,6 +37,10 @@ int32_t dpilqr_dispatch_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, cons
     }
     const int64_t n = (int64_t)S * k;
     const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    {   // (k + 1) x kSortThreads counters: above 64 KiB at k = 64 -- ask for it before anything of this call is queued
+        const int32_t rc_lds = allow_lds(k_bucket_sort, sizeof(int32_t) * (k + 1) * kSortThreads);
+        if (rc_lds) return rc_lds;
+    }
     hipLaunchKernelGGL(k_graph_bits, grid, block, 0, st, S, N, k, n_s, X, radius, radius_stride,
                        reinterpret_cast<unsigned long long*>(bits));
     hipLaunchKernelGGL(k_dedup, grid, block, 0, st, S, k, reinterpret_cast<const unsigned long long*>(bits), ignore, rep, size);

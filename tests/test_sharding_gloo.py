@@ -160,3 +160,58 @@ def test_bench_gather_path_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _chunked_worker(rank, world, port, B, chunk, q):
+    """ResultBuffers: the chunked, overlapped form of the one collective.  Each rank 'solves' by filling its send side item
+    by item and reporting a growing finished prefix at its own pace (different per rank), exactly as the solve's progress
+    callback does; two jobs in a row reuse the buffers."""
+    from dpilqr_amd.sharding import ResultBuffers
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, n, m = 4, 6, 3
+    rb = ResultBuffers(B, T, n, m, chunk=chunk)
+    rb.warm()
+    ok = True
+    for job in range(2):
+        rb.begin()
+        base = 1000.0 * job + 100.0 * rank
+        steps = [B // 3, B // 3, B - 1, B] if rank % 2 == 0 else [1, B // 2, B]      # ranks report at different paces
+        done = 0
+        for upto in steps:
+            for i in range(done, upto):
+                rb.out["X"][i] = base + i; rb.out["U"][i] = -(base + i)
+                rb.out["status"][i] = 1 + (i % 3); rb.out["n_bwd"][i] = i; rb.out["n_fwd"][i] = 2 * i
+            done = max(done, upto)
+            if upto < B:
+                rb.progress(done, B)
+        rb.out["J"][:] = torch.arange(B, dtype=torch.float64) + base      # J is written when the solve ends
+        rb.finish()
+        g = rb.results()
+        for r in range(world):
+            b = 1000.0 * job + 100.0 * r
+            idx = torch.arange(B, dtype=torch.float64)
+            ok &= torch.equal(g["X"][r, :, 0, 0], idx + b) and torch.equal(g["X"][r, :, T, n - 1], idx + b)
+            ok &= torch.equal(g["U"][r, :, T - 1, m - 1], -(idx + b)) and torch.equal(g["J"][r], idx + b)
+            ok &= torch.equal(g["n_fwd"][r], (2 * torch.arange(B)).to(torch.int32))
+            ok &= torch.equal(g["status"][r], (1 + torch.arange(B) % 3).to(torch.int32))
+        ok &= tuple(g["X"].shape) == (world, B, T + 1, n)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,chunk", [(2, 12, 4), (3, 10, 4), (2, 7, None), (3, 5, 8)])
+def test_chunked_overlapped_gather(world, B, chunk):
+    """world 2 and 3; B a multiple of the chunk, ragged last chunk, one chunk (chunk=None), chunk larger than the batch."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, B, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
