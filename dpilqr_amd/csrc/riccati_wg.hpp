@@ -148,6 +148,27 @@ __device__ __forceinline__ void st_row(double* p, const double* v) {
 }
 
 
+// FUSED S0, one lane per agent: MultiDynamicalModel.linearize's per-agent call (dynamics.py:173-186) -> the agent's rows of
+// [A_blk | B_blk] in LDS.  (Measured out of line as well -- the run-time model switch carries the sincos / tan expansions of
+// several models -- with no effect on the kernel's register allocation and a per cent or two of launch time lost to the call.)
+template <int NS, int NC, int NSCP>
+__device__ __forceinline__ void wg_linearize_agent(int model, const double* __restrict__ sx, const double* __restrict__ su,
+                                                             double dt, double* __restrict__ sab) {
+    double x[NS], u[NC], A[NS * NS], Bm[NS * NC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) x[i] = sx[i];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) u[i] = su[i];
+    linearize_rt<NS>(model, x, u, dt, A, Bm);
+#pragma unroll
+    for (int l = 0; l < NS; ++l) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) sab[l * NSCP + c] = A[l * NS + c];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sab[l * NSCP + NS + c] = Bm[l * NC + c];
+    }
+}
+
 // S3's fall-back (and, where gj_blocked is not used, S3 itself): LU with LAPACK-order partial pivoting in registers.  Lanes
 // 0..M-1 hold Q_uu's columns, lanes M..63 this wavefront's right-hand sides; [K|d] columns of this wavefront -> sK.
 // Returns bit 0: an exactly zero pivot; bit 1: the search-free elimination ran (strictly column-dominant Q_uu); bit 2: partial
@@ -341,7 +362,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
     const int b = items ? items[slot] : slot;
     if (b >= B) return;
     const int64_t gslot = gains_by_item ? b : slot;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tid_k = tid;
     const TileLayout L(N, M);
     // The lane terms of a phase (tile coordinates, LDS addresses) are recomputed at the phase's start from a thread id the
     // optimiser cannot see through: hoisted out of the horizon loop they would occupy well over a hundred registers,
@@ -408,19 +429,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
     auto fused_derive = [&](bool terminal) {
         if (tid < KA) {
             if (!terminal) {
-                double x[NS], u[NC], A[NS * NS], Bm[NS * NC];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) x[i] = sFx[tid * NS + i];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) u[i] = sFu[tid * NC + i];
-                linearize_rt<NS>(f_model, x, u, F.D.dt, A, Bm);
-#pragma unroll
-                for (int l = 0; l < NS; ++l) {
-#pragma unroll
-                    for (int c = 0; c < NS; ++c) sAB[(NS * tid + l) * NSCP + c] = A[l * NS + c];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) sAB[(NS * tid + l) * NSCP + NS + c] = Bm[l * NC + c];
-                }
+                wg_linearize_agent<NS, NC, NSCP>(f_model, sFx + tid * NS, sFu + tid * NC, F.D.dt, sAB + NS * tid * NSCP);
             }
         } else if (tid >= 64 && tid - 64 < C::NPR) {
             const int p = tid - 64;
@@ -434,7 +443,11 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         wg_barrier();
         if (KA > 1) {
             // per agent: the sums over its pairs, in combinations order (a serial chain of adds, as in the producer; the
-            // loads are all issued first)
+            // loads are all issued first).  The lane's pair addresses and signs are formed HERE from a thread id the
+            // optimiser cannot see through: as loop invariants of the horizon loop they were 2 k_a addresses + k_a masks per
+            // lane, computed once and spilled (round 2: 30-50 spilled registers in every fused instantiation)
+            int tid = tid_k;
+            asm volatile("" : "+v"(tid));
             if (tid < 9 * KA) {
                 const int a = tid / 9, c = tid - 9 * a;
                 double h[KA];

@@ -53,8 +53,12 @@ for k in ks:
     tiles = pb.make_tiles(X, U)
     t_t = timeit(lambda: pb.make_tiles(X, U, tiles))
     t_s = timeit(lambda: backward_pass_tiles(tiles, B, T, n, m, mu, blocks=(ns, nc)))
+    try:       # the record-free form the solve loop uses (k_riccati_wg<..., FUSED = true>)
+        t_f = timeit(lambda: pb.backward_pass_fused(X, U, mu))
+    except Exception:
+        t_f = float("nan")
     flops = T * (4.0 * n ** 3 + 8.0 * n * n * m + 6.0 * n * m * m + 2.0 * m ** 3 / 3.0)
     rec = 8.0 * (T + 1) * (2 * n * n + 2 * n * m + m * m + n + m)
-    print(f"{args.model} k={k:2d} n_x={n:2d} n_u={m:2d} B={B}: make_tiles {t_t * 1e3:7.2f} ms | sweep {t_s * 1e3:7.2f} ms = "
+    print(f"{args.model} k={k:2d} n_x={n:2d} n_u={m:2d} B={B}: make_tiles {t_t * 1e3:7.2f} ms | fused sweep {t_f * 1e3:7.2f} ms | record-fed sweep {t_s * 1e3:7.2f} ms = "
           f"{t_s / B / T * 1e9 * min(B, 256):7.0f} ns per item-step per CU slot, {B * flops / t_s / 1e12:5.2f} TFLOP/s dense count, "
           f"records {B * rec / t_s / 1e9:6.0f} GB/s", flush=True)
