@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
     ap.add_argument("--window", type=int, default=6144, help="sub-problems in flight per GPU (a multiple of 3072 = three sweep wavefronts per SIMD)")
     ap.add_argument("--gather-chunk", type=int, default=2048, help="N > 1: items per chunk of the overlapped all-gather")
+    ap.add_argument("--gather-path", action="store_true", help="N = 1: run the job through the N > 1 path (results written into "
+                    "ResultBuffers, chunks 'gathered' from the progress callback on a side stream; one rank: a copy) -- diagnostic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events in the timed run "
                     "(per-kernel breakdown; costs ~4 %% of throughput in dispatch gaps) instead of the Riccati sweep only")
@@ -195,7 +197,8 @@ def main():
     jobs = [make_job(args.steps, seed_base + r * args.steps * B, host=(r == 0 and rank == 0)) for r in range(reps)]
     warm = make_job(args.warmup, seed_base + reps * args.steps * B) if args.warmup > 0 else None
     # N > 1: the results' home and the gathered results of all ranks, allocated once for the job's shape
-    rb = ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank)) if world > 1 else None
+    rb = (ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank))
+          if (world > 1 or args.gather_path) else None)
 
     def run(j, gather):
         if gather is not None:

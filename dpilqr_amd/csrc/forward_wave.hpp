@@ -278,10 +278,15 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         // the trajectory stores of the previous step go out here, BEFORE the next prefetch is issued: memory
         // operations retire in order, so the wait for that prefetch at the top of the next step then never
         // includes a younger store's round trip (the stores are invisible to the compiler's wait counts)
+#ifdef DPILQR_LS_EXP   // timing experiments only (wrong results): which of the candidate stores the launch time depends on
+        if (active && (DPILQR_LS_EXP < 3) && (g == 0 || DPILQR_LS_EXP < 1)) store_vec(Xw + (int64_t)t * n, x, NS);
+        if (active && (DPILQR_LS_EXP < 3) && (g == 0 || DPILQR_LS_EXP < 2) && t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
+#else
         if (active) {
             store_vec(Xw + (int64_t)t * n, x, NS);
             if (t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
         }
+#endif
 #pragma unroll
         for (int i = 0; i < NC; ++i) ut[i] = u[i];
         if (active) {
@@ -308,8 +313,13 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
+#ifdef DPILQR_LS_FMA
+                        sum[c] = fma(kr.x, dx2.x, sum[c]);
+                        sum[c] = fma(kr.y, dx2.y, sum[c]);
+#else
                         sum[c] += kr.x * dx2.x;
                         sum[c] += kr.y * dx2.y;
+#endif
                     }
                 }
             } else {

@@ -118,7 +118,8 @@ class ResultBuffers:
 
     def __init__(self, B, T, n_x, n_u, chunk=None, group=None, device=None, dtype=torch.float64):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized()            # no process group: one rank, the "gather" is a copy
+        self.world = dist.get_world_size(group) if self.collective else 1
         self.B, self.T, self.n_x, self.n_u = int(B), int(T), int(n_x), int(n_u)
         self.chunk = int(chunk) if chunk else max(self.B, 1)
         self.n_chunks = max(1, -(-self.B // self.chunk))
@@ -140,7 +141,7 @@ class ResultBuffers:
     # -- the collective, chunk by chunk
     def _gather_chunk(self, c):
         lo, hi = c * self.chunk, (c + 1) * self.chunk
-        if self.world == 1:
+        if not self.collective:
             self._Xall[c, 0].copy_(self._X[lo:hi]); self._Uall[c, 0].copy_(self._U[lo:hi])
             return
         dist.all_gather_into_tensor(self._Xall[c].view(-1), self._X[lo:hi].view(-1), group=self.group)
@@ -168,7 +169,7 @@ class ResultBuffers:
         with self._on_side():
             self._stats[:, 0].copy_(self._J); self._stats[:, 1].copy_(self._st); self._stats[:, 2].copy_(self._nb)
             self._stats[:, 3].copy_(self._nf)
-            if self.world == 1:
+            if not self.collective:
                 self._stats_all[0].copy_(self._stats)
             else:
                 dist.all_gather_into_tensor(self._stats_all.view(-1), self._stats.view(-1), group=self.group)

@@ -61,7 +61,7 @@ js = {"kernel": name.split("(")[0].replace("void dpilqr::", ""), "window_items":
       "hbm_bytes_per_full_window_launch": total, "hbm_bytes_per_subproblem_pass": total / window,
       "algorithmic_bytes_per_subproblem_pass": ALGO,
       "source": f"profiles/{tag}_bench_hbm_counters.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-                "bench.py --steps 8 --warmup 1 --no-cpu-baseline)"}
+                "bench.py --steps 16 --warmup 1 --reps 1 --no-cpu-baseline)"}
 tj = ROOT / "profiles" / "riccati_traffic.json"
 old = json.loads(tj.read_text()) if tj.exists() else {}
 if fused:      # keep the record-fed sweep's entry (bench.py reads it when DPILQR_NO_FUSED is set), add the fused one beside it
@@ -72,6 +72,9 @@ else:
     for key in ("hbm_bytes_per_subproblem_pass_fused", "fused"):
         if key in old:
             js[key] = old[key]
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402  (the hash of the sweep's source these passes were taken on)
+js["kernel_source_sha16"] = bench.kernel_source_sha16()
 tj.write_text(json.dumps(js, indent=1))
 for r in rows: print(r)
 print(json.dumps(js, indent=1))

@@ -295,6 +295,30 @@ def test_scenarios_sharded_single_rank_equals_front_end(dp, golden):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
         Xg, Ug, Jg, info = solve_scenarios_sharded(prob, x0[:, None, :], U0, 0.5)
+        # ... and the batch-sharded form over the same RCCL group: the chunked all-gather issued from inside the solve's
+        # progress callback, on a side stream, while the solve's own stream is busy (bench.py's N > 1 path with one rank)
+        import torch
+        from dpilqr_amd.sharding import ResultBuffers
+        from dpilqr_amd.util import random_setup_batch
+        from tests.golden_util import cfg2_params
+        c = cfg2_params(); Bc = 2500
+        xc0, xcf = random_setup_batch((31000, Bc), 5, 4, var=2.5, n_d=2, energy=10.0)
+        pbc = dp.ProblemBatch(c["model"], c["n_dims"], xcf, c["Q"], c["R"], c["Qf"], c["radius"], c["dt"], c["T"])
+        Uc0 = torch.zeros((Bc, 50, 10), dtype=torch.float64, device="cuda")
+        ref = pbc.solve(xc0, Uc0, window=512)
+        rb = ResultBuffers(Bc, 50, 20, 10, chunk=512, device=torch.device("cuda"))
+        assert rb.collective and rb.world == 1
+        rb.warm()
+        sent_early = []
+        for _ in range(2):
+            rb.begin()
+            pbc.solve(xc0, Uc0, window=512, out=rb.out, progress=lambda n, tot: (rb.progress(n, tot), sent_early.append(rb._sent)))
+            rb.finish()
+            torch.cuda.synchronize()
+            g = rb.results()
+            for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
+                assert torch.equal(g[key][0], ref[key]), key
+        assert max(sent_early) >= 2            # chunks went out while the solve was still running
     finally:
         dist.destroy_process_group()
     Xd, Ud, Jd, _ = solve_scenarios_distributed(prob, x0[:, None, :], U0, 0.5)
