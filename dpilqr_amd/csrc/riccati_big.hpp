@@ -93,7 +93,10 @@ struct BigLds {   // offsets in elements of R (all even)
         H = o;   o += ev(np * 9);               // pair Hessians
         p = o;   o += ev(n);
         ldlu = mk + 2;
-        LU = o;  o += ev(mk * ldlu > k * ns * (ns + nc) ? mk * ldlu : k * ns * (ns + nc));   // also the Jacobians' scratch between steps
+        {   // also the Jacobians' scratch between steps and the tile-transposition buffer of S5 (16 wavefronts x 2 x 16 x 17)
+            const int a = mk * ldlu, b = k * ns * (ns + nc), c = 16 * 544;
+            LU = o;  o += ev(a > b ? (a > c ? a : c) : (b > c ? b : c));
+        }
         inv = o; o += mk;
         perm = o; o += 2 * mk + 4;              // int32 perm[mk], piv[mk], flags, in R-sized slots (>= 4 bytes each)
         total = ev(o);
@@ -484,6 +487,77 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         __syncthreads();
         BPHASE(4)
 
+#ifndef DPILQR_BIG_S5_SEPARATE
+        // ---- S5 + S6 on tile PAIRS: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T, then
+        // P <- (V + V^T)/2, p <- V[:, n].  A wavefront computes the tiles (it, jt) AND (jt, it) of V together: they share all six
+        // operand streams (T3^T, [K|d], [Q_ux|Q_u] at column blocks it and jt: 6 loads per 6 matrix-pipe products instead of
+        // 10 per 6 for two separate tiles -- the phase is bound by those loads, section 9), and having both it forms P's two tiles
+        // at once: the transposed tile goes through 2 KB of LDS per wavefront (the LU buffer is dead here), V is never written
+        // back and the separate pass over V with its transposed reads (round 2's S6, 9 % of a step) is gone.  Same values, same
+        // operations as the separate phases: 0.5 (V[i][j] + V[j][i]) with V's entries rounded exactly as before
+        // (-DDPILQR_BIG_S5_SEPARATE builds round 2's phases for A/B).
+        {
+            const int tn = (n1 + 15) / 16, npair = tn * (tn + 1) / 2;
+            R* sT = sLU + wave * 544;        // two 16 x 17 tiles per wavefront
+            const int jt_p = n / 16, c_p = n - 16 * jt_p;   // where column n (the vector part) lives
+            for (int job = wave; job < npair; job += kBigThreads / 64) {
+                int it = 0, rem = job;
+                while (rem >= tn - it) { rem -= tn - it; ++it; }
+                const int jt = it + rem;
+                const bool off = it != jt;
+                acc_t a1 = acc_t{0, 0, 0, 0}, a2 = acc_t{0, 0, 0, 0}, a2t = acc_t{0, 0, 0, 0};
+                acc_t b1 = acc_t{0, 0, 0, 0}, b2 = acc_t{0, 0, 0, 0}, b2t = acc_t{0, 0, 0, 0};
+                const int64_t xo = (int64_t)g16 * ldw + 16 * it + c16, yo = (int64_t)g16 * ldw + 16 * jt + c16;
+                for (int ks = 0; ks < mk; ks += 4) {
+                    const int64_t ro = (int64_t)ks * ldw;
+                    const R t3i = gT3[ro + xo], kdi = gKd[ro + xo], gi = gG[ro + xo];
+                    const R t3j = gT3[ro + yo], kdj = gKd[ro + yo], gj = gG[ro + yo];
+                    a1 = Mfma<R>::mac(t3i, kdj, a1);
+                    a2 = Mfma<R>::mac(kdi, gj, a2);
+                    a2t = Mfma<R>::mac(gi, kdj, a2t);
+                    if (off) {          // tile (jt, it): the same products with i and j exchanged
+                        b1 = Mfma<R>::mac(t3j, kdi, b1);
+                        b2 = Mfma<R>::mac(kdj, gi, b2);
+                        b2t = Mfma<R>::mac(gj, kdi, b2t);
+                    }
+                }
+                R vij[4], vji[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int lr = Mfma<R>::row(v, g16);
+                    const int row = 16 * it + lr, col = 16 * jt + c16;           // tile (it, jt)
+                    const R q = (row < n && col <= n) ? gV[(int64_t)row * ldw + col] : (R)0.0;
+                    vij[v] = ((q + a1[v]) + a2[v]) + a2t[v];
+                    const int row2 = 16 * jt + lr, col2 = 16 * it + c16;         // tile (jt, it)
+                    const R q2 = (off && row2 < n && col2 <= n) ? gV[(int64_t)row2 * ldw + col2] : (R)0.0;
+                    vji[v] = off ? ((q2 + b1[v]) + b2[v]) + b2t[v] : vij[v];
+                    sT[lr * 17 + c16] = vij[v];
+                    sT[272 + lr * 17 + c16] = vji[v];
+                    // V[:, n] goes back to its place in the scratch and is read as p behind the barrier below, as in round 2.  (A
+                    // direct store sp[row] = vij[v] from here faulted -- HSA aperture violation -- on mid-solve iterates of the
+                    // twelve-state family although every index is in range and three debug variants of the same code did not;
+                    // not understood, so the store that is known to be sound is kept.)
+                    if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int lr = Mfma<R>::row(v, g16);
+                    const int row = 16 * it + lr, col = 16 * jt + c16;
+                    const R vt = sT[272 + c16 * 17 + lr];                          // V[col][row]
+                    if (row < n && col < n) gP[(int64_t)row * ldw + col] = (R)0.5 * (vij[v] + vt);
+                    if (off) {
+                        const int row2 = 16 * jt + lr, col2 = 16 * it + c16;
+                        const R vt2 = sT[c16 * 17 + lr];                           // V[col2][row2]
+                        if (row2 < n && col2 < n) gP[(int64_t)row2 * ldw + col2] = (R)0.5 * (vji[v] + vt2);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and the reads, before the next job overwrites the tiles
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+#else
         // ---- S5: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T   rows < n, columns <= n
         {
             const int ti_n = (n + 15) / 16, tj_n = (n1 + 15) / 16;
@@ -519,6 +593,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             gP[(int64_t)i * ldw + j] = (R)0.5 * (gV[(int64_t)i * ldw + j] + gV[(int64_t)j * ldw + i]);
         }
         for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+#endif
         __syncthreads();
         BPHASE(6)
     }
