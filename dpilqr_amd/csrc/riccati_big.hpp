@@ -115,10 +115,12 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     constexpr int NSC = NS + NC;
     const int slot = blockIdx.x;
     if (n_items && slot >= *n_items) return;
-    const int b = items ? items[slot] : slot;
+    // (the item index is the same in every lane: say so, or every pointer derived from it -- scratch regions, trajectory, gains,
+    // descriptor arrays: three dozen 64-bit values -- is held per lane and, at 128 registers per lane, spilled)
+    const int b = __builtin_amdgcn_readfirstlane(items ? items[slot] : slot);
     if (b >= D.B) return;
     const int64_t gslot = gains_by_item ? b : slot;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g16 = lane >> 4, c16 = lane & 15;
     const int k = D.k, T = D.T, n = k * NS, m = k * NC, npairs = k * (k - 1) / 2;
     const BigScratch S(n, m);
@@ -256,6 +258,15 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     for (int i = tid; i < n; i += kBigThreads) sp[i] = lx(i / NS, i % NS);
     __syncthreads();
 
+    // The lane terms of a phase (tile coordinates, operand addresses) are formed at the phase's start from a thread id the
+    // optimiser cannot see through: hoisted out of the horizon loop they are some fifty 64-bit addresses per lane, and at the
+    // 128 registers per lane that sixteen wavefronts per CU allow they were spilled in the prologue and reloaded inside the
+    // phases' inner loops (round 2: 82 spilled registers, 324 B of scratch per lane).
+#define BIG_LANE_TERMS()                                                                                   \
+    int tid_p_ = threadIdx.x;                                                                              \
+    asm volatile("" : "+v"(tid_p_));                                                                       \
+    const int tid = tid_p_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g16 = lane >> 4, c16 = lane & 15; \
+    (void)wave; (void)g16; (void)c16; (void)lane;
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bph_t = __builtin_amdgcn_s_memtime();
 #define BPHASE(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[i] += now_ - bph_t; bph_t = now_; }
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         __syncthreads();
         BPHASE(0)
 
+        { BIG_LANE_TERMS()
         // ---- S1: the block products.  Work item (ai, aj, r): row r of [A_ai | B_ai]^T P_(ai,aj) (NS terms), then times
         // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).  (An MFMA formulation -- two
         // 16x16x4 products per block pair with T transposed through LDS -- was built and measured SLOWER, 500 k against 250 k
@@ -335,9 +347,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 gG[(int64_t)ia * ldw + n] = lu + s;
             }
         }
+        }
         __syncthreads();
         BPHASE(1)
 
+        { BIG_LANE_TERMS()
         // ---- S3a: LU of Q_uu in LDS, partial pivoting in dgetf2's order (first POSITION of largest magnitude), without moving
         // rows: sPerm[pos] is the row that stands at position pos after the exchanges so far; the factors stay where they are
         // and every later access goes through sPerm
@@ -385,9 +399,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             R* row = sLU + sPerm[ps] * ldlu;
             for (int c = (e & 31); c < ps; c += 32) row[c] *= sInv[c];
         }
+        }
         __syncthreads();
         BPHASE(2)
 
+        { BIG_LANE_TERMS()
         // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u]: one right-hand side per thread, substitution in blocks of 16 rows
         // (solved blocks go through the scratch; a row of 16 threads' values is one coalesced access)
         const int nb = mk / 16;
@@ -450,9 +466,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
             }
         }
+        }
         __syncthreads();
         BPHASE(3)
 
+        { BIG_LANE_TERMS()
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]   (K^T Q_uu, associated as the reference's K.T @ Q_uu @ K)
         {
             const int ti_n = (m + 15) / 16, tj_n = (n + 15) / 16, tj2 = (tj_n + 1) / 2;
@@ -484,10 +502,12 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
             }
         }
+        }
         __syncthreads();
         BPHASE(4)
 
 #ifndef DPILQR_BIG_S5_SEPARATE
+        { BIG_LANE_TERMS()
         // ---- S5 + S6 on tile PAIRS: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T, then
         // P <- (V + V^T)/2, p <- V[:, n].  A wavefront computes the tiles (it, jt) AND (jt, it) of V together: they share all six
         // operand streams (T3^T, [K|d], [Q_ux|Q_u] at column blocks it and jt: 6 loads per 6 matrix-pipe products instead of
@@ -508,10 +528,13 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 acc_t a1 = acc_t{0, 0, 0, 0}, a2 = acc_t{0, 0, 0, 0}, a2t = acc_t{0, 0, 0, 0};
                 acc_t b1 = acc_t{0, 0, 0, 0}, b2 = acc_t{0, 0, 0, 0}, b2t = acc_t{0, 0, 0, 0};
                 const int64_t xo = (int64_t)g16 * ldw + 16 * it + c16, yo = (int64_t)g16 * ldw + 16 * jt + c16;
+                // operands of reduction rows ks + 4 .. ks + 7 are requested before the products of rows ks .. ks + 3 are issued: the
+                // loop is bound by the latency / bandwidth of these loads (scratch in L2 / Infinity Cache), not by the matrix pipe
+                R t3i = gT3[xo], kdi = gKd[xo], gi = gG[xo], t3j = gT3[yo], kdj = gKd[yo], gj = gG[yo];
                 for (int ks = 0; ks < mk; ks += 4) {
-                    const int64_t ro = (int64_t)ks * ldw;
-                    const R t3i = gT3[ro + xo], kdi = gKd[ro + xo], gi = gG[ro + xo];
-                    const R t3j = gT3[ro + yo], kdj = gKd[ro + yo], gj = gG[ro + yo];
+                    const int64_t ro = (int64_t)min(ks + 4, mk - 4) * ldw;     // the last round re-reads its own rows
+                    const R n_t3i = gT3[ro + xo], n_kdi = gKd[ro + xo], n_gi = gG[ro + xo];
+                    const R n_t3j = gT3[ro + yo], n_kdj = gKd[ro + yo], n_gj = gG[ro + yo];
                     a1 = Mfma<R>::mac(t3i, kdj, a1);
                     a2 = Mfma<R>::mac(kdi, gj, a2);
                     a2t = Mfma<R>::mac(gi, kdj, a2t);
@@ -520,6 +543,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         b2 = Mfma<R>::mac(kdj, gi, b2);
                         b2t = Mfma<R>::mac(gj, kdi, b2t);
                     }
+                    t3i = n_t3i; kdi = n_kdi; gi = n_gi; t3j = n_t3j; kdj = n_kdj; gj = n_gj;
                 }
                 R vij[4], vji[4];
 #pragma unroll
@@ -557,6 +581,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         }
         __syncthreads();
         for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+        }
 #else
         // ---- S5: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T   rows < n, columns <= n
         {
