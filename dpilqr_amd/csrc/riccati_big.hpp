@@ -357,6 +357,91 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // and every later access goes through sPerm
         for (int r = tid; r < mk; r += kBigThreads) sPerm[r] = r;
         __syncthreads();
+#ifndef DPILQR_BIG_LU_PLAIN
+        // With LOOK-AHEAD (round 3): while fifteen wavefronts apply column kk's eliminations to the columns from kk + 2 on, the
+        // first wavefront applies them to column kk + 1 alone and then searches THAT column's pivot, exchanges and inverts --
+        // the search, the exchange and the fp64 division were a third of every column's critical path (238 k of a step's 1.47 M
+        // clocks in the plain form below, -DDPILQR_BIG_LU_PLAIN for A/B, which also costs two workgroup barriers per column
+        // instead of one).  Same pivots, same multipliers, every entry updated by the same operations in the same order.  The
+        // permutation is double-buffered: a column's eliminations read perm_kk while perm_kk+1 is being written (both exchanges
+        // that separate the two buffers are applied by the one lane that decides them).  (Measured and dropped: panels of eight
+        // columns factorised by one wavefront, 40 instead of 160 barriers -- 290 k: the per-column chain through LDS, not
+        // the barriers, sets the pace.)
+        int* sPermB = sPiv;                               // the second permutation buffer (sPiv is otherwise unused)
+        for (int r = tid; r < mk; r += kBigThreads) sPermB[r] = r;
+        if (wave == 0) {                                  // column 0's pivot, before the loop
+            R best = -1.0;
+            int piv = 0;
+            for (int ps = (lane & 15); ps < m; ps += 16) {
+                const R v = fabs(sLU[ps * ldlu]);
+                if (v > best) { best = v; piv = ps; }
+            }
+#define DPILQR_ARGMAX_STEP(CTRL)                                                                \
+            {                                                                               \
+                const R ob = dpp_val<CTRL>(best);                                           \
+                const int op = dpp_i32<CTRL>(piv);                                          \
+                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }         \
+            }
+            DPILQR_ARGMAX_STEP(0xB1) DPILQR_ARGMAX_STEP(0x4E) DPILQR_ARGMAX_STEP(0x141) DPILQR_ARGMAX_STEP(0x140)
+            if (lane == 0) {
+                sPerm[0] = piv; sPerm[piv] = 0;             // perm_0 lives in sPerm (even columns), perm_1 will live in sPermB
+                const R pv = sLU[piv * ldlu];
+                if (!(best > (R)0.0)) sFlag[0] = 1;        // zero (or NaN) pivot: np.linalg.solve would raise
+                sInv[0] = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                sFlag[1] = piv;                            // the exchange (0, piv), to be replayed into the other buffer
+            }
+        }
+        __syncthreads();
+        for (int kk = 0; kk < m; ++kk) {
+            const int* pk = (kk & 1) ? sPermB : sPerm;     // perm_kk
+            int* pn = (kk & 1) ? sPerm : sPermB;           // becomes perm_kk+1
+            const R inv = sInv[kk];
+            const R* prow = sLU + pk[kk] * ldlu;
+            if (wave == 0) {
+                if (kk + 1 < m) {
+                    // column kk + 1 first, all rows below the pivot ...
+                    for (int ps = kk + 1 + lane; ps < m; ps += 64) {
+                        R* row = sLU + pk[ps] * ldlu;
+                        const R l = row[kk] * inv;
+                        row[kk + 1] = fma(-l, prow[kk + 1], row[kk + 1]);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // ... then its pivot: sixteen lanes scan the column, ties go to the lower position
+                    R best = -1.0;
+                    int piv = kk + 1;
+                    for (int ps = kk + 1 + (lane & 15); ps < m; ps += 16) {
+                        const R v = fabs(sLU[pk[ps] * ldlu + kk + 1]);
+                        if (v > best) { best = v; piv = ps; }
+                    }
+                    DPILQR_ARGMAX_STEP(0xB1) DPILQR_ARGMAX_STEP(0x4E) DPILQR_ARGMAX_STEP(0x141) DPILQR_ARGMAX_STEP(0x140)
+                    if (lane == 0) {
+                        // pn holds perm_kk-1: replay the exchange that made perm_kk, then make this column's
+                        const int a0 = kk, b0 = sFlag[1];
+                        const int t0 = pn[a0]; pn[a0] = pn[b0]; pn[b0] = t0;
+                        const int rk = pn[kk + 1], rp = pn[piv];
+                        pn[kk + 1] = rp; pn[piv] = rk;
+                        const R pv = sLU[rp * ldlu + kk + 1];
+                        if (!(best > (R)0.0)) sFlag[0] = 1;
+                        sInv[kk + 1] = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                        sFlag[1] = piv;
+                    }
+                }
+            } else {
+                // the columns from kk + 2 on: positions > kk, a 30 x 32 thread tile over the other fifteen wavefronts
+                const int t = tid - 64;
+                for (int ps = kk + 1 + (t >> 5); ps < m; ps += (kBigThreads - 64) / 32) {
+                    R* row = sLU + pk[ps] * ldlu;
+                    const R l = row[kk] * inv;
+                    for (int c = kk + 2 + (t & 31); c < m; c += 32) row[c] = fma(-l, prow[c], row[c]);
+                }
+            }
+            __syncthreads();
+        }
+#undef DPILQR_ARGMAX_STEP
+        // the final permutation perm_m-1 into sPerm, where the substitution reads it
+        if (((m - 1) & 1) && tid < mk) sPerm[tid] = sPermB[tid];
+        __syncthreads();
+#else
         for (int kk = 0; kk < m; ++kk) {
             if (wave == 0) {
                 // sixteen lanes scan the column, five candidates each at n_u = 80; ties go to the lower position
@@ -393,6 +478,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
             __syncthreads();
         }
+#endif
         // multipliers l = a / pivot in place (exactly the values the elimination used)
         for (int e = tid; e < m * 32; e += kBigThreads) {
             const int ps = e >> 5;
