@@ -169,10 +169,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # DPILQR_BENCH_BACKEND=gloo (diagnostic): the N > 1 code path with gloo instead of RCCL, every rank on whatever GPU its
+    # LOCAL_RANK maps to modulo the visible ones -- how the multi-rank path is exercised on a one-GPU box (tests/test_gpu_api.py)
+    backend = os.environ.get("DPILQR_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import dpilqr_amd
     from dpilqr_amd import _lib
@@ -234,6 +241,10 @@ def main():
         times.append(float(dt.item()))
         if rep == 0:
             r0 = {k: v.clone() for k, v in r.items()} if rb is not None else r      # the parity leg looks at repetition 0
+            if rb is not None:      # untimed sanity of the collective: this rank's block of the gathered results is what it solved,
+                g = rb.results()    # and every rank's block is a finished job (status 1..3 everywhere)
+                assert torch.equal(g["X"][rank], r["X"]) and torch.equal(g["J"][rank], r["J"]), "all-gather returned another block"
+                assert bool(((g["status"] >= 1) & (g["status"] <= 3)).all()), "a rank's gathered results are not finished solves"
         nb_mean = float(r["n_bwd"].double().mean()); nf_mean = float(r["n_fwd"].double().mean())
         del r
     prof = _lib.profile_read(reset=True)

@@ -580,3 +580,29 @@ def test_progress_reports_and_chunked_gather_world1(dp):
         ns = [n for n, _, _ in calls]
         assert ns == sorted(ns) and ns[-1] == B and all(t == B for _, t, _ in calls) and all(ok for _, _, ok in calls)
         assert len([n for n in ns if 0 < n < B]) >= 2    # progress was reported while the solve was still running
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's N > 1 path end to end with two processes (torch.distributed.run, backend gloo through
+    DPILQR_BENCH_BACKEND, both ranks on the one GPU of the box): per-rank seeds, results written into ResultBuffers, chunks
+    all-gathered from the solve's progress callback on a side stream while the solve runs, barrier + MAX over ranks, one JSON
+    line from rank 0 -- and bench.py's own check that each rank's block of the gathered results is what that rank solved."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, DPILQR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "2",
+           "--gather-chunk", "512", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and len(d["repetitions"]["ms_per_step"]) == 2
+    assert "all-gather in chunks of 512" in d["config"]["parallelism"]
