@@ -305,6 +305,11 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
             double sum[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) sum[c] = 0.0;
+#ifdef DPILQR_LS_SPLIT
+            double sum2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum2[c] = 0.0;
+#endif
             const double* rows = sK + (a * NC) * n;
             if (n % 2 == 0) {
 #pragma unroll 5
@@ -313,7 +318,10 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
-#ifdef DPILQR_LS_FMA
+#if defined(DPILQR_LS_SPLIT)   // timing experiment: two partial sums per control (another summation order)
+                        sum[c] += kr.x * dx2.x;
+                        sum2[c] += kr.y * dx2.y;
+#elif defined(DPILQR_LS_FMA)
                         sum[c] = fma(kr.x, dx2.x, sum[c]);
                         sum[c] = fma(kr.y, dx2.y, sum[c]);
 #else
@@ -330,6 +338,10 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
                     for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
                 }
             }
+#ifdef DPILQR_LS_SPLIT
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum[c] += sum2[c];
+#endif
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double du = sum[c] + alpha * sd[a * NC + c];
