@@ -245,7 +245,6 @@ def main():
                 g = rb.results()    # and every rank's block is a finished job (status 1..3 everywhere)
                 assert torch.equal(g["X"][rank], r["X"]) and torch.equal(g["J"][rank], r["J"]), "all-gather returned another block"
                 assert bool(((g["status"] >= 1) & (g["status"] <= 3)).all()), "a rank's gathered results are not finished solves"
-        nb_mean = float(r["n_bwd"].double().mean()); nf_mean = float(r["n_fwd"].double().mean())
         del r
     prof = _lib.profile_read(reset=True)
     sweep_variants = {w: _lib.profile_read_sweep(w, reset=True) for w in (12, 8, 4)}
