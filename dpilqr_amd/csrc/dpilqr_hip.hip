@@ -331,7 +331,7 @@ template <> struct Passes<float> {
 template <typename R>
 SolveShape shape_of(const dpilqr_batch_desc& D) {
     const bool big = sizeof(R) == 4 || uses_big_path(D.k * D.n_s);
-    return SolveShape{big, sizeof(R), !big && fused_sweep_applies(D)};
+    return SolveShape{big, sizeof(R), !big && fused_sweep_applies(D) && !solve_prefers_records(D)};
 }
 
 // ilqrSolver.solve for every item of the batch.  solver != NULL: the synchronous, adaptive form (the host follows the

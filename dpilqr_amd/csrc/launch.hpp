@@ -68,6 +68,16 @@ inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
 inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
     return fused_wavefront_sweep_applies(D) || fused_workgroup_sweep_applies(D);
 }
+// The solve loop's choice where both a record-free workgroup sweep and a record-fed WAVEFRONT sweep serve a batch: at
+// n_x = 12 and 24 (two / four six-state agents: cfg4's small clusters; six four-state agents: cfg3's smallest) a wavefront
+// per item beats a workgroup per item by more than the tile producer costs.  2048 items, one sweep (profiles/
+// r03_small_clusters.txt): n_x = 12 fused workgroup sweep 1.74 ms against producer 0.36 + wavefront sweep 0.26 ms; n_x = 24
+// (four quadcopters) 2.67 against 1.01 + 0.88.  Whole solves of 2048 items: two quadcopters 24.3 -> 13.4 ms, four 26.7 -> 20.6,
+// six unicycles 86.2 -> 80.6, six double integrators 23.8 -> 21.3.  DPILQR_NO_WAVE_PREF: A/B switch.
+inline bool solve_prefers_records(const dpilqr_batch_desc& D) {
+    static const bool off = getenv("DPILQR_NO_WAVE_PREF") != nullptr;
+    return !off && ((D.n_s == 6 && D.n_c == 3 && (D.k == 2 || D.k == 4)) || (D.n_s == 4 && D.n_c == 2 && D.k == 6));
+}
 
 // ---- tu_tiles.hip
 int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const double* U, double* tiles,

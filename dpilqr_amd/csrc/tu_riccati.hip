@@ -58,7 +58,25 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
         return DPILQR_OK;                                                                                          \
     }
         DPILQR_TILED_SIZES(DPILQR_TRY_MFMA)
+        // n_x = 24 (four six-state or six four-state agents): 19 KB of LDS per wavefront, two per SIMD; the workgroup sweep
+        // costs 2.2 ms per 2048 items there, a wavefront per item 0.7 (profiles/r03_small_clusters.txt)
 #undef DPILQR_TRY_MFMA
+        if (n == 24 && m == 12) {   // the all-MFMA (dense) instantiation only: the block-diagonal lane mapping stops at five agents
+            static_assert(MfmaCfg<24, 12>::supported, "MFMA sweep not available for this size");
+            static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 8;
+            const int wv = (grid_items > 1024 && max_wv >= 8) ? 8 : 4;
+            g_sweep_waves = wv;
+            const size_t lds_t = sizeof(double) * MfmaCfg<24, 12>::total * wv;
+            auto kern = wv == 8 ? k_riccati_mfma<24, 12, 8, 0, 0> : k_riccati_mfma<24, 12, 4, 0, 0>;
+            int32_t rc_t = allow_lds(kern, lds_t);
+            if (rc_t) return rc_t;
+            const int cus = device_cus();
+            const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d, singular, items, n_items,
+                               gains_by_item, cus, FusedArgs{});
+            HIP_TRY(hipGetLastError());
+            return DPILQR_OK;
+        }
     }
     // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
     static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
