@@ -298,7 +298,12 @@ class ProblemBatch:
         1024, except on the large-cluster path (one workgroup per item: 256 = one per CU)."""
         per_item = self.workspace_bytes(2, True, dtype) - self.workspace_bytes(1, True, dtype)
         floor = 256 if (self.fused_sweep or dtype != torch.float64) else 1024
-        return int(min(self.B, 6144, max(floor, (4 << 30) // max(per_item, 1))))
+        w = max(floor, (4 << 30) // max(per_item, 1))
+        if self.n_x <= 24 and dtype == torch.float64:
+            # the wavefront sweeps deal items in layers of 1024 (one wavefront per SIMD of every CU): a window of 2450 items
+            # would run every sweep as a full round plus a fifth of one
+            w = max(1024, (w // 1024) * 1024)
+        return int(min(self.B, 6144, w))
 
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64, out=None,
               progress=None):
