@@ -645,9 +645,10 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     sT[lr * 17 + c16] = vij[v];
                     sT[272 + lr * 17 + c16] = vji[v];
                     // V[:, n] goes back to its place in the scratch and is read as p behind the barrier below, as in round 2.  (A
-                    // direct store sp[row] = vij[v] from here faulted -- HSA aperture violation -- on mid-solve iterates of the
-                    // twelve-state family although every index is in range and three debug variants of the same code did not;
-                    // not understood, so the store that is known to be sound is kept.)
+                    // direct store sp[row] = vij[v] from here faulted -- HSA aperture violation on mid-solve iterates of the
+                    // twelve-state family, every index in range -- in the build that still spilled 95 registers around this
+                    // loop, and runs clean since the lane terms are formed per phase (45 spilled): a code-generation problem of
+                    // that build, not of the store.  The round trip through the scratch costs one barrier and is kept.)
                     if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes
