@@ -471,7 +471,9 @@ def test_sweep_twelve_state_family(dp, k):
 
 
 @pytest.mark.parametrize("model,k,T", [(0, 7, 50), (0, 13, 50), (0, 15, 50), (3, 7, 100), (3, 8, 100), (3, 12, 100), (3, 13, 100),
-                                       (3, 14, 100), (3, 15, 100), (4, 5, 75), (4, 8, 75), (4, 10, 75)])
+                                       (3, 14, 100), (3, 15, 100), (4, 5, 75), (4, 8, 75), (4, 10, 75),
+                                       # round 3: the sizes the solve loop routes to producer + wavefront sweep (n_x = 12, 24)
+                                       (0, 6, 50), (3, 6, 100), (4, 2, 75), (4, 4, 75), (4, 3, 75)])
 def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     """Whole solves of 7..15-agent clusters at the configs' horizons (cfg3: unicycles T = 100, cfg4: quadcopters T = 75) and
     the reference's n_lqr_iter = 50: the workgroup-per-item sweep and the two / three-wavefront line search against the
@@ -500,7 +502,7 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     plain = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
     # (ten quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the oracle itself on most seeds:
     # the envelope above still holds for every item, through every iteration)
-    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8)) else 2), rep["summary"]
+    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8), (3, 6)) else 2), rep["summary"]
     for i in np.where(plain)[0]:
         assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i
         assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i
