@@ -167,6 +167,20 @@ __device__ __forceinline__ void for_rows(int row0, int lo, int hi, int g, bool c
     }
 }
 
+// The same walk for epilogues that LOAD: f(v, r - lo, ok) runs for every row group that is not wholly outside, and says
+// whether this lane's element is inside.  The caller loads from a clamped address whatever `ok` is and uses the predicate for
+// the store only -- a load inside `if (ok)` is an exec-mask region with its own LDS wait, one round trip per element.
+template <typename F>
+__device__ __forceinline__ void for_rows_p(int row0, int lo, int hi, int g, bool col_ok, F&& f) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = row0 + 4 * v;
+        if (r + 3 < lo || r >= hi) continue;
+        const bool inside = (r >= lo) && (r + 3 < hi);
+        f(v, r - lo, col_ok && (inside || (r + g >= lo && r + g < hi)));
+    }
+}
+
 // In-register LU of S3: lane = column (of Q_uu or of a right-hand side), v[r] = its entry in row r.  SEARCH: with
 // dgetf2's partial pivoting; without, for matrices that are known not to need a row swap (see S3).
 // KEEPINV = false: the reciprocal pivots are not kept (invd has one element and is not written): the caller's substitution
@@ -424,6 +438,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #define MPHASE(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#elif defined(DPILQR_PHASE_MARKS)   // assembly listings only: where each phase ends (hipcc -S, scripts/isa_census.py)
+#define MPHASE(i) asm volatile("; ==== end of phase " #i);
 #else
 #define MPHASE(i)
 #endif
@@ -564,6 +580,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             // [T1;T2] [A|B] with the same patterns: columns 0, 1 of T A are T's, columns 2, 3 are dt T_0 + T_2, dt T_1 + T_3,
             // T B = dt [T_2 T_3]; then the step's l-values, formed here instead of being read
             const double fdt = F.D.dt, wp = F.D.w_prox;
+            // (the Hessian entries of all rows first, from a clamped offset: no load behind a per-lane test)
+            v2d hh[RPL];
+            const bool with_h = FKA > 1 && f_prox;
+            if (with_h) {
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) hh[r] = *reinterpret_cast<const v2d*>(sFH + max(lv_h[r], 0));
+            }
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 double tv[NS], acc[NSC], lv[NSC];
@@ -577,10 +600,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 acc[4] = tv[2] * fdt; acc[5] = tv[3] * fdt;
 #pragma unroll
                 for (int c = 0; c < NSC; ++c) lv[c] = lvc[r][c];
-                if (FKA > 1 && f_prox && lv_h[r] >= 0) {     // the pair Hessian (or the agent's sum of them) on the position entries
-                    const v2d h = *reinterpret_cast<const v2d*>(sFH + lv_h[r]);
-                    lv[0] += wp * (lv_neg[r] ? -h.x : h.x);
-                    lv[1] += wp * (lv_neg[r] ? -h.y : h.y);
+                if (with_h) {     // the pair Hessian (or the agent's sum of them) on the position entries
+                    const bool on = lv_h[r] >= 0;
+                    const double l0 = lv[0] + wp * (lv_neg[r] ? -hh[r].x : hh[r].x), l1 = lv[1] + wp * (lv_neg[r] ? -hh[r].y : hh[r].y);
+                    lv[0] = on ? l0 : lv[0];
+                    lv[1] = on ? l1 : lv[1];
                 }
 #pragma unroll
                 for (int q = 0; q < NS / 2; ++q)
@@ -744,8 +768,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 for (int jt = 0; jt < T_NP; ++jt) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) vb[it][jt][v] = 0.0;
-                    for_rows(16 * it, 0, N, g, colLE[jt], [&](int v, int r) {
-                        vb[it][jt][v] = ((dQ[16 * jt + r * LQ] + a1[it][jt][v]) + a2[it][jt][v]) + dMtT[16 * jt * LM + r];
+                    for_rows_p(16 * it, 0, N, g, colLE[jt], [&](int v, int r, bool ok) {   // (stored under the same predicate)
+                        const double q = *(ok ? dQ + 16 * jt + r * LQ : sP), mt = *(ok ? dMtT + 16 * jt * LM + r : sP);
+                        vb[it][jt][v] = ((q + a1[it][jt][v]) + a2[it][jt][v]) + mt;
                     });
                 }
             DPILQR_LDS_FENCE();
@@ -760,8 +785,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_NP; ++jt) {
-                    for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) {
-                        vb[it][jt][v] = 0.5 * (vb[it][jt][v] + dPt[16 * jt * LP + r]);
+                    for_rows_p(16 * it, 0, N, g, colN[jt], [&](int v, int r, bool ok) {
+                        vb[it][jt][v] = 0.5 * (vb[it][jt][v] + *(ok ? dPt + 16 * jt * LP + r : sP));
                     });
                 }
             DPILQR_LDS_FENCE();

@@ -318,9 +318,18 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
             for (int jp = 0; jp < 4; ++jp) W[itp][jp] = W[itp][jp] * sc;
         }
         // 3. everything from the panel's tile on: += W * (the panel's rows), the panel's rows themselves replaced
+        // (W pinned first: seen through, the selects that built W and this one are merged into control flow -- seven
+        // branches per panel)
         double a_op[RT];
 #pragma unroll
-        for (int it = 0; it < RT; ++it) a_op[it] = g == 0 ? W[it][0] : (g == 1 ? W[it][1] : (g == 2 ? W[it][2] : W[it][3]));
+        for (int it = 0; it < RT; ++it) {
+            asm volatile("" : "+v"(W[it][0]), "+v"(W[it][1]), "+v"(W[it][2]), "+v"(W[it][3]));
+            double r = W[it][0];
+            r = g == 1 ? W[it][1] : r; asm volatile("" : "+v"(r));
+            r = g == 2 ? W[it][2] : r; asm volatile("" : "+v"(r));
+            r = g == 3 ? W[it][3] : r;
+            a_op[it] = r;
+        }
         const int jt_first = (Kp + 4) / 16 < RT ? (Kp + 4) / 16 : itp;   // the tile the next panel's columns are in goes first
 #pragma unroll
         for (int jo = 0; jo < CT; ++jo) {
@@ -579,6 +588,8 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
 #define WPHASE(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - ph_t; ph_t = now_; }
+#elif defined(DPILQR_PHASE_MARKS)   // assembly listings only: where each phase ends (hipcc -S)
+#define WPHASE(i) asm volatile("; ==== end of phase " #i);
 #else
 #define WPHASE(i)
 #endif
@@ -915,48 +926,78 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         {
             WG_LANE_TERMS()
             wg_barrier();   // every operand read of G, [K|d], T3^T is done: a2 goes there for the transposed read
-            double W[C::TPW5][4];
+            // No exec-mask regions from here to the store of P: a lane whose element lies outside the matrix loads from
+            // offset 0 and stores to its own word of the trash region, so every pass is loads | arithmetic | stores with
+            // one wait each.  (Written with `if (i < n && j < n)` around each element this epilogue was 144 branches and 55
+            // full LDS waits per step -- a quarter of the step's instructions.)
+            double* const trash = sTrash + lane;
+            double W[C::TPW5][4], ld0[C::TPW5][4], ld1[C::TPW5][4];
+            // the loads of two tiles at a time where the registers allow it (two sub-problems per CU), tile by tile otherwise
+            constexpr int CH6 = C::OCC >= 3 ? 1 : (C::TPW5 % 2 == 0 ? 2 : C::TPW5);
 #pragma unroll
-            for (int q = 0; q < C::TPW5; ++q) {
-                const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
-                const int tc = min(tl, C::NT5 - 1);
-                const int it = tc / T_NP, jt = tc - it * T_NP;
-                const int j = 16 * jt + c16;
+            for (int q0 = 0; q0 < C::TPW5; q0 += CH6) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int i = 16 * it + g + 4 * v;
-                    W[q][v] = 0.0;
-                    if (tl < C::NT5) {
-                        if (i < NP && j < N) sMt[i * LM + j] = a2[q][v];
-                        if (i < N && j <= N) {
-                            W[q][v] = (sQ[i * LQ + j] + a1[q][v]) + a2[q][v];
-                            if (j < N) sQ[i * LQ + j] = W[q][v];
-                        }
+                for (int q = q0; q < q0 + CH6; ++q) {
+                    const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
+                    const int tc = min(tl, C::NT5 - 1);
+                    const int it = tc / T_NP, jt = tc - it * T_NP;
+                    const int j = 16 * jt + c16;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = 16 * it + g + 4 * v;
+                        const bool in_w = tl < C::NT5 && i < N && j <= N;
+                        ld0[q][v] = sQ[in_w ? i * LQ + j : 0];
+                    }
+                }
+#pragma unroll
+                for (int q = q0; q < q0 + CH6; ++q) {
+                    const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
+                    const int tc = min(tl, C::NT5 - 1);
+                    const int it = tc / T_NP, jt = tc - it * T_NP;
+                    const int j = 16 * jt + c16;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = 16 * it + g + 4 * v;
+                        const bool live = tl < C::NT5;
+                        W[q][v] = (ld0[q][v] + a1[q][v]) + a2[q][v];
+                        *((live && i < NP && j < N) ? sMt + i * LM + j : trash) = a2[q][v];
+                        *((live && i < N && j < N) ? sQ + i * LQ + j : trash) = W[q][v];
                     }
                 }
             }
             wg_barrier();
             // ---- S6: V = W + a2^T ; V^T from the mirrored pair (same operands, same order) ; P <- (V + V^T)/2.
-            // P takes W's place: every transposed read of W happens before the barrier, every store after it
+            // P takes W's place: every transposed read of W happens before the barrier, every store after it.
 #pragma unroll
-            for (int q = 0; q < C::TPW5; ++q) {
-                const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
-                const int tc = min(tl, C::NT5 - 1);
-                const int it = tc / T_NP, jt = tc - it * T_NP;
-                const int j = 16 * jt + c16;
+            for (int q0 = 0; q0 < C::TPW5; q0 += CH6) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int i = 16 * it + g + 4 * v;
-                    if (tl < C::NT5 && i < N && j <= N) {
-                        const double V = W[q][v] + sMt[j * LM + i];
-                        double out = V;
-                        if (j < N) {
-                            const double Vt = sQ[j * LQ + i] + a2[q][v];
-                            out = 0.5 * (V + Vt);
-                        }
-                        W[q][v] = out;
+                for (int q = q0; q < q0 + CH6; ++q) {
+                    const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
+                    const int tc = min(tl, C::NT5 - 1);
+                    const int it = tc / T_NP, jt = tc - it * T_NP;
+                    const int j = 16 * jt + c16;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = 16 * it + g + 4 * v;
+                        const bool in_w = tl < C::NT5 && i < N && j <= N;
+                        ld0[q][v] = sMt[in_w ? j * LM + i : 0];
+                        ld1[q][v] = sQ[(in_w && j < N) ? j * LQ + i : 0];
                     }
                 }
+#pragma unroll
+                for (int q = q0; q < q0 + CH6; ++q) {
+                    const int tl = C::T3REG ? wave * T_NP + q : wave + 4 * q;
+                    const int tc = min(tl, C::NT5 - 1);
+                    const int jt = tc - (tc / T_NP) * T_NP;
+                    const int j = 16 * jt + c16;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double V = W[q][v] + ld0[q][v];
+                        const double Vt = ld1[q][v] + a2[q][v];
+                        W[q][v] = j < N ? 0.5 * (V + Vt) : V;
+                    }
+                }
+                if constexpr (CH6 < C::TPW5) asm volatile("" ::: "memory");   // the next chunk's loads stay behind this chunk's sums
             }
             wg_barrier();
 #pragma unroll
@@ -968,7 +1009,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int i = 16 * it + g + 4 * v;
-                    if (tl < C::NT5 && i < N && j <= N) sP[i * LP + j] = W[q][v];
+                    *((tl < C::NT5 && i < N && j <= N) ? sP + i * LP + j : trash) = W[q][v];
                 }
             }
         }

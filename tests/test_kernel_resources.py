@@ -48,7 +48,7 @@ def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
     assert len(wg) >= 40
     for k, r in wg.items():
         fused = k.endswith("true>")
-        assert r["vgpr_spill_count"] <= (10 if fused else 16), (k, r)          # round 2: up to 48
+        assert r["vgpr_spill_count"] <= 16, (k, r)                              # round 2: up to 48
         assert r["sgpr_spill_count"] <= 96, (k, r)                              # round 2: up to 1012
     big = table["k_riccati_wg<60, 30, 4, 2, true>"]
     assert big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 256            # cfg3's 15-unicycle clusters: two per CU
