@@ -131,8 +131,11 @@ __device__ __forceinline__ void wave_sync() {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef DPILQR_LS_OCC   // workgroups per CU the register allocation aims at (A/B builds: 3 -> 168 registers, 8 of them spilled, +20 % launch time)
+#define DPILQR_LS_OCC 2
+#endif
 template <int MODEL, int KA>
-__global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL, KA>::IPB), 2) void k_linesearch_wave(
+__global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL, KA>::IPB), DPILQR_LS_OCC) void k_linesearch_wave(
     dpilqr_batch_desc D, double* X, double* U, const double* __restrict__ K, const double* __restrict__ d,
     const double* __restrict__ alphas, double* Xc, double* Uc, SolveState S, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items) {

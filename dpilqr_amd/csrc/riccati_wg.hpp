@@ -230,12 +230,23 @@ __device__ __attribute__((noinline)) int lu_fallback_wg(const double* __restrict
 // After the last panel Q_uu has become I and the right-hand sides hold the solution; no substitution pass.
 //
 // Pivoting: threshold pivoting that prefers the diagonal.  The diagonal entry is the pivot as long as no entry below it in its
-// column is more than 8 times larger (the classical threshold rule of sparse LU, there with 0.1: element growth per step is
-// bounded by 1 + 8 instead of partial pivoting's 2).  Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is
+// column is more than 8 times larger (the threshold rule of sparse LU with a diagonal preference -- UMFPACK / MA48 use 0.1
+// there, KLU 0.001; element growth per step is bounded by 1 + 8 instead of partial pivoting's 2).  A looser threshold declines
+// less often -- 7 % / 4 % / 2 % / 1.5 % of the steps of 15-unicycle iterates at 8 / 16 / 32 / 64 (scripts/threshold_study.py),
+// each decline a 50 k-cycle register LU all four wavefronts wait for, 4..7 k cycles per step on average -- and at 64 a 2048-item
+// sweep is 12..14 % faster; but the end-to-end envelope (oracle/parity.py) sees the price: over cfg4's 8077 audited solves the
+// worst cost error sits at 2.6 / 4.7 / 7.5 / 12.9 ensemble spreads (allowed: 10; scripts/envelope_tail.py,
+// profiles/r03_gj_threshold_tails.txt).  8 stays.  (DPILQR_GJ_THRESHOLD: A/B builds.)
+// Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is
 // NOT always positive definite away from a minimum (half of the steps of a fresh 15-unicycle iterate have a negative pivot),
 // which is why the rule looks at magnitudes.  If the rule fails anywhere, or a pivot is zero / not finite, nothing has been
 // written and the caller runs LAPACK-order partial pivoting (lu_eliminate<true>) instead.  Every wavefront factorises the
 // same Q_uu with the same instructions, so all of them take the same decision.
+#ifndef DPILQR_GJ_THRESHOLD
+#define DPILQR_GJ_THRESHOLD 8
+#endif
+constexpr double kGjThreshold = 1.0 / DPILQR_GJ_THRESHOLD;
+
 template <int M, int MO, int LG, int LK, int NP>
 __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double* __restrict__ sK, double* __restrict__ sPan,
                                            int wave, int lane) {
@@ -296,7 +307,7 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
             for (int it = 0; it < RT; ++it) {
                 const int row = 16 * it + c;
                 const double a = pan[it][j];
-                bad = bad || (row > Kp + j && 0.125 * fabs(a) > fabs(pv));
+                bad = bad || (row > Kp + j && kGjThreshold * fabs(a) > fabs(pv));
                 l[it] = (row != Kp + j) ? a * ninv : 0.0;
             }
 #pragma unroll
@@ -812,11 +823,14 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                 WG_LANE_TERMS()
                 const bool declined = gj_blocked<M, MO, LG, LK, NP>(sG, sK, lds + (C::PAN_IN_AB ? C::oAB : C::oPan) + 128 * wave, wave, lane);
                 lu_needed = lu_needed && declined;
-#ifdef DPILQR_PHASE_STAMPS
+#if defined(DPILQR_PHASE_STAMPS) && !defined(DPILQR_S3_SPLIT)
                 if (!declined) ph[6] += 1000;   // diagnostic: share of the steps solved by blocks (per mille)
 #endif
             }
         }
+#if defined(DPILQR_PHASE_STAMPS) && defined(DPILQR_S3_SPLIT)   // slots 6, 7: the blocked elimination, the fall-back (instead of the two shares)
+        WPHASE(6)
+#endif
         if (lu_needed) {
             WG_LANE_TERMS()
             // out of line: the register LU holds m columns + its broadcasts (250 registers, hundreds of scalar temporaries at
@@ -824,11 +838,14 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
             // it set the register allocation of the whole kernel (round 2: every fused instantiation spilled)
             const int flags = lu_fallback_wg<M, N, NP, MO, LG, LK, RW>(sG, sK, wave, lane);
             if (flags & 1) sing = 1;
-#ifdef DPILQR_PHASE_STAMPS
+#if defined(DPILQR_PHASE_STAMPS) && !defined(DPILQR_S3_SPLIT)
             if (!C::GJ && (flags & 2)) ph[6] += 1000;   // diagnostic: share of the steps with the search-free elimination
             if (flags & 4) ph[7] += 1000;               // ... and of the steps in which partial pivoting moved a row
 #endif
         }
+#if defined(DPILQR_PHASE_STAMPS) && defined(DPILQR_S3_SPLIT)
+        WPHASE(7)
+#endif
         wg_barrier();
         {
             int tid_p = tid;

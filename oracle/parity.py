@@ -105,9 +105,12 @@ def _envelope_once(got, proto, x0, xf, U0, n_lqr_iter, tol, n_threads, deltas, C
             ok[i] = False; why[i] = msg
 
     # (1) costs, iteration by iteration, to the end of the solve
+    cost_ratio = np.zeros(B)     # reported: the largest cost error in units of max(FLOOR, ensemble spread); rule (1) is cost_ratio <= C
     for col, name in ((3, "accepted cost"), (2, "last evaluated cost")):
         dg = np.where(live, _reldiff(tg[:, :rows, col], rt[:, :, col]), 0.0)
         bad = dg > bJ
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cost_ratio = np.maximum(cost_ratio, np.nan_to_num(np.max(dg / np.maximum(FLOOR, sJ), axis=1, initial=0.0), nan=np.inf))
         for i in np.where(bad.any(axis=1))[0]:
             j = int(np.argmax(bad[i]))
             fail(i, f"{name} of iteration {j} off by {dg[i, j]:.2e}; the ensemble spreads by {sJ[i, j]:.2e} there")
@@ -152,7 +155,7 @@ def _envelope_once(got, proto, x0, xf, U0, n_lqr_iter, tol, n_threads, deltas, C
 
     return dict(ok=ok, why=why, flipped=flipped, explained=explained, errX=errX, errU=errU, spreadX=sX, spreadU=sU,
                 spreadJ=sJ, flip=flip, member_agrees=member_agrees, X_replay=r["X"], U_replay=r["U"], J_replay=r["J"],
-                rtrace=rt)
+                rtrace=rt, cost_ratio=cost_ratio)
 
 
 DELTAS_WIDE = tuple(sg * v for v in np.geomspace(1e-13, 5e-13, 32) for sg in (1.0, -1.0))
@@ -173,7 +176,7 @@ def envelope(got, proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, delta
     if len(again) and escalate is not None:
         sub = _envelope_once({k: v[again] for k, v in g.items()}, proto, x0[again], xf[again], U0[again], n_lqr_iter, tol,
                              n_threads, escalate, C)
-        for key in ("ok", "flipped", "explained", "spreadX", "spreadU", "spreadJ", "flip", "member_agrees"):
+        for key in ("ok", "flipped", "explained", "spreadX", "spreadU", "spreadJ", "flip", "member_agrees", "cost_ratio"):
             rep[key][again] = sub[key]
         for a, i in enumerate(again):
             rep["why"][i] = sub["why"][a]
@@ -192,6 +195,7 @@ def envelope(got, proto, x0, xf, U0, n_lqr_iter=50, tol=1e-3, n_threads=0, delta
                 bound_above_1e5_frac=float((bound_X > 1e-5).mean()),
                 ensemble_spread_above_1e5_frac=float((sX > 1e-5).mean()),
                 max_err_over_bound=float(np.max(np.where(np.isinf(bound_X), 0.0, errX / np.where(np.isinf(bound_X), 1.0, bound_X)))),
+                max_cost_err_over_spread=float(np.max(rep["cost_ratio"])) if B else 0.0,
                 median_err=float(np.median(errX)), median_spread=float(np.median(sX)),
                 reference_result_undetermined_frac=float(np.isinf(sX).mean()))
     if natural is not None:

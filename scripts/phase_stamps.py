@@ -1,6 +1,7 @@
 """Diagnostic: per-phase shader cycles of the wavefront sweep (record-fed or fused), from in-kernel s_memtime stamps.
 Needs a -DDPILQR_PHASE_STAMPS build of the library: `python scripts/phase_stamps.py --build` makes build/libdpilqr_stamps.so
-(no GPU needed); then, on the GPU box, `python scripts/phase_stamps.py [B] [--fused]`."""
+(no GPU needed); then, on the GPU box, `python scripts/phase_stamps.py [B] [--fused]`.  `--wg B k [quad6|uni4]`: the workgroup sweep;
+`--s3split` (at --build and at run time): its S3 split into blocked elimination / fall-back / barrier + store."""
 import subprocess
 import sys
 from pathlib import Path
@@ -19,7 +20,8 @@ if "--build" in sys.argv:
         obj = so.parent / f"stamps_{src.stem}.o"
         objs.append(str(obj))
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                                       "-DDPILQR_PHASE_STAMPS", f"-I{ROOT / 'include'}", f"-I{csrc}", "-c", "-o", str(obj), str(src)]))
+                                       "-DDPILQR_PHASE_STAMPS", *(["-DDPILQR_S3_SPLIT"] if "--s3split" in sys.argv else []),
+                                       f"-I{ROOT / 'include'}", f"-I{csrc}", "-c", "-o", str(obj), str(src)]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(so), *objs], check=True)
     sys.exit(0)
@@ -59,8 +61,12 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     torch.cuda.synchronize()
     ph = buf.cpu().numpy()[4 * B:].reshape(B, 8) / Tw
     names = ["S0 stage AB, request l-values", "S1 [A|B]^T[P|p]", "S2 [T1;T2][A|B]", "S3 LU solve+store", "S4 T3", "S5+S6", "-"]
-    print(f"S3: steps solved by blocks (m = 13..16 and m >= 24; else: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
-          f"fall-back's partial pivoting moved a row: {ph[:, 7].mean() / 10:.1f} %")
+    if "--s3split" in sys.argv:   # a --build --s3split library: slots 6, 7 are times (wavefront 0's), slot 3 is what is left of S3 (barrier, store of K)
+        print(f"S3 split: blocked elimination {ph[:, 6].mean():.0f} ticks/step, fall-back {ph[:, 7].mean():.0f}, barrier + store of [K|d] {ph[:, 3].mean():.0f}")
+        ph[:, 3] += ph[:, 6] + ph[:, 7]
+    else:
+        print(f"S3: steps solved by blocks (m = 13..16 and m >= 24; else: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
+              f"fall-back's partial pivoting moved a row: {ph[:, 7].mean() / 10:.1f} %")
     ph = ph[:, :6]
     tot = ph.sum(1).mean()
     for nm_, v in zip(names, ph.mean(0)):
