@@ -270,6 +270,8 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bph_t = __builtin_amdgcn_s_memtime();
 #define BPHASE(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[i] += now_ - bph_t; bph_t = now_; }
+#elif defined(DPILQR_PHASE_MARKS)   // assembly listings only (scripts/isa_census.py)
+#define BPHASE(i) asm volatile("; ==== end of phase " #i);
 #else
 #define BPHASE(i)
 #endif
@@ -492,13 +494,25 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         { BIG_LANE_TERMS()
         // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u]: one right-hand side per thread, substitution in blocks of 16 rows
         // (solved blocks go through the scratch; a row of 16 threads' values is one coalesced access)
+        // The factors' rows are read sixteen entries at a time as pairs (every row starts on an even offset): element by element
+        // each multiply-add waited for its own LDS load -- a 6 400-step chain per right-hand side at one LDS round trip per step
+        typedef R pair_t __attribute__((ext_vector_type(2)));
+        auto ld8 = [](const R* __restrict__ src, R (&o)[8]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const pair_t v = *reinterpret_cast<const pair_t*>(src + 2 * q);
+                o[2 * q] = v.x; o[2 * q + 1] = v.y;
+            }
+        };
         const int nb = mk / 16;
         for (int j = tid; j < n1; j += kBigThreads) {
             for (int I = 0; I < nb; ++I) {                       // L y = P b
                 R y[16];
+                int pr[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int r = 16 * I + i;
+                    pr[i] = sPerm[r] * ldlu;   // (the same for every thread; moved to scalar registers by readfirstlane it gave wrong rows at n_x = 64 -- not understood, not used)
                     y[i] = (r < m) ? gG[(int64_t)sPerm[r] * ldw + j] : (R)0.0;
                 }
                 for (int J = 0; J < I; ++J) {
@@ -506,40 +520,61 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #pragma unroll
                     for (int c = 0; c < 16; ++c) yj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const R* Lr = sLU + sPerm[16 * I + i] * ldlu + 16 * J;
+                    for (int i = 0; i < 16; ++i)
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) y[i] = fma(-Lr[c], yj[c], y[i]);
-                    }
+                        for (int h = 0; h < 2; ++h) {
+                            R l[8];
+                            ld8(sLU + pr[i] + 16 * J + 8 * h, l);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) y[i] = fma(-l[c], yj[8 * h + c], y[i]);
+                        }
                 }
+                // the diagonal block, row by row (each y[i] still takes its terms in ascending c: the same sums as column by column)
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
+                for (int i = 1; i < 16; ++i) {
+                    R l[16];
 #pragma unroll
-                    for (int i = c + 1; i < 16; ++i) y[i] = fma(-sLU[sPerm[16 * I + i] * ldlu + 16 * I + c], y[c], y[i]);
+                    for (int q = 0; q < (i + 1) / 2; ++q) {
+                        const pair_t v = *reinterpret_cast<const pair_t*>(sLU + pr[i] + 16 * I + 2 * q);
+                        l[2 * q] = v.x; l[2 * q + 1] = v.y;
+                    }
+#pragma unroll
+                    for (int c = 0; c < i; ++c) y[i] = fma(-l[c], y[c], y[i]);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gKd[(int64_t)(16 * I + i) * ldw + j] = y[i];
             }
             for (int I = nb - 1; I >= 0; --I) {                  // U x = y ; [K | d] = -x
                 R y[16];
+                int pr[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) y[i] = gKd[(int64_t)(16 * I + i) * ldw + j];
+                for (int i = 0; i < 16; ++i) { y[i] = gKd[(int64_t)(16 * I + i) * ldw + j]; pr[i] = sPerm[16 * I + i] * ldlu; }
                 for (int J = nb - 1; J > I; --J) {
                     R xj[16];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) xj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const R* Ur = sLU + sPerm[16 * I + i] * ldlu + 16 * J;
+                    for (int i = 0; i < 16; ++i)
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) y[i] = fma(Ur[c], xj[c], y[i]);   // xj holds -x
-                    }
+                        for (int h = 0; h < 2; ++h) {
+                            R u[8];
+                            ld8(sLU + pr[i] + 16 * J + 8 * h, u);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) y[i] = fma(u[c], xj[8 * h + c], y[i]);   // xj holds -x
+                        }
                 }
 #pragma unroll
                 for (int i = 15; i >= 0; --i) {
+                    R u[16];
+#pragma unroll
+                    for (int q = i / 2; q < 8; ++q) {
+                        const pair_t v = *reinterpret_cast<const pair_t*>(sLU + pr[i] + 16 * I + 2 * q);
+                        u[2 * q] = v.x; u[2 * q + 1] = v.y;
+                    }
                     R s = y[i];
 #pragma unroll
-                    for (int c = i + 1; c < 16; ++c) s = fma(sLU[sPerm[16 * I + i] * ldlu + 16 * I + c], y[c], s);
-                    y[i] = -(s / sLU[sPerm[16 * I + i] * ldlu + 16 * I + i]);
+                    for (int c = i + 1; c < 16; ++c) s = fma(u[c], y[c], s);
+                    y[i] = -(s / u[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
