@@ -735,17 +735,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
 
         __builtin_amdgcn_s_setprio(0);
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
-        {
-            v4d acc[T_M][T_N];
-            zero_tiles(acc);
-            mfma_product<T_M, T_N, MK, LG, LK>(pGuu, pK, acc);
+        // One row tile of controls (m <= 16): T3^T never goes through LDS.  The fp64 MFMA's output layout -- lane (g, c) holds rows
+        // g + 4 v of column c -- IS its A-operand layout for the reduction rows 4 v .. 4 v + 3, so S4's accumulator register v of
+        // column tile jt is S5's A operand of reduction step v for row tile jt of a1: same products, same order, one store pass,
+        // one LDS round trip and six operand loads less per step.
+        // (Not with three wavefronts per SIMD: at 168 registers the two tiles held across the phase boundary cost two spilled
+        // registers; the variants for few live items -- the latency-bound ones -- have 256.)
+        constexpr bool T3R = (T_M == 1) && (T_N == T_NP) && (WAVES != 12);
+        v4d t3[T_M][T_N];
+        zero_tiles(t3);
+        mfma_product<T_M, T_N, MK, LG, LK>(pGuu, pK, t3);
+        if constexpr (!T3R) {
 #pragma unroll
             for (int it = 0; it < T_M; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_N; ++jt)
-                    for_rows(16 * it, 0, M, g, colN[jt], [&](int v, int r) { dT3[16 * jt + r * N] = acc[it][jt][v]; });
+                    for_rows(16 * it, 0, M, g, colN[jt], [&](int v, int r) { dT3[16 * jt + r * N] = t3[it][jt][v]; });
+            DPILQR_LDS_FENCE();
         }
-        DPILQR_LDS_FENCE();
         MPHASE(4)
 
         // ---- S5: a1 = T3 [K|d] ; a2 = [K|d]^T [Q_ux|Q_u] ; V = ((Q + a1) + a2) + a2^T   (rows < n, cols <= n)
@@ -754,7 +761,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             v4d a1[T_NP][T_NP], a2[T_NP][T_NP];
             zero_tiles(a1);
             zero_tiles(a2);
-            mfma_product<T_NP, T_NP, MK, N, LK>(pT3, pK, a1);
+            if constexpr (T3R) {
+#pragma unroll
+                for (int ks = 0; ks < MK / 4; ++ks) {
+                    double b[T_NP];
+#pragma unroll
+                    for (int jt = 0; jt < T_NP; ++jt) b[jt] = pK[ks * 4 * LK + 16 * jt];
+#pragma unroll
+                    for (int it = 0; it < T_NP; ++it)
+#pragma unroll
+                        for (int jt = 0; jt < T_NP; ++jt) a1[it][jt] = mfma_f64(t3[0][it][ks], b[jt], a1[it][jt]);
+                }
+            } else {
+                mfma_product<T_NP, T_NP, MK, N, LK>(pT3, pK, a1);
+            }
             mfma_product<T_NP, T_NP, MK, LK, LG>(pK, pGux, a2);
 #pragma unroll
             for (int it = 0; it < T_NP; ++it)

@@ -54,14 +54,15 @@ struct WgCfg {
     // a2 (n+1 x n, S5 epilogue -> S6) starts at G and runs on into the [K|d] region: both are dead by then
     static constexpr int szK = round_up(szG + szKT3 >= NP * LM ? szKT3 : NP * LM - szG, 2);
     static constexpr int szAB = round_up(KA * NS * NSCP, 2);
-    // S3 by blocks (gj_blocked below) for m = 13 .. 16 (one row tile: 16 registers of accumulators) and from m = 24 on (where
-    // the register budget of two sub-problems per CU holds both it and the fall-back); at m = 17 .. 23 it spills at three and
-    // four sub-problems per CU and those sizes keep the register LU.  32 x 4 doubles per wavefront to turn a panel's columns
+    // S3 by blocks (gj_blocked below) for m = 13 .. 16 (one row tile: 16 registers of accumulators) and from m = 22 on (where
+    // the register budget of two sub-problems per CU holds both it and the fall-back); at m = 17 .. 21 it needs two sub-problems
+    // per CU where the register LU runs with three or four, and measures slower (m = 18: 4.4 -> 5.6 ms per 2048 items) or equal
+    // (m = 20, 21); m = 22 (eleven unicycles) gains 5 .. 9 % (-DDPILQR_GJ_ALL builds, profiles/r03_wg_gj_all.txt).  32 x 4 doubles per wavefront to turn a panel's columns
     // into rows
 #ifdef DPILQR_GJ_ALL   // A/B builds
     static constexpr bool GJ = (M >= 13);
 #else
-    static constexpr bool GJ = (M >= 24) || (M >= 13 && M <= 16);
+    static constexpr bool GJ = (M >= 22) || (M >= 13 && M <= 16);
 #endif
     // ... which take the place of the [A|B] blocks where those are large enough (dead between S2 and the next S0)
     static constexpr bool PAN_IN_AB = GJ && szAB >= 4 * 128;
@@ -97,7 +98,7 @@ struct WgCfg {
 #ifdef DPILQR_GJ_ALL
     static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 16 ? 3 : 2) : (M <= 16 ? 4 : 2));
 #else
-    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 22 ? 3 : 2)));
+    static constexpr int kRegFit = NS >= 12 ? 2 : (NS >= 6 ? (M <= 21 ? 3 : 2) : (M <= 18 ? 4 : (M <= 21 ? 3 : 2)));
 #endif
 #ifdef DPILQR_WG_OCC   // A/B builds
     static constexpr int OCC = kLdsFit < DPILQR_WG_OCC ? (kLdsFit < 1 ? 1 : kLdsFit) : DPILQR_WG_OCC;

@@ -65,7 +65,7 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
         print(f"S3 split: blocked elimination {ph[:, 6].mean():.0f} ticks/step, fall-back {ph[:, 7].mean():.0f}, barrier + store of [K|d] {ph[:, 3].mean():.0f}")
         ph[:, 3] += ph[:, 6] + ph[:, 7]
     else:
-        print(f"S3: steps solved by blocks (m = 13..16 and m >= 24; else: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
+        print(f"S3: steps solved by blocks (m = 13..16 and m >= 22; else: by the search-free register elimination) {ph[:, 6].mean() / 10:.1f} %; steps in which the "
               f"fall-back's partial pivoting moved a row: {ph[:, 7].mean() / 10:.1f} %")
     ph = ph[:, :6]
     tot = ph.sum(1).mean()

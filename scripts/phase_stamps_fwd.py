@@ -1,15 +1,14 @@
 """Diagnostic: cycles the line-search kernel spends waiting for its per-step prefetch vs in total (needs a
--DDPILQR_PHASE_STAMPS build, made here in /tmp)."""
-import sys, subprocess
+-DDPILQR_PHASE_STAMPS build: python scripts/phase_stamps.py --build).
+    python scripts/phase_stamps_fwd.py [B]"""
+import sys
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import torch
-so = "/tmp/libdpilqr_stamps.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-                "-DDPILQR_PHASE_STAMPS", f"-I{ROOT/'include'}", f"-I{ROOT/'dpilqr_amd'/'csrc'}", "-o", so,
-                str(ROOT/"dpilqr_amd"/"csrc"/"dpilqr_hip.hip")], check=True)
+so = ROOT / "build" / "libdpilqr_stamps.so"     # python scripts/phase_stamps.py --build
+assert so.exists(), "build the stamps library first: python scripts/phase_stamps.py --build"
 from dpilqr_amd import _lib
 _lib.LIB_PATH = Path(so)
 import dpilqr_amd as dp
