@@ -115,6 +115,14 @@ struct WaveFwdLds {
     // up to 550 bytes -- Quadcopter12D: 2 KB -- per lane into the horizon loop.  (One to six four-state agents: registers are
     // the faster place, measured.)
     static constexpr bool CONST_LDS = NW > 1 || NS >= 6;
+    // Wavefronts per SIMD the register allocation aims at.  Two; one for nine and ten six-state agents, where two meant 32 / 63
+    // spilled registers and 24 scratch loads per step INSIDE the horizon loop (ten quadcopters: 29.8 -> 21.0 ms of line search in a
+    // 2048-item solve, nine: 18.8 -> 17.2; eight: equal, seven and the unicycle clusters of 12 .. 15: slower with one).  Three
+    // (168 registers, 8 spilled) makes cfg2's five-agent kernel 20 % slower.  DPILQR_LS_OCC: A/B builds.
+#ifndef DPILQR_LS_OCC
+#define DPILQR_LS_OCC 2
+#endif
+    static constexpr int OCC = (NW > 1 && NS >= 6 && KA >= 9) ? 1 : DPILQR_LS_OCC;
     static constexpr int oQ = (octl + 2 + 1) & ~1;                 // Q [agent][NS*NS]
     static constexpr int oR = oQ + (CONST_LDS ? KA * NS * NS : 0); // R [agent][NC*NC]
     static constexpr int oXf = oR + (CONST_LDS ? KA * NC * NC : 0);
@@ -131,11 +139,8 @@ __device__ __forceinline__ void wave_sync() {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifndef DPILQR_LS_OCC   // workgroups per CU the register allocation aims at (A/B builds: 3 -> 168 registers, 8 of them spilled, +20 % launch time)
-#define DPILQR_LS_OCC 2
-#endif
 template <int MODEL, int KA>
-__global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL, KA>::IPB), DPILQR_LS_OCC) void k_linesearch_wave(
+__global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL, KA>::IPB), (WaveFwdLds<MODEL, KA>::OCC)) void k_linesearch_wave(
     dpilqr_batch_desc D, double* X, double* U, const double* __restrict__ K, const double* __restrict__ d,
     const double* __restrict__ alphas, double* Xc, double* Uc, SolveState S, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items) {
