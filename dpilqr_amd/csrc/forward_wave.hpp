@@ -122,7 +122,9 @@ struct WaveFwdLds {
 #ifndef DPILQR_LS_OCC
 #define DPILQR_LS_OCC 2
 #endif
-    static constexpr int OCC = (NW > 1 && NS >= 6 && KA >= 9) ? 1 : DPILQR_LS_OCC;
+    // ... and one for twelve-state agents (Quadcopter12D's RK4 stages hold 7 x 12 doubles next to the sincos expansions: 64 .. 102
+    // scratch loads per step at two; one to three agents 11 .. 18 % faster with one, five equal; scripts/bench_q12.py)
+    static constexpr int OCC = ((NW > 1 && NS >= 6 && KA >= 9) || NS >= 12) ? 1 : DPILQR_LS_OCC;
     static constexpr int oQ = (octl + 2 + 1) & ~1;                 // Q [agent][NS*NS]
     static constexpr int oR = oQ + (CONST_LDS ? KA * NS * NS : 0); // R [agent][NC*NC]
     static constexpr int oXf = oR + (CONST_LDS ? KA * NC * NC : 0);
