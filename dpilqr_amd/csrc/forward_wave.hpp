@@ -114,7 +114,10 @@ struct WaveFwdLds {
     // LDS: in registers (48 for a four-state agent, 104 for a six-state one, next to the pair tables) those kernels spill
     // up to 550 bytes -- Quadcopter12D: 2 KB -- per lane into the horizon loop.  (One to six four-state agents: registers are
     // the faster place, measured.)
-    static constexpr bool CONST_LDS = NW > 1 || NS >= 6;
+#ifndef DPILQR_LS_CL_ALL   // A/B builds: the per-agent constants in LDS for every size
+#define DPILQR_LS_CL_ALL 0
+#endif
+    static constexpr bool CONST_LDS = NW > 1 || NS >= 6 || DPILQR_LS_CL_ALL;
     // Wavefronts per SIMD the register allocation aims at.  Two; one for nine and ten six-state agents, where two meant 32 / 63
     // spilled registers and 24 scratch loads per step INSIDE the horizon loop (ten quadcopters: 29.8 -> 21.0 ms of line search in a
     // 2048-item solve, nine: 18.8 -> 17.2; eight: equal, seven and the unicycle clusters of 12 .. 15: slower with one).  Three
