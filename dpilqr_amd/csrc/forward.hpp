@@ -251,7 +251,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
 // LDS slice and no workgroup barrier -- the same SIMD-placement argument as for the sweep (riccati_tiled.hpp).
 // R: arithmetic type; KDIRECT: K[t] is not staged in LDS (large clusters); lds_per_item in elements of R.
 template <typename R, int NS, int NC, bool KDIRECT>
-__global__ __launch_bounds__(256, KDIRECT ? 1 : 2) void k_forward(dpilqr_batch_desc D, int mode, const R* __restrict__ x0, R* X,
+__global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(dpilqr_batch_desc D, int mode, const R* __restrict__ x0, R* X,
                                                   R* U, const R* __restrict__ K, const R* __restrict__ d,
                                                   const double* __restrict__ alphas, int ngrp, R* Xc, R* Uc,
                                                   double* Jc, SolveState S, const int32_t* __restrict__ items,
