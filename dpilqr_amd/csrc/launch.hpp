@@ -59,6 +59,13 @@ inline bool fused_wavefront_sweep_applies(const dpilqr_batch_desc& D) {
     return !off && hint_model(D) == 0 && hint_n_dims(D) == 2 && hint_shared_weights(D) && D.Q_bstride == 0 && D.R_bstride == 0 &&
            D.Qf_bstride == 0 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
 }
+// ... and its general form (FUSED == 2): at most five agents of ONE model of the four-state family -- DoubleIntDynamics4D or
+// UnicycleDynamics4D (the descriptor's hint) -- with any per-agent, per-item Q / R / Q_f, planar proximity cost.  Two wavefronts
+// per SIMD at most (the per-agent weights take the LDS the third one needs).
+inline bool fused_wavefront_general_applies(const dpilqr_batch_desc& D) {
+    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_GENERAL") != nullptr;
+    return !off && (hint_model(D) == 0 || hint_model(D) == 3) && hint_n_dims(D) == 2 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
+}
 // Workgroup sweep (riccati_wg.hpp): 6..15 agents of the four-state family or 2..10 of the six-state family -- any models of
 // the family, any per-agent weights, any n_dims.
 inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
@@ -66,7 +73,7 @@ inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
     return !off && ((D.n_s == 4 && D.n_c == 2 && D.k >= 6 && D.k <= 15) || (D.n_s == 6 && D.n_c == 3 && D.k >= 2 && D.k <= 10));
 }
 inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
-    return fused_wavefront_sweep_applies(D) || fused_workgroup_sweep_applies(D);
+    return fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D) || fused_workgroup_sweep_applies(D);
 }
 // The solve loop's choice where both a record-free workgroup sweep and a record-fed WAVEFRONT sweep serve a batch: at
 // n_x = 12 and 24 (two / four six-state agents: cfg4's small clusters; six four-state agents: cfg3's smallest) a wavefront

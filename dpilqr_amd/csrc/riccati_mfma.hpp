@@ -38,7 +38,7 @@ namespace dpilqr {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int N, int M, bool FUSED = false>
+template <int N, int M, int FUSED = 0>   // FUSED: 0 tile records; 1 DoubleInt4D, one Q / R / Q_f; 2 four-state family, per-agent weights
 struct MfmaCfg {
     static constexpr int NM = N + M;
     static constexpr int NP = N + 1;                   // columns of [P|p], [K|d], [Q_ux|Q_u]
@@ -67,8 +67,11 @@ struct MfmaCfg {
     // pair gradients [NPAIR][2], pair Hessians [NPAIR][4], their per-agent sums [KA][4], Q + Q^T [16], R + R^T [4], x_f [N]
     static constexpr int F_KA = N / 4, F_NP = F_KA * (F_KA - 1) / 2;
     // and the step's [l_x | l_u] [N + M]
-    static constexpr int oFG = N * LQ, oFH = oFG + 2 * F_NP, oFD = oFH + 4 * F_NP, oFQQ = oFD + 4 * F_KA, oFRR = oFQQ + 16,
-                         oFXf = oFRR + 4, oFL = oFXf + N, szF = round_up(oFL + NM, 2);
+    // (FUSED == 2: Q + Q^T, R + R^T of every agent, and the step's state-dependent entries of every agent's A block [F_KA][4])
+    static constexpr int F_W = FUSED == 2 ? F_KA : 1;
+    static constexpr int oFG = N * LQ, oFH = oFG + 2 * F_NP, oFD = oFH + 4 * F_NP, oFQQ = oFD + 4 * F_KA, oFRR = oFQQ + 16 * F_W,
+                         oFXf = oFRR + 4 * F_W, oFL = oFXf + N, oFA = oFL + round_up(NM, 2),
+                         szF = round_up(oFA + (FUSED == 2 ? 4 * F_KA : 0), 2);
     static constexpr int szR1 = FUSED ? szF : round_up(N * LAB > N * LQ ? N * LAB : N * LQ, 2);
     static constexpr int szT0 = N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N;
     static constexpr int szT1 = szT0 > NM * LTB ? szT0 : NM * LTB;
@@ -270,13 +273,15 @@ struct FusedArgs {
     const double* U;
 };
 
-template <int N, int M, int WAVES, int NS, int NC, bool FUSED = false>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
+// (The sweep's body, shared by the two kernels below: FUSED 0 tile records, 1 the DoubleInt4D form, 2 the general four-state form.)
+template <int N, int M, int WAVES, int NS, int NC, int FUSED>
+__device__ __forceinline__ void riccati_mfma_sweep(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
     using C = MfmaCfg<N, M, FUSED>;
-    static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variant is written for DoubleIntDynamics4D blocks");
+    static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variants are written for the four-state family's blocks");
+    constexpr bool FGEN = (FUSED == 2);   // per-agent weights, per-agent model (DoubleIntDynamics4D / UnicycleDynamics4D)
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
     constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
     // Items are DEALT to workgroups in layers, not blocked.  A workgroup owns a CU (its LDS), so a launch runs in rounds
@@ -365,8 +370,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             if (ip < N) {
                 const int ar = ip >> 2, li = ip & 3;
                 if (ar == ag_) {
+                    const double* Qa = IP.Q + (FGEN ? 16 * ag_ : 0);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) lvc[r][c] = F.D.w_ref * (IP.Q[li * 4 + c] + IP.Q[c * 4 + li]);
+                    for (int c = 0; c < NS; ++c) lvc[r][c] = F.D.w_ref * (Qa[li * 4 + c] + Qa[c * 4 + li]);
                 }
                 if (FKA_ > 1 && li < 2) {
                     lv_neg[r] = ar != ag_;
@@ -376,8 +382,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             } else {
                 const int a = ip - N;
                 if ((a >> 1) == ag_) {
-                    lvc[r][NS] = F.D.w_ref * (IP.R[(a & 1) * 2] + IP.R[a & 1]);
-                    lvc[r][NS + 1] = F.D.w_ref * (IP.R[(a & 1) * 2 + 1] + IP.R[2 + (a & 1)]);
+                    const double* Ra = IP.R + (FGEN ? 4 * ag_ : 0);
+                    lvc[r][NS] = F.D.w_ref * (Ra[(a & 1) * 2] + Ra[a & 1]);
+                    lvc[r][NS + 1] = F.D.w_ref * (Ra[(a & 1) * 2 + 1] + Ra[2 + (a & 1)]);
                 }
             }
         }
@@ -400,8 +407,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         // symmetrised weights and the goal, once; then the terminal condition p = l_x(T), P = l_xx(T) (control.py:125-129)
         // with the tile producer's expressions (tiles_wave.hpp phases A2-B2, Q_f in place of Q)
         const ItemParams IP = item_params(F.D, b);
+        if constexpr (FGEN) {
+            for (int e = lane; e < 16 * FKA; e += 64) {
+                const int a = e >> 4, q = e & 15;
+                sFQQ[e] = IP.Q[16 * a + q] + IP.Q[16 * a + (q & 3) * 4 + (q >> 2)];
+            }
+            for (int e = lane; e < 4 * FKA; e += 64) {
+                const int a = e >> 2, q = e & 3;
+                sFRR[e] = IP.R[4 * a + q] + IP.R[4 * a + (q & 1) * 2 + (q >> 1)];
+            }
+        } else {
         if (lane < 16) sFQQ[lane] = IP.Q[lane] + IP.Q[(lane & 3) * 4 + (lane >> 2)];
         if (lane < 4) sFRR[lane] = IP.R[lane] + IP.R[(lane & 1) * 2 + (lane >> 1)];
+        }
         for (int e = lane; e < N; e += 64) sFXf[e] = IP.xf[e];
         DPILQR_LDS_FENCE();
         fused_prefetch(T);
@@ -410,7 +428,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N, ai = i >> 2, li = i & 3, aj = j >> 2, lj = j & 3;
             double val = 0.0;
-            if (ai == aj) val = F.D.w_ref * (IP.Qf[li * 4 + lj] + IP.Qf[lj * 4 + li]);
+            if (ai == aj) {
+                const double* Qfa = IP.Qf + (FGEN ? 16 * ai : 0);
+                val = F.D.w_ref * (Qfa[li * 4 + lj] + Qfa[lj * 4 + li]);
+            }
             if (FKA > 1 && li < 2 && lj < 2 && f_prox) {
                 double acc = 0.0;
                 if (ai == aj) acc = sFD[ai * 4 + li * 2 + lj];
@@ -479,12 +500,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                 const v2d v = *reinterpret_cast<const v2d*>(bP + l * LP);
                 pr[l][0] = v.x; pr[l][1] = v.y;
             }
+            // FGEN: the agent's A block is I + dt A_c with A_c's entries (0,2), (1,2), (0,3), (1,3) free (Unicycle4D: dt cos, dt sin,
+            // -dt v sin, dt v cos; DoubleInt4D: dt, 0, 0, dt), the step's values in sFA.  Row 2 of A^T P is the record-fed sweep's
+            // four-term chain a02 P_0, fma(a12, P_1, .), fma(1, P_2, .), fma(0, P_3, .) with the last two written as what they are
+            double fa[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (FGEN) {
+                const v2d a0 = *reinterpret_cast<const v2d*>(sFA + 4 * ag), a1 = *reinterpret_cast<const v2d*>(sFA + 4 * ag + 2);
+                fa[0] = a0.x; fa[1] = a0.y; fa[2] = a1.x; fa[3] = a1.y;   // a02, a12, a03, a13
+            }
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 acc[0][c] = pr[0][c];
                 acc[1][c] = pr[1][c];
+                if constexpr (FGEN) {
+                    acc[2][c] = fma(fa[1], pr[1][c], fa[0] * pr[0][c]) + pr[2][c];
+                    acc[3][c] = fma(fa[3], pr[1][c], fa[2] * pr[0][c]) + pr[3][c];
+                } else {
                 acc[2][c] = fdt * pr[0][c] + pr[2][c];
                 acc[3][c] = fdt * pr[1][c] + pr[3][c];
+                }
                 acc[4][c] = fdt * pr[2][c];
                 acc[5][c] = fdt * pr[3][c];
                 // T2 rows: + mu B[j][c] with B[j][2 ag + q] = dt iff j = 4 ag + 2 + q   (quirk Q6)
@@ -580,6 +614,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
             // [T1;T2] [A|B] with the same patterns: columns 0, 1 of T A are T's, columns 2, 3 are dt T_0 + T_2, dt T_1 + T_3,
             // T B = dt [T_2 T_3]; then the step's l-values, formed here instead of being read
             const double fdt = F.D.dt, wp = F.D.w_prox;
+            double fa2[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (FGEN) {
+                const v2d a0 = *reinterpret_cast<const v2d*>(sFA + 4 * ag), a1 = *reinterpret_cast<const v2d*>(sFA + 4 * ag + 2);
+                fa2[0] = a0.x; fa2[1] = a0.y; fa2[2] = a1.x; fa2[3] = a1.y;
+            }
             // (the Hessian entries of all rows first, from a clamped offset: no load behind a per-lane test)
             v2d hh[RPL];
             const bool with_h = FKA > 1 && f_prox;
@@ -596,7 +635,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
                     tv[2 * q] = v.x; tv[2 * q + 1] = v.y;
                 }
                 acc[0] = tv[0]; acc[1] = tv[1];
+                if constexpr (FGEN) {   // columns 2, 3 of T A: the chain over A's rows 0, 1, then the unit entry (see S1)
+                    acc[2] = fma(tv[1], fa2[1], tv[0] * fa2[0]) + tv[2];
+                    acc[3] = fma(tv[1], fa2[3], tv[0] * fa2[2]) + tv[3];
+                } else {
                 acc[2] = tv[0] * fdt + tv[2]; acc[3] = tv[1] * fdt + tv[3];
+                }
                 acc[4] = tv[2] * fdt; acc[5] = tv[3] * fdt;
 #pragma unroll
                 for (int c = 0; c < NSC; ++c) lv[c] = lvc[r][c];
@@ -833,6 +877,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
         for (int i = 0; i < 7; ++i) stamps[4 * B + 8 * slot + i] = ph[i];
 #endif
     }
+}
+
+template <int N, int M, int WAVES, int NS, int NC, bool FUSED = false>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
+    int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
+    double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
+    riccati_mfma_sweep<N, M, WAVES, NS, NC, (FUSED ? 1 : 0)>(B, T, tiles, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus, F);
+}
+
+// The record-free sweep's general form for the four-state family (FUSED = 2 above): at most five agents of one model --
+// DoubleIntDynamics4D or UnicycleDynamics4D -- with per-agent, per-item weights.
+template <int N, int M, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma_general(
+    int B, int T, const double* __restrict__ mu_arr, double* __restrict__ Kout, double* __restrict__ dout,
+    int32_t* __restrict__ singular, const int32_t* __restrict__ items, const int32_t* __restrict__ n_items, int gains_by_item,
+    int n_cus, FusedArgs F) {
+    riccati_mfma_sweep<N, M, WAVES, 4, 2, 2>(B, T, nullptr, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus, F);
 }
 
 }  // namespace dpilqr

@@ -163,6 +163,27 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
         DPILQR_TILED_SIZES(DPILQR_TRY_FUSED)
     }
 #undef DPILQR_TRY_FUSED
+    // the general form for the four-state family (FUSED == 2): UnicycleDynamics4D, per-agent / per-item weights
+#define DPILQR_TRY_FUSED2(NN, MM)                                                                                  \
+    if (n == NN && m == MM) {                                                                                      \
+        using CF = MfmaCfg<NN, MM, 2>;                                                                             \
+        const int wv = (grid_items > 1024 && max_wv >= 8) ? 8 : 4;                                                 \
+        g_sweep_waves = wv;                                                                                        \
+        const size_t lds_t = sizeof(double) * CF::total * wv;                                                      \
+        auto kern = wv == 8 ? k_riccati_mfma_general<NN, MM, 8> : k_riccati_mfma_general<NN, MM, 4>;               \
+        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
+        if (rc_t) return rc_t;                                                                                     \
+        const int cus = device_cus();                                                                              \
+        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, D.B, D.T, mu, K, d, singular, items,         \
+                           n_items, gains_by_item, cus, FusedArgs{D, X, U});                                       \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+    if (fused_wavefront_general_applies(D)) {
+        DPILQR_TILED_SIZES(DPILQR_TRY_FUSED2)
+    }
+#undef DPILQR_TRY_FUSED2
     // larger clusters: the workgroup sweep, fused (riccati_wg.hpp): any models of the four- or six-state family
 #define DPILQR_TRY_WGF(KK, NS_, NC_)                                                                                \
     if (D.n_s == NS_ && D.n_c == NC_ && D.k == KK) {                                                                \

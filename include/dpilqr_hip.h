@@ -169,9 +169,11 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
 /* The same backward pass without tile records ("fused variant"): the sweep evaluates linearize / quadraticize
  * itself and reads only (X, U).  Gains are bit-identical to dpilqr_backward_pass.  Served: (a) batches whose descriptor hints
  * say "DoubleIntDynamics4D agents only (at most five), n_dims = 2 everywhere, one Q, R, Q_f for every agent of every item"
- * (12 KB instead of 535 KB per cfg2 pass); (b) 6..15 agents of the four-state family or 2..10 of the six-state family, any
+ * (12 KB instead of 535 KB per cfg2 pass); (a') at most five agents of ONE model of the four-state family -- DoubleIntDynamics4D
+ * or UnicycleDynamics4D, the descriptor's model hint -- with n_dims = 2 everywhere and ANY per-agent, per-item Q, R, Q_f;
+ * (b) 6..15 agents of the four-state family or 2..10 of the six-state family, any
  * models of the family, any weights (cfg3 / cfg4 clusters: 90 doubles instead of a 94 KB record per step at n_x = 60).
- * DPILQR_EUNSUPPORTED for any other batch.  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
+ * DPILQR_EUNSUPPORTED for any other batch (mixed models or CarDynamics3D at n_x <= 20, twelve-state agents).  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
 int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
                                    double* d, int32_t* singular, void* stream);
 /* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:

@@ -586,12 +586,39 @@ def test_fused_sweep_is_bit_identical_to_the_record_fed_sweep(dp, k, B):
     K0, d0 = pb.backward_pass(X, U0, mu)
     K1, d1 = pb.backward_pass_fused(X, U0, mu)
     assert torch.equal(K0, K1) and torch.equal(d0, d1)
-    # per-agent weights that differ: the fused sweep must refuse, not silently use the first agent's
+    # per-agent weights that differ: the general form of the fused sweep serves them (it must not silently use the first agent's)
     if k > 1:
         Qk = np.stack([Q * (1 + 0.1 * i) for i in range(k)])
         pb2 = dp.ProblemBatch([0] * k, [2] * k, xf, Qk, R, Qf, 0.5, 0.1, T)
-        with pytest.raises(dp._lib.DpilqrError):
-            pb2.backward_pass_fused(X, U0, mu)
+        K2, d2 = pb2.backward_pass(X, U0, mu)
+        K3, d3 = pb2.backward_pass_fused(X, U0, mu)
+        assert torch.equal(K2, K3) and torch.equal(d2, d3) and not torch.equal(K2, K0)
+
+
+@pytest.mark.parametrize("model,k,B", [(3, 5, 2600), (3, 5, 700), (3, 4, 1500), (3, 3, 300), (3, 2, 1100), (3, 1, 333), (0, 5, 1300), (0, 3, 90)])
+def test_fused_general_wavefront_sweep_is_bit_identical_to_the_record_fed_sweep(dp, model, k, B):
+    """The general form of the record-free wavefront sweep (k_riccati_mfma_general: UnicycleDynamics4D or
+    DoubleIntDynamics4D agents, per-agent AND per-item non-symmetric weights, per-item radii and mu) against the record-fed sweep
+    on the tile producer's records: same gains bit for bit, both wavefront layouts (B > 1024, smaller), states where agents are
+    inside each other's radius and the unicycles' headings and speeds are spread."""
+    import torch
+    from dpilqr_amd.device import to_dev
+    T = 16
+    rng = np.random.default_rng(500 + 10 * model + k)
+    x0 = rng.normal(size=(B, 4 * k)) * 0.6; xf = rng.normal(size=(B, 4 * k))
+    if model == 3:
+        x0[:, 3::4] = rng.uniform(-3.5, 3.5, size=(B, k))          # headings over more than a full turn
+    U0 = rng.normal(size=(B, T, 2 * k)) * 0.4
+    Q = np.stack([np.stack([np.diag(rng.uniform(0.2, 2.0, size=4)) + 0.1 * rng.normal(size=(4, 4)) for _ in range(k)]) for _ in range(B)])
+    R = np.stack([np.stack([np.diag(rng.uniform(0.5, 2.0, size=2)) + 0.1 * rng.normal(size=(2, 2)) for _ in range(k)]) for _ in range(B)])
+    Qf = np.stack([30.0 * np.eye(4) + rng.normal(size=(4, 4)) for _ in range(k)])
+    pb = dp.ProblemBatch([model] * k, [2] * k, xf, Q, R, Qf, rng.uniform(0.3, 0.9, size=B), 0.1, T)
+    X, _ = pb.rollout(x0, U0)
+    mu = to_dev(rng.choice([0.0, 0.125, 1.0], size=B))
+    K0, d0 = pb.backward_pass(X, U0, mu)
+    K1, d1 = pb.backward_pass_fused(X, U0, mu)
+    assert bool(torch.isfinite(K0).all())
+    assert torch.equal(K0, K1) and torch.equal(d0, d1), (float((K0 - K1).abs().max()), float((d0 - d1).abs().max()))
 
 
 @pytest.mark.parametrize("family,k,B", [(4, 6, 300), (4, 9, 700), (4, 12, 260), (4, 15, 520), (6, 2, 300), (6, 5, 900), (6, 8, 260),
