@@ -145,6 +145,8 @@ class ProblemBatch:
         Qk, Rk, Qfk = (np.asarray(expand(M_, n_)) for M_, n_ in ((Q, ns), (R, nc), (Qf, ns)))
         if qs == 0 and rs == 0 and fs == 0 and all(M_.ndim == 3 and bool((M_ == M_[0]).all()) for M_ in (Qk, Rk, Qfk)):
             uniform |= 1 << 16                                       # one Q, R, Q_f for every agent of every item
+        if bool(np.isin(np.asarray(model), (0, 3)).all()):
+            uniform |= 1 << 17                                       # DoubleIntDynamics4D / UnicycleDynamics4D agents only
         self.desc = _lib.BatchDesc(B_, k, ns, nc, self.T, uniform, self.dt, self.w_ref, self.w_prox,
                                    ptr(self._model), ms, ptr(self._n_dims), ds, ptr(self._xf), xs,
                                    ptr(self._Q), qs, ptr(self._R), rs, ptr(self._Qf), fs, ptr(self._radius), ras)
@@ -183,6 +185,8 @@ class ProblemBatch:
             w |= (1 + int(nd.reshape(-1)[0])) << 8
         if all(np.asarray(M).ndim == 3 and bool((np.asarray(M) == np.asarray(M)[0]).all()) for M in (Q, R, Qf)):
             w |= 1 << 16
+        if model.size and bool(np.isin(model, (0, 3)).all()):
+            w |= 1 << 17                                             # DoubleIntDynamics4D / UnicycleDynamics4D agents only
         return w
 
     # ------------------------------------------------------------------ helpers

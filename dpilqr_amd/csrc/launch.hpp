@@ -51,6 +51,7 @@ int device_cus();
 inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
 inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
 inline bool hint_shared_weights(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 16) & 1) != 0; }
+inline bool hint_planar4(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 17) & 1) != 0 || hint_model(D) == 0 || hint_model(D) == 3; }
 // The fused sweeps (no tile records: linearize / quadraticize evaluated inside the sweep).
 // Wavefront sweep (n_x <= 20, riccati_mfma.hpp): DoubleIntDynamics4D agents only, planar proximity cost, one Q / R / Q_f for
 // every agent of every item (the descriptor's hints), at most five agents.
@@ -59,12 +60,12 @@ inline bool fused_wavefront_sweep_applies(const dpilqr_batch_desc& D) {
     return !off && hint_model(D) == 0 && hint_n_dims(D) == 2 && hint_shared_weights(D) && D.Q_bstride == 0 && D.R_bstride == 0 &&
            D.Qf_bstride == 0 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
 }
-// ... and its general form (FUSED == 2): at most five agents of ONE model of the four-state family -- DoubleIntDynamics4D or
-// UnicycleDynamics4D (the descriptor's hint) -- with any per-agent, per-item Q / R / Q_f, planar proximity cost.  Two wavefronts
-// per SIMD at most (the per-agent weights take the LDS the third one needs).
+// ... and its general form (k_riccati_mfma_general, FUSED == 2): at most five agents of the planar four-state models --
+// DoubleIntDynamics4D and UnicycleDynamics4D, mixed or not (the descriptor's hints) -- with any per-agent, per-item Q / R / Q_f,
+// planar proximity cost.  Two wavefronts per SIMD at most (the per-agent weights take the LDS the third one needs).
 inline bool fused_wavefront_general_applies(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_GENERAL") != nullptr;
-    return !off && (hint_model(D) == 0 || hint_model(D) == 3) && hint_n_dims(D) == 2 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
+    return !off && hint_planar4(D) && hint_n_dims(D) == 2 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
 }
 // Workgroup sweep (riccati_wg.hpp): 6..15 agents of the four-state family or 2..10 of the six-state family -- any models of
 // the family, any per-agent weights, any n_dims.

@@ -143,8 +143,15 @@ class ScenarioFrontEnd:
                 _lib.check(self.lib.dpilqr_dispatch_gather_params(cnt, kc, width, eb, ptr(members), ptr(self.dev_params[key]),
                                                                   ptr(out), stream_handle()))
                 g[key] = out
+            # hints that hold for every subset of the agents: one n_dims for all of them; DoubleInt4D / Unicycle4D agents only
+            word = 0
+            nd_all = np.asarray(d["n_dims"], dtype=np.int32)
+            if bool((nd_all == nd_all[0]).all()):
+                word |= (1 + int(nd_all[0])) << 8
+            if bool(np.isin(np.asarray(d["model"]), (0, 3)).all()):
+                word |= 1 << 17
             pb = ProblemBatch(g["model"], g["n_dims"], xfb, g["Q"], g["R"], g["Qf"], d["radius"], d["dt"], T, w_ref=d["w_ref"],
-                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, 0))
+                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, word))
         return pb, x0, U0
 
     def results_struct(self, solved):

@@ -85,8 +85,9 @@ typedef struct dpilqr_batch_desc {
     int32_t uniform_model; /* hints, 0 = unknown / mixed (always valid).  Bits 0..7: 1 + Model enum when EVERY agent of
                               EVERY item uses that model; bits 8..15: 1 + n_dims when every agent of every item has
                               that ProximityCost.n_dims; bit 16: every agent has the same Q, the same R and the same Q_f
-                              (and their batch strides are 0).  They let the solver pick kernels compiled per model and
-                              skip work that cannot depend on the item.                                         */
+                              (and their batch strides are 0); bit 17: every agent of every item is a DoubleIntDynamics4D
+                              or a UnicycleDynamics4D (models may be mixed).  They let the solver pick kernels compiled
+                              per model and skip work that cannot depend on the item.                           */
     double dt;     /* DynamicalModel.dt                                          */
     double w_ref;  /* GameCost.REF_WEIGHT  = 1   (cost.py:185)                   */
     double w_prox; /* GameCost.PROX_WEIGHT = 200 (cost.py:186)                   */
@@ -169,11 +170,12 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
 /* The same backward pass without tile records ("fused variant"): the sweep evaluates linearize / quadraticize
  * itself and reads only (X, U).  Gains are bit-identical to dpilqr_backward_pass.  Served: (a) batches whose descriptor hints
  * say "DoubleIntDynamics4D agents only (at most five), n_dims = 2 everywhere, one Q, R, Q_f for every agent of every item"
- * (12 KB instead of 535 KB per cfg2 pass); (a') at most five agents of ONE model of the four-state family -- DoubleIntDynamics4D
- * or UnicycleDynamics4D, the descriptor's model hint -- with n_dims = 2 everywhere and ANY per-agent, per-item Q, R, Q_f;
+ * (12 KB instead of 535 KB per cfg2 pass); (a') at most five agents of the planar four-state models -- DoubleIntDynamics4D
+ * and UnicycleDynamics4D, mixed or not (the descriptor's model hint or its bit 17) -- with n_dims = 2 everywhere and ANY
+ * per-agent, per-item Q, R, Q_f;
  * (b) 6..15 agents of the four-state family or 2..10 of the six-state family, any
  * models of the family, any weights (cfg3 / cfg4 clusters: 90 doubles instead of a 94 KB record per step at n_x = 60).
- * DPILQR_EUNSUPPORTED for any other batch (mixed models or CarDynamics3D at n_x <= 20, twelve-state agents).  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
+ * DPILQR_EUNSUPPORTED for any other batch (CarDynamics3D and six-state agents at n_x <= 20, twelve-state agents).  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
 int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
                                    double* d, int32_t* singular, void* stream);
 /* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:

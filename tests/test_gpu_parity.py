@@ -595,10 +595,11 @@ def test_fused_sweep_is_bit_identical_to_the_record_fed_sweep(dp, k, B):
         assert torch.equal(K2, K3) and torch.equal(d2, d3) and not torch.equal(K2, K0)
 
 
-@pytest.mark.parametrize("model,k,B", [(3, 5, 2600), (3, 5, 700), (3, 4, 1500), (3, 3, 300), (3, 2, 1100), (3, 1, 333), (0, 5, 1300), (0, 3, 90)])
+@pytest.mark.parametrize("model,k,B", [(3, 5, 2600), (3, 5, 700), (3, 4, 1500), (3, 3, 300), (3, 2, 1100), (3, 1, 333), (0, 5, 1300), (0, 3, 90),
+                                       (-1, 5, 1400), (-1, 4, 600), (-1, 2, 200)])
 def test_fused_general_wavefront_sweep_is_bit_identical_to_the_record_fed_sweep(dp, model, k, B):
     """The general form of the record-free wavefront sweep (k_riccati_mfma_general: UnicycleDynamics4D or
-    DoubleIntDynamics4D agents, per-agent AND per-item non-symmetric weights, per-item radii and mu) against the record-fed sweep
+    DoubleIntDynamics4D agents or a mix of both, per-agent AND per-item non-symmetric weights, per-item radii and mu) against the record-fed sweep
     on the tile producer's records: same gains bit for bit, both wavefront layouts (B > 1024, smaller), states where agents are
     inside each other's radius and the unicycles' headings and speeds are spread."""
     import torch
@@ -606,19 +607,23 @@ def test_fused_general_wavefront_sweep_is_bit_identical_to_the_record_fed_sweep(
     T = 16
     rng = np.random.default_rng(500 + 10 * model + k)
     x0 = rng.normal(size=(B, 4 * k)) * 0.6; xf = rng.normal(size=(B, 4 * k))
-    if model == 3:
+    models = [model] * k if model >= 0 else [(3 if a % 2 == 0 else 0) for a in range(k)]       # -1: unicycles and integrators mixed
+    if model != 0:
         x0[:, 3::4] = rng.uniform(-3.5, 3.5, size=(B, k))          # headings over more than a full turn
     U0 = rng.normal(size=(B, T, 2 * k)) * 0.4
     Q = np.stack([np.stack([np.diag(rng.uniform(0.2, 2.0, size=4)) + 0.1 * rng.normal(size=(4, 4)) for _ in range(k)]) for _ in range(B)])
     R = np.stack([np.stack([np.diag(rng.uniform(0.5, 2.0, size=2)) + 0.1 * rng.normal(size=(2, 2)) for _ in range(k)]) for _ in range(B)])
     Qf = np.stack([30.0 * np.eye(4) + rng.normal(size=(4, 4)) for _ in range(k)])
-    pb = dp.ProblemBatch([model] * k, [2] * k, xf, Q, R, Qf, rng.uniform(0.3, 0.9, size=B), 0.1, T)
+    pb = dp.ProblemBatch(models, [2] * k, xf, Q, R, Qf, rng.uniform(0.3, 0.9, size=B), 0.1, T)
     X, _ = pb.rollout(x0, U0)
     mu = to_dev(rng.choice([0.0, 0.125, 1.0], size=B))
     K0, d0 = pb.backward_pass(X, U0, mu)
     K1, d1 = pb.backward_pass_fused(X, U0, mu)
     assert bool(torch.isfinite(K0).all())
     assert torch.equal(K0, K1) and torch.equal(d0, d1), (float((K0 - K1).abs().max()), float((d0 - d1).abs().max()))
+    if model < 0 and k >= 2:       # a six-state agent among them is not this sweep's: refused, not mis-solved
+        with pytest.raises((dp._lib.DpilqrError, ValueError)):
+            dp.ProblemBatch([3, 4] + [0] * (k - 2), [2] * k, xf, Q, R, Qf, 0.5, 0.1, T).backward_pass_fused(X, U0, mu)
 
 
 @pytest.mark.parametrize("family,k,B", [(4, 6, 300), (4, 9, 700), (4, 12, 260), (4, 15, 520), (6, 2, 300), (6, 5, 900), (6, 8, 260),
