@@ -277,10 +277,13 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
     using D = ModelDef<M>;
     constexpr int NS = D::NS;
     const R dh = dt / 5;
+    constexpr int kSubUnroll = (M == kDoubleInt4D) ? 5 : 1;
     R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) xn[i] = x[i];
-#pragma unroll 1
+    // (the double integrator's five sub-steps unrolled: a dozen instructions each -- line search -1..2 %, rollout -7 %; the models
+    // with trigonometry keep the loop: their stage evaluations are hundreds of instructions)
+#pragma unroll kSubUnroll
     for (int s = 0; s < 5; ++s) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) xa[i] = xn[i];
