@@ -145,3 +145,21 @@ def test_graph_neighbours_are_numpy_ints_like_the_references(golden):
         assert members == sorted(members) and id_ in members
         for v in members:
             assert isinstance(v, int) if v == id_ else isinstance(v, np.integer)
+
+
+def test_descriptor_hints_of_a_batch():
+    """The uniform_model word of include/dpilqr_hip.h as ProblemBatch.hint_word packs it from host arrays: model (bits 0-7), n_dims
+    (8-15), shared weights (16), "DoubleIntDynamics4D / UnicycleDynamics4D agents only" (17: what lets the record-free wavefront
+    sweep serve mixed planar clusters)."""
+    from dpilqr_amd.batch import ProblemBatch
+    Q = np.broadcast_to(np.eye(4), (3, 4, 4)); R = np.broadcast_to(np.eye(2), (3, 2, 2))
+    w = ProblemBatch.hint_word([0, 0, 0], [2, 2, 2], Q, R, Q)
+    assert w & 0xff == 1 and (w >> 8) & 0xff == 3 and (w >> 16) & 1 == 1 and (w >> 17) & 1 == 1
+    w = ProblemBatch.hint_word([3, 0, 3], [2, 2, 2], Q, R, Q)            # unicycles and integrators mixed
+    assert w & 0xff == 0 and (w >> 8) & 0xff == 3 and (w >> 17) & 1 == 1
+    Qd = np.stack([np.eye(4) * (1 + i) for i in range(3)])
+    w = ProblemBatch.hint_word([3, 3, 3], [2, 2, 2], Qd, R, Q)            # per-agent weights
+    assert w & 0xff == 4 and (w >> 16) & 1 == 0 and (w >> 17) & 1 == 1
+    Q6 = np.broadcast_to(np.eye(6), (2, 6, 6)); R3 = np.broadcast_to(np.eye(3), (2, 3, 3))
+    w = ProblemBatch.hint_word([4, 1], [3, 2], Q6, R3, Q6)                # six-state agents, mixed n_dims
+    assert w & 0xff == 0 and (w >> 8) & 0xff == 0 and (w >> 17) & 1 == 0
