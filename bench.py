@@ -18,8 +18,9 @@ and the collective warmed on them outside the clock).
 The timed K-step job is REPEATED --reps times (default 5) on disjoint seeds inside one invocation; `value` and
 `ms_per_step` are the MEDIAN repetition (max over ranks each), the spread is reported beside them (`repetitions`).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+A rank count that is not --gpus, or fewer visible GPUs than ranks (RCCL), ends the run with a non-zero exit code.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -146,6 +147,54 @@ def _read(path):
         return "n/a"
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N child ranks of this very command line (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, what torch.distributed.run would set), let rank 0's JSON line through on the
+    inherited stdout and return non-zero as soon as any rank fails (the others are then stopped: a rank alone would wait in
+    its first collective for ever).  Replaces multiprocessing.Pool of the reference's distributed.py:80-97 at job level."""
+    import signal
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), start_new_session=True))
+    rc = 0
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} of {n} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in live:          # exact process groups we started, nothing by pattern
+                        try:
+                            os.killpg(procs[q].pid, signal.SIGTERM)
+                        except ProcessLookupError:
+                            pass
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in live:
+            try:
+                os.killpg(procs[q].pid, signal.SIGTERM)
+            except ProcessLookupError:
+                pass
+        rc = 130
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,16 +212,27 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks, one per GPU, BEFORE anything here
+        # has imported torch or touched a GPU (a process that has initialised HIP must never be replaced or forked)
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the rank count is not the one asked for")
     # DPILQR_BENCH_BACKEND=gloo (diagnostic): the N > 1 code path with gloo instead of RCCL, every rank on whatever GPU its
     # LOCAL_RANK maps to modulo the visible ones -- how the multi-rank path is exercised on a one-GPU box (tests/test_gpu_api.py)
     backend = os.environ.get("DPILQR_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise HIP
+    if backend == "nccl" and world > 1 and n_dev < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, one per rank over RCCL; this node shows {n_dev} "
+                         "(DPILQR_BENCH_BACKEND=gloo runs the multi-rank path with several ranks per GPU: a diagnostic, not a measurement)")
+    local_rank = local_rank % max(n_dev, 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -183,10 +183,24 @@ PROGRESS_FN = C.CFUNCTYPE(None, vp, i32, i32)
 
 class progress_callback:
     """with progress_callback(fn): ... -- fn(n_finished, n_items) is called from inside this thread's synchronous solves as
-    a prefix of the batch finishes (dpilqr_solver_set_progress)."""
+    a prefix of the batch finishes (dpilqr_solver_set_progress).
+
+    ctypes swallows an exception raised inside a callback (it only prints it), and ranks whose callbacks issue collectives
+    would then have issued different numbers of them: the first exception is kept, later calls of the callback do nothing,
+    and leaving the `with` block re-raises it -- after the solve has returned, so no kernel is left queued behind the error."""
 
     def __init__(self, fn):
-        self._c = PROGRESS_FN(lambda user, done, total: fn(int(done), int(total))) if fn is not None else None
+        self.error = None
+
+        def call(user, done, total):
+            if self.error is not None:
+                return
+            try:
+                fn(int(done), int(total))
+            except BaseException as e:          # noqa: BLE001 -- must not escape into the C caller
+                self.error = e
+
+        self._c = PROGRESS_FN(call) if fn is not None else None
 
     def __enter__(self):
         if self._c is not None:
@@ -196,6 +210,8 @@ class progress_callback:
     def __exit__(self, *exc):
         if self._c is not None:
             check(load().dpilqr_solver_set_progress(solver(), None, None))
+        if self.error is not None and exc[0] is None:
+            raise self.error
         return False
 
 

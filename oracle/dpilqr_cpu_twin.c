@@ -255,7 +255,7 @@ int32_t dpilqr_alphas(double *a)
     return DPILQR_OK;
 }
 int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc *D, int32_t w, int32_t g) { (void)D; (void)w; (void)g; return 8; }
-struct dpilqr_solver { int unused; };
+struct dpilqr_solver { dpilqr_progress_fn progress; void *progress_user; };
 int32_t dpilqr_solver_create(dpilqr_solver **out)
 {
     if (!out) return fail(DPILQR_EINVAL, "solver_create: NULL pointer");
@@ -263,12 +263,19 @@ int32_t dpilqr_solver_create(dpilqr_solver **out)
     return DPILQR_OK;
 }
 int32_t dpilqr_solver_destroy(dpilqr_solver *sv) { free(sv); return DPILQR_OK; }
-int32_t dpilqr_solver_set_progress(dpilqr_solver *sv, dpilqr_progress_fn fn, void *user) { (void)sv; (void)fn; (void)user; return DPILQR_OK; }
+static _Thread_local dpilqr_solver default_solver;       /* solver = NULL: the calling thread's default solver (header) */
+int32_t dpilqr_solver_set_progress(dpilqr_solver *sv, dpilqr_progress_fn fn, void *user)
+{
+    if (!sv) sv = &default_solver;
+    sv->progress = fn; sv->progress_user = user;
+    return DPILQR_OK;
+}
 int32_t dpilqr_solve_batch(dpilqr_solver *sv, const dpilqr_batch_desc *D, const double *x0, double *U, int32_t n_lqr_iter, double tol,
                            int32_t window, void *ws, int64_t ws_bytes, double *X, double *J, int32_t *status, int32_t *n_bwd,
                            int32_t *n_fwd, double *trace, double *K_out, double *d_out, void *s)
 {
-    (void)sv; (void)window; (void)ws; (void)ws_bytes; (void)s;
+    (void)window; (void)ws; (void)ws_bytes; (void)s;
+    if (!sv) sv = &default_solver;
     if (check_desc(D) || !x0 || !U || !X || !J || !status || !n_bwd || !n_fwd) return fail(DPILQR_EINVAL, "solve_batch: bad argument");
     if (K_out || d_out) return fail(DPILQR_EUNSUPPORTED, "solve_batch: the CPU twin does not return the last gains");
     const int n = D->k * D->n_s, m = D->k * D->n_c, T = D->T;
@@ -280,6 +287,7 @@ int32_t dpilqr_solve_batch(dpilqr_solver *sv, const dpilqr_batch_desc *D, const 
                                  trace ? trace + (size_t)b * (n_lqr_iter > 0 ? n_lqr_iter : 1) * 5 : NULL, &nb, &nf);
         n_bwd[b] = nb; n_fwd[b] = nf;
     }
+    if (sv->progress) sv->progress(sv->progress_user, D->B, D->B);      /* the header's "a last time with n_finished = n_items" */
     return DPILQR_OK;
 }
 int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, const double *X, const double *radius, int32_t *adj, void *s)

@@ -7,12 +7,16 @@ set -e
 tag=$1; unit=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/dpilqr_amd/variants $root/build/variants
-python $root/__graft_entry__.py > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$root/include -I$root/dpilqr_amd/csrc "$@" \
-    -c -o $root/build/variants/${unit}_$tag.o $root/dpilqr_amd/csrc/$unit.hip
+# every translation unit's object must exist and be current (build() alone compiles nothing when the linked library is newer
+# than the sources, and objects do not travel to the GPU box)
+flags=$(cd $root && python -c "import __graft_entry__ as g; g.build(need_objects=True); print(' '.join(g.HIPCC_FLAGS))" | tail -1)
+/opt/rocm/bin/hipcc $flags "$@" -c -o $root/build/variants/${unit}_$tag.o $root/dpilqr_amd/csrc/$unit.hip
 objs=""
-for o in $root/build/obj/*.o; do
-  if [ "$(basename $o .o)" == "$unit" ]; then objs="$objs $root/build/variants/${unit}_$tag.o"; else objs="$objs $o"; fi
+for src in $root/dpilqr_amd/csrc/*.hip; do
+  u=$(basename $src .hip); o=$root/build/obj/$u.o
+  if [ "$u" == "$unit" ]; then objs="$objs $root/build/variants/${unit}_$tag.o"; continue; fi
+  if [ ! -f $o ] || [ $o -ot $src ]; then echo "build_variant.sh: object $o is missing or older than its source" >&2; exit 1; fi
+  objs="$objs $o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/dpilqr_amd/variants/libdpilqr_hip_$tag.so $objs
 echo $root/dpilqr_amd/variants/libdpilqr_hip_$tag.so

@@ -157,7 +157,12 @@ def test_solve_batch_through_the_abi(twin, golden):
     trace = np.zeros((B, n_iter, 5))
     sv = C.c_void_p()
     assert L.dpilqr_solver_create(C.byref(sv)) == 0
+    seen = []
+    cb = _lib.PROGRESS_FN(lambda user, done, total: seen.append((done, total)))
+    assert L.dpilqr_solver_set_progress(sv, C.cast(cb, C.c_void_p), None) == 0
     assert L.dpilqr_solve_batch(sv, D.ref(), hp(x0), hp(U), n_iter, 1e-3, 0, None, 0, hp(X), hp(J), hp(st), hp(nb), hp(nf), hp(trace), None, None, None) == 0
+    assert seen and seen[-1] == (B, B)         # the header: "a last time with n_finished = n_items"
+    assert L.dpilqr_solver_set_progress(sv, None, None) == 0
     assert L.dpilqr_solver_destroy(sv) == 0
     for i, s in enumerate(seeds):
         pre = f"s{s}_"

@@ -564,10 +564,17 @@ def test_progress_reports_and_chunked_gather_world1(dp):
     for _ in range(2):                                   # the buffers are reused job after job
         calls = []
 
+        side = torch.cuda.Stream()
+
         def prog(n, total):
-            # what is reported finished IS final: compare the prefix's X with the reference right now, on a side stream
-            calls.append((n, total, bool(torch.equal(rb.out["status"][:n], ref["status"][:n]))))
+            # what is reported finished IS final AT CALLBACK TIME: the chunk gather is issued first, with no synchronisation of the
+            # solve's stream (which still has look-ahead iterations queued), then the prefix's X, U and status are snapshotted
+            # by a side stream that waits for nothing; the snapshots are compared with the plain solve after this one has ended
             rb.progress(n, total)
+            with torch.cuda.stream(side):
+                lo = calls[-1][0] if calls else 0
+                snap = (rb.out["X"][lo:n].clone(), rb.out["U"][lo:n].clone(), rb.out["status"][lo:n].clone())
+            calls.append((n, total, lo, snap))
 
         rb.begin()
         r = pb.solve(x0, U0, window=512, out=rb.out, progress=prog)
@@ -577,8 +584,11 @@ def test_progress_reports_and_chunked_gather_world1(dp):
         for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
             assert torch.equal(g[key][0], ref[key]), key
             assert torch.equal(r[key], ref[key]), key
-        ns = [n for n, _, _ in calls]
-        assert ns == sorted(ns) and ns[-1] == B and all(t == B for _, t, _ in calls) and all(ok for _, _, ok in calls)
+        ns = [c_[0] for c_ in calls]
+        assert ns == sorted(ns) and ns[-1] == B and all(c_[1] == B for c_ in calls)
+        for n, _, lo, (sx, su, ss) in calls:
+            assert torch.equal(sx, ref["X"][lo:n]) and torch.equal(su, ref["U"][lo:n]) and torch.equal(ss, ref["status"][lo:n]), \
+                f"items {lo}..{n} were reported finished before their results were final"
         assert len([n for n in ns if 0 < n < B]) >= 2    # progress was reported while the solve was still running
 
 
@@ -606,3 +616,42 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and len(d["repetitions"]["ms_per_step"]) == 2
     assert "all-gather in chunks of 512" in d["config"]["parallelism"]
+
+
+def _run_bench(args, env_extra, timeout=900):
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, str(root / "bench.py"), *args], env=env, capture_output=True, text=True,
+                          timeout=timeout, cwd=str(root))
+
+
+def test_plain_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in front (the driver's command shape for N = 1, extended to N): bench.py
+    starts its own two ranks before anything touches the GPU and rank 0's line says n_gpus = 2 (gloo, both ranks on the one GPU
+    of this box: the multi-rank path as a diagnostic)."""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "2", "--gather-chunk", "512", "--no-cpu-baseline"],
+                     {"DPILQR_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["launches"] > 0
+    assert "cpu_baseline" not in d                       # N = 1 only
+    assert "batch-sharded x2" in d["config"]["parallelism"]
+
+
+def test_plain_bench_gpus_2_on_one_gpu_over_rccl_fails_loudly():
+    """Without the diagnostic backend two ranks need two GPUs: on a one-GPU box the run must end non-zero with a message that
+    says so -- never a silent one-GPU line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two GPUs")
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--reps", "1", "--no-cpu-baseline"], {}, timeout=300)
+    assert out.returncode != 0
+    assert "needs 2 visible GPUs" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

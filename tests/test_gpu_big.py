@@ -180,7 +180,7 @@ def test_cfg5_whole_solves_at_the_stated_size(dp, hetero, seeds):
     r = {k: v.cpu().numpy() for k, v in pb.solve(x0, U0, n_lqr_iter=6, trace=True).items()}
     proto = orc.Problem(models, nd, xf[0], Q, R, Qf, 0.5, 0.1, T)
     o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=6, trace=True)
-    rep = parity.envelope(r, proto, x0, xf, U0, n_lqr_iter=6, natural=o, deltas=(1e-13, -1e-13, 5e-13, -5e-13), escalate=None)
+    rep = parity.envelope(r, proto, x0, xf, U0, n_lqr_iter=6, natural=o, deltas=(1e-13, -1e-13, 5e-13, -5e-13))
     sm = rep["summary"]
     print(sm, "n_bwd", r["n_bwd"], "oracle", o["n_bwd"], "status", r["status"])
     assert sm["all_ok"], (sm, [w for w in rep["why"] if w])
