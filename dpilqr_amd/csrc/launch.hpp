@@ -84,7 +84,9 @@ inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
 // six unicycles 86.2 -> 80.6, six double integrators 23.8 -> 21.3.  DPILQR_NO_WAVE_PREF: A/B switch.
 inline bool solve_prefers_records(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_WAVE_PREF") != nullptr;
-    return !off && ((D.n_s == 6 && D.n_c == 3 && (D.k == 2 || D.k == 4)) || (D.n_s == 4 && D.n_c == 2 && D.k == 6));
+    // round 4: three six-state agents (n_x = 18: 16 % of cfg4's sub-problems) through the (20, 10) wavefront sweep, padded
+    // while loading (riccati_mfma.hpp, PAD; DPILQR_RICCATI_NO_PAD switches it off in the launcher)
+    return !off && ((D.n_s == 6 && D.n_c == 3 && (D.k == 2 || D.k == 3 || D.k == 4)) || (D.n_s == 4 && D.n_c == 2 && D.k == 6));
 }
 
 // ---- tu_tiles.hip

@@ -274,13 +274,22 @@ struct FusedArgs {
 };
 
 // (The sweep's body, shared by the two kernels below: FUSED 0 tile records, 1 the DoubleInt4D form, 2 the general four-state form.)
-template <int N, int M, int WAVES, int NS, int NC, int FUSED>
+// PAD (dense record-fed form only): the records and the gains have the sizes n_rec <= N, m_rec <= M of a cluster that has no
+// instantiation of its own (n_x not a multiple of 4: three six-state agents, CarDynamics3D; or tiny: one six-state agent) and
+// the sweep pads them WHILE LOADING into a decoupled (N, M) problem: A = 1 on the diagonal of the padded states, B = 0 in
+// their rows and in the padded controls' columns, no cost on padded states, unit L_uu on the diagonal of padded controls.
+// Then P, p, Q_ux stay exact zeros in the padded rows and columns, Q_uu is [Q_uu 0; 0 I] (partial pivoting never picks a
+// padded row: its entries in the real columns are zeros), the padded rows of [K|d] are zeros, and every sum of the real
+// block only gains terms that are exact zeros: the real gains are those of an unpadded sweep.  Only the real m_rec x n_rec
+// block of K[t] and the first m_rec entries of d[t] are stored, in the real layout.
+template <int N, int M, int WAVES, int NS, int NC, int FUSED, bool PAD = false>
 __device__ __forceinline__ void riccati_mfma_sweep(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
+    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F, int n_rec = N, int m_rec = M) {
     using C = MfmaCfg<N, M, FUSED>;
     static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variants are written for the four-state family's blocks");
+    static_assert(!PAD || (NS == 0 && FUSED == 0), "padding while loading is written for the dense record-fed form");
     constexpr bool FGEN = (FUSED == 2);   // per-agent weights, per-agent model (DoubleIntDynamics4D / UnicycleDynamics4D)
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
     constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
@@ -310,7 +319,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     if (b >= B) return;
     const int64_t gslot = gains_by_item ? b : slot;
     const int lane0 = threadIdx.x & 63;
-    const TileLayout L(N, M);
+    const TileLayout L(PAD ? n_rec : N, PAD ? m_rec : M);
 
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds = lds_all + wave * C::total;
@@ -349,7 +358,11 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     v2d nAB[C::AB_ROUNDS];
     double nL[T_NM][T_NM][4];
     double nLxu[T_NM][4];
-    constexpr bool REMAT = (WAVES == 12);   // see riccati_mfma_lane.inc
+    // see riccati_mfma_lane.inc.  PAD at N >= 20: the offset codes of every prefetched element (some forty per lane) must not
+    // be hoisted out of the horizon loop either: kept, they spilled 108 registers at two wavefronts per SIMD (three quadcopters:
+    // 1.63 ms per 2048 items against 0.83 ms).  The smaller sizes have the registers and are faster with the terms kept
+    // (one quadcopter 0.13 against 0.21 ms).
+    constexpr bool REMAT = (WAVES == 12) || (PAD && N >= 20);
     v2d pf[2];   // FUSED: this lane's share of (X[t], U[t]), one step ahead
     bool f_prox = false;   // FUSED: some pair of the current step is within the radius (wave uniform)
     // FUSED: the part of this lane's S2 l-values that does not depend on (X, U) -- w_ref (Q + Q^T), w_ref (R + R^T) on the
@@ -397,9 +410,17 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         const double* rec = base + (int64_t)T * L.stride;
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N;
+            if constexpr (PAD) {
+                const double val = rec[L.oLxx + min(i, n_rec - 1) * n_rec + min(j, n_rec - 1)];
+                sP[i * LP + j] = (i < n_rec && j < n_rec) ? val : 0.0;
+            } else {
             sP[i * LP + j] = rec[L.oLxx + e];
+            }
         }
-        for (int i = lane; i < N; i += 64) sP[i * LP + N] = rec[L.oLx + i];
+        for (int i = lane; i < N; i += 64) {
+            const double val = rec[L.oLx + (PAD ? min(i, n_rec - 1) : i)];
+            sP[i * LP + N] = (!PAD || i < n_rec) ? val : 0.0;
+        }
     }
 
 #include "riccati_mfma_lane.inc"
@@ -763,7 +784,18 @@ __device__ __forceinline__ void riccati_mfma_sweep(
             for (int a = 0; a < M; ++a) s3_k[a * LK] = -v[a];
         }
         DPILQR_LDS_FENCE();
-        {
+        if constexpr (PAD) {   // the real block only, in the real layout (n_rec may be odd: 8-byte stores)
+            double* Kt = Kout + (gslot * T + t) * m_rec * n_rec;
+            double* dt_ = dout + (gslot * T + t) * m_rec;
+            const double* krow = sK + min(lane, N - 1);
+            double kv[M];
+#pragma unroll
+            for (int a = 0; a < M; ++a) kv[a] = krow[a * LK];
+#pragma unroll
+            for (int a = 0; a < M; ++a)   // row by row: n_rec <= 24 lanes each, no division by the run-time row length
+                if (a < m_rec && lane < n_rec) store_f64_nt(Kt + a * n_rec + lane, kv[a]);
+            if (lane < m_rec) store_f64_nt(dt_ + lane, sK[lane * LK + N]);
+        } else {
             double* Kt = Kout + (gslot * T + t) * M * N;
             double* dt_ = dout + (gslot * T + t) * M;
 #pragma unroll
@@ -885,6 +917,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
     riccati_mfma_sweep<N, M, WAVES, NS, NC, (FUSED ? 1 : 0)>(B, T, tiles, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus, F);
+}
+
+// The dense record-fed sweep for cluster sizes without an instantiation of their own: records and gains of size (n_rec, m_rec),
+// padded into (N, M) while loading (PAD above).
+template <int N, int M, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma_pad(
+    int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
+    double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, int n_rec, int m_rec) {
+    riccati_mfma_sweep<N, M, WAVES, 0, 0, 0, true>(B, T, tiles, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus,
+                                                   FusedArgs{}, n_rec, m_rec);
 }
 
 // The record-free sweep's general form for the four-state family (FUSED = 2 above): at most five agents of one model --

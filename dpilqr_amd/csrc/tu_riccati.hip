@@ -78,6 +78,35 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
             return DPILQR_OK;
         }
     }
+    // Cluster sizes without a wavefront instantiation of their own (n_x not a multiple of 4: three six-state agents,
+    // CarDynamics3D; tiny: one six-state agent; a user plugin's odd sizes): the dense wavefront sweep of the next larger
+    // instantiated size, which pads the records while loading them and stores the real block of the gains
+    // (riccati_mfma.hpp, PAD).  Before: the workgroup sweep or the generic kernel -- slower than clusters twice the size
+    // (profiles/r03_small_clusters.txt: three quadcopters 1.85 ms per 2048 items against 0.89 ms for four).
+    static const bool no_pad = getenv("DPILQR_RICCATI_NO_PAD") != nullptr;   // A/B switch
+    // (not two twelve-state agents: n_u = 8 padded to 12 is slower than their workgroup sweep, 1.72 against 1.51 ms per 512 items)
+    if (pick == 0 && !no_pad && n <= 24 && m <= 12 && !(block_ns == 12 && n == 24)) {
+#define DPILQR_TRY_PAD(NN, MM)                                                                                     \
+    if (n <= NN && m <= MM) {                                                                                      \
+        static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
+        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 8;             \
+        const int wv = (grid_items > 1024 && max_wv >= 8) ? 8 : 4;                                                 \
+        g_sweep_waves = wv;                                                                                        \
+        const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
+        auto kern = wv == 8 ? k_riccati_mfma_pad<NN, MM, 8> : k_riccati_mfma_pad<NN, MM, 4>;                       \
+        int32_t rc_t = allow_lds(kern, lds_t);                                                                     \
+        if (rc_t) return rc_t;                                                                                     \
+        const int cus = device_cus();                                                                              \
+        const int grid = grid_items <= cus ? grid_items : (grid_items + cus * wv - 1) / (cus * wv) * cus;          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wv), lds_t, st, B, T, tiles, mu, K, d, singular, items,      \
+                           n_items, gains_by_item, cus, n, m);                                                     \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return DPILQR_OK;                                                                                          \
+    }
+        DPILQR_TILED_SIZES(DPILQR_TRY_PAD)
+        DPILQR_TRY_PAD(24, 12)
+#undef DPILQR_TRY_PAD
+    }
     // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
     static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
     if (pick == 0 && !no_wg && block_ns > 0) {

@@ -22,7 +22,8 @@ ap.add_argument("--model", default="quad6")
 ap.add_argument("--B", type=int, default=2048)
 ap.add_argument("ks", nargs="*", type=int)
 args = ap.parse_args()
-mdl, ns, nc, nd, T = (4, 6, 3, 3, 75) if args.model == "quad6" else (3, 4, 2, 2, 100)
+mdl, ns, nc, nd, T = {"quad6": (4, 6, 3, 3, 75), "uni4": (3, 4, 2, 2, 100), "car3": (2, 3, 2, 2, 50), "quad12": (7, 12, 4, 3, 150),
+                       "di6": (1, 6, 3, 3, 75)}[args.model]
 ks = args.ks or ([4, 5, 6, 7, 8, 9, 10] if mdl == 4 else [7, 9, 11, 13, 15])
 
 
@@ -42,10 +43,12 @@ for k in ks:
         np.random.seed(500 + s)
         a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0)
         x0[s], xf[s] = a.ravel(), b.ravel()
-    Q = (50.0 * np.eye(6)) if mdl == 4 else np.diag([1.0, 1, 0, 0])
+    Q = (50.0 * np.eye(6)) if ns == 6 else (np.diag([1.0, 1, 0, 0]) if ns == 4 else np.eye(ns))
     U0 = np.zeros((B, T, m))
     if mdl == 4:
         U0[:, :, 0::3] = 9.80665
+    if mdl == 7:
+        U0[:, :, 3::4] = 9.80665 * 63 / 2000
     pb = dp.ProblemBatch([mdl] * k, [nd] * k, xf, Q, np.eye(nc), 1000.0 * np.eye(ns), 0.5, 0.1, T)
     r = pb.solve(x0, U0, n_lqr_iter=2)
     X, U = r["X"], r["U"]

@@ -5,6 +5,7 @@ Tolerances (fp64): the north star asks for 1e-5 relative on gains and rolled-out
 are held to 1e-9 here, whole solves to 1e-5 with the decision trace required to match exactly."""
 import numpy as np
 import pytest
+import torch
 
 from tests.golden_util import CFG2_SEEDS, MISC_SOLVES, MODEL_NAMES, PASS_CASES, cfg2_params, relerr
 
@@ -427,10 +428,11 @@ def test_sweep_blocked_elimination_and_its_fallback(dp, k, blocks):
         assert relerr(K[b], Ko) < 1e-9 and relerr(d[b], do) < 1e-9, (b, kinds[b], relerr(K[b], Ko))
 
 
-@pytest.mark.parametrize("k", [1, 2, 4, 7, 10])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 10])
 def test_sweep_six_state_family(dp, k):
     """The 6-state / 3-control family (Quadcopter6D; odd block sizes: no 16-byte alignment to lean on) through the
-    workgroup-per-item sweep and, for k = 1, the size-generic one: gains against the oracle, per-item mu."""
+    workgroup-per-item sweep and, for k = 1 and 3 (n_x = 6, 18: no wavefront instantiation of their own), the dense wavefront
+    sweep of the next larger size padded while loading: gains against the oracle, per-item mu."""
     from oracle import oracle as orc
     from dpilqr_amd.device import to_dev
     rng = np.random.default_rng(40 + k)
@@ -680,3 +682,44 @@ def test_sweep_three_state_family(dp, k):
         p = orc.Problem([2] * k, [2] * k, xf[i], Q, R, Qf, 0.6, 0.1, T)
         Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+
+
+@pytest.mark.parametrize("model,k,T", [(4, 3, 75), (4, 1, 75), (2, 3, 50), (2, 5, 50), (7, 1, 20)])
+def test_padded_wavefront_sweep_many_items(dp, model, k, T):
+    """Cluster sizes without a wavefront instantiation of their own (three / one Quadcopter6D: n_x = 18 / 6; three / five
+    CarDynamics3D: n_x = 9 / 15, odd row lengths; one Quadcopter12D: only the controls are padded) run the dense wavefront sweep
+    of the next larger size, which pads the records while loading (riccati_mfma.hpp, PAD).  More than 1024 items: the
+    two-wavefronts-per-SIMD layout with its layered item dealing; gains of items all over the launch against the oracle, and
+    the solve loop's route (producer + this sweep) against the oracle's whole solve."""
+    from oracle import oracle as orc
+    from dpilqr_amd.device import to_dev
+    ns, nc = {4: (6, 3), 2: (3, 2), 7: (12, 4)}[model]
+    nd = 3 if ns > 3 else 2
+    rng = np.random.default_rng(900 + 10 * model + k)
+    B = 1100
+    xf = rng.normal(size=(B, ns * k)) * (0.3 if model == 7 else 2.0)
+    x0 = xf + rng.normal(size=(B, ns * k)) * (0.05 if model == 7 else 1.0)
+    U = rng.normal(size=(B, T, nc * k)) * (1e-3 if model == 7 else 0.05)
+    if model == 4:
+        U[:, :, 0::3] += 9.80665
+    if model == 7:
+        U[:, :, 3::4] += 9.80665 * 63.0 / 2000.0
+    Q, R, Qf = np.eye(ns), np.eye(nc), 100.0 * np.eye(ns)
+    dt = 0.05 if model == 7 else 0.1
+    pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.5, dt, T)
+    X, _ = pb.rollout(x0, U)
+    mu = rng.uniform(0, 1, size=B)
+    K, d = pb.backward_pass(X, U, to_dev(mu))
+    assert bool(torch.isfinite(K).all()) and bool(torch.isfinite(d).all())
+    for i in list(range(0, B, 97)) + [B - 1]:
+        p = orc.Problem([model] * k, [nd] * k, xf[i], Q, R, Qf, 0.5, dt, T)
+        Ko, do = p.backward_pass(X[i].cpu().numpy(), U[i], mu[i])
+        assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
+    if model != 7:      # the solve loop's route (producer + this sweep): every item under the envelope of oracle/parity.py
+        from oracle import parity
+        nb = 24
+        r = dp.ProblemBatch([model] * k, [nd] * k, xf[:nb], Q, R, Qf, 0.5, dt, T).solve(x0[:nb], U[:nb], n_lqr_iter=4, trace=True)
+        proto = orc.Problem([model] * k, [nd] * k, xf[0], Q, R, Qf, 0.5, dt, T)
+        rep = parity.envelope({k_: v.cpu().numpy() for k_, v in r.items()}, proto, x0[:nb], xf[:nb], U[:nb], n_lqr_iter=4)
+        assert rep["summary"]["all_ok"], (rep["summary"], [w for w in rep["why"] if w][:3])
+        assert rep["summary"]["identical_decision_trace_frac"] >= 0.8
