@@ -100,14 +100,30 @@ struct WaveFwdLds {
     // and 1/9, 22 doubles does not -- any n that is a multiple of 4 collides.  Line search 0.361 -> 0.345 ms per bench
     // step.  (The same padding of K[t]'s rows, read by lanes of different agents, measured slower: 0.398 ms.)
     static constexpr int LDG = (n % 4 == 0) ? n + 2 : n;
-    static constexpr int oK = 0;                                   // K[t]  m x n
-    static constexpr int od = oK + m * n;                          // d[t]  m
+    static constexpr int NW = (KA * DPILQR_N_ALPHA + 63) / 64;     // wavefronts per sub-problem
+    // K[t]: the lanes of different AGENTS read their NC rows at the same column at once (16-byte reads), i.e. addresses
+    // NC n doubles apart: at 15 unicycles that is 240 dwords = 48 mod 64 banks, so agents 0, 4, 8, 12 collide -- four-way, 3.9
+    // conflict cycles per LDS instruction over the whole kernel (profiles/r03_wg_counters.csv).  A gap of KGAP doubles after
+    // every agent's block of rows makes the agents' distance 4 x (an odd number) banks: sixteen agents, sixteen different
+    // four-bank groups.  (Per-ROW padding measured slower at cfg2 in round 1; the per-agent gap keeps the rows of one agent
+    // contiguous and costs the staging one precomputed offset per copied pair.)  Clusters of 7+ agents (two or three
+    // wavefronts per item); DPILQR_LS_KGAP_ALL: A/B builds with the gap for every size.
+#ifndef DPILQR_LS_KGAP_ALL
+#define DPILQR_LS_KGAP_ALL 0
+#endif
+#ifndef DPILQR_LS_NO_KGAP
+#define DPILQR_LS_NO_KGAP 0
+#endif
+    static constexpr int kgap_for(int blk) { int g = 0; while ((((blk + g) / 2) & 1) == 0) g += 2; return g; }
+    static constexpr int KBLK = NC * n;                            // doubles of one agent's rows of K[t]
+    static constexpr int KGAP = (!DPILQR_LS_NO_KGAP && (NW > 1 || DPILQR_LS_KGAP_ALL) && KBLK % 2 == 0) ? kgap_for(KBLK) : 0;
+    static constexpr int oK = 0;                                   // K[t]  m x n (+ the gaps)
+    static constexpr int od = oK + m * n + KA * KGAP;              // d[t]  m
     static constexpr int odx = (od + m + 1) & ~1;                  // dx    [g][n]
     static constexpr int oxs = odx + DPILQR_N_ALPHA * LDG;         // x'    [g][LDG]
     static constexpr int ocr = oxs + DPILQR_N_ALPHA * LDG;         // ref cost  [parity][g][KA]
     static constexpr int ocp = ocr + 2 * DPILQR_N_ALPHA * KA;      // pair cost [parity][g][NP1]
     static constexpr int oJ = ocp + 2 * DPILQR_N_ALPHA * NP1;      // J [g]
-    static constexpr int NW = (KA * DPILQR_N_ALPHA + 63) / 64;     // wavefronts per sub-problem
     static constexpr int IPB = NW == 1 ? 4 : 1;                    // sub-problems per workgroup
     static constexpr int octl = oJ + DPILQR_N_ALPHA;
     // items of more than one wavefront (7+ agents) and six- / twelve-state agents keep the per-agent constants Q, R, x_f in
@@ -284,8 +300,13 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         // K[t], d[t], dx, x' -> LDS
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
-            const int e = min(tid + NTH * q, mn / 2 - 1);
-            *reinterpret_cast<v2d*>(sK + 2 * e) = stK[q];
+            // where this lane's pair goes: behind the gaps of the agents before it (WaveFwdLds::KGAP).  Formed here from a lane id
+            // the optimiser cannot see through: hoisted out of the horizon loop these offsets were KV more registers in kernels
+            // that already spill
+            int tid_o = tid;
+            if constexpr (W::KGAP > 0) asm volatile("" : "+v"(tid_o));
+            const int e = min(tid_o + NTH * q, mn / 2 - 1);
+            *reinterpret_cast<v2d*>(sK + 2 * e + (W::KGAP > 0 ? ((2 * e) / W::KBLK) * W::KGAP : 0)) = stK[q];
         }
         if (tid < m) sd[tid] = std_;
         // the trajectory stores of the previous step go out here, BEFORE the next prefetch is issued: memory
@@ -323,7 +344,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
             for (int c = 0; c < NC; ++c) sum2[c] = 0.0;
 #endif
-            const double* rows = sK + (a * NC) * n;
+            const double* rows = sK + a * (W::KBLK + W::KGAP);
             if (n % 2 == 0) {
 #pragma unroll 5
                 for (int j = 0; j < n; j += 2) {

@@ -184,6 +184,9 @@ def test_cfg5_whole_solves_at_the_stated_size(dp, hetero, seeds):
     sm = rep["summary"]
     print(sm, "n_bwd", r["n_bwd"], "oracle", o["n_bwd"], "status", r["status"])
     assert sm["all_ok"], (sm, [w for w in rep["why"] if w])
+    # (at this size half of the first iteration's candidates overflow to NaN in the reference itself, DESIGN.md section 5: a member
+    # of the ensemble that is forced through such a candidate draws no bound for its item -- at most one of the four here)
+    assert sm["unchecked_frac"] <= 0.25, sm
     assert r["n_bwd"].max() >= 5 and np.isfinite(r["X"]).all()
     tight = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
     assert tight.sum() >= 2, (sm, rep["spreadX"])

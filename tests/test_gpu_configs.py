@@ -48,6 +48,7 @@ def _envelope_over_buckets(audit, model, n_d, Q, R, Qf, T, n_lqr_iter=50):
         rep = parity.envelope(a, proto, a["x0"], a["xf"], a["U0"], n_lqr_iter=n_lqr_iter)
         sm = rep["summary"]
         assert sm["all_ok"], (kc, sm, [f"item {i}: {w}" for i, w in enumerate(rep["why"]) if w][:6])
+        assert sm["unchecked_frac"] <= 0.01, (kc, sm)      # items whose ensemble ended in NaN draw no bound: few
         tight = rep["spreadX"] < 1e-6
         assert (rep["errX"][tight] < 1e-5).all() and (rep["errU"][tight] < 1e-5).all(), kc
         n_items += sm["items"]; n_flipped += int(rep["flipped"].sum()); n_tight += int(tight.sum())
@@ -101,6 +102,9 @@ def test_cfg3_fifteen_unicycles_T100_solve_distributed(dp):
     assert np.isfinite(Xd2).all() and np.isfinite(J2).all()
 
 
+DELTAS_12 = tuple(float(sg * v) for v in np.geomspace(1e-14, 5e-13, 6) for sg in (1.0, -1.0))
+
+
 def test_cfg4_monte_carlo_1024_seeds_ten_quadcopters_T75(dp):
     """1024 random-goal scenarios of 10 QuadcopterDynamics6D (an eighth of cfg4's 8192: one rank's share at 8 GPUs) through
     the many-scenario front end -- one windowed device solve per cluster size -- with EVERY distinct sub-problem solve
@@ -129,9 +133,13 @@ def test_cfg4_monte_carlo_1024_seeds_ten_quadcopters_T75(dp):
     worst = 0.0
     for kc, a in sorted(audit.items()):
         proto = orc.Problem([4] * kc, [3] * kc, a["xf"][0], Q, R, Qf, 0.5, 0.1, T)
-        rep = parity.envelope(a, proto, a["x0"], a["xf"], a["U0"])
+        # (a 12-member ensemble over the same range of perturbations instead of the default 32: fewer members draw a
+        # NARROWER envelope and explain fewer flips -- a stricter test -- and 8 000 solves of up to ten quadcopters replayed
+        # 13 times instead of 33 keep this test at a minute of host time)
+        rep = parity.envelope(a, proto, a["x0"], a["xf"], a["U0"], deltas=DELTAS_12)
         sm = rep["summary"]
         assert sm["all_ok"], (kc, sm, [f"item {i}: {w}" for i, w in enumerate(rep["why"]) if w][:6])
+        assert sm["unchecked_frac"] <= 0.01, (kc, sm)
         tight = rep["spreadX"] < 1e-6
         assert (rep["errX"][tight] < 1e-5).all() and (rep["errU"][tight] < 1e-5).all(), kc
         n_items += sm["items"]; n_flipped += int(rep["flipped"].sum()); n_tight += int(tight.sum())
