@@ -2,7 +2,8 @@
 //
 // The library is built from several .hip files so that they compile in parallel (one file with every kernel
 // instantiation took over two minutes): tu_tiles.hip (K1), tu_riccati.hip (K2), tu_forward.hip (K3, rollouts, the small
-// batched entry points), tu_big.hip (the sweep for n_x > 60 and the fp32 arm) and dpilqr_hip.hip (the C ABI and the
+// batched entry points), tu_big.hip (the sweep for n_x > 60 and the fp32 arm), tu_team.hip (the fused
+// wavefront sweeps with a helper wavefront per item) and dpilqr_hip.hip (the C ABI and the
 // solve loop).  No device code crosses a file boundary.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -104,6 +105,10 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
                              double* d, int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items,
                              int gains_by_item, hipStream_t st);
 int32_t set_stamp_buffer_riccati(void* device_buffer);
+// ---- tu_team.hip: the fused wavefront sweeps with a helper wavefront per item, for launches of at most 1024 items
+int32_t launch_riccati_team(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
+                            int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items, int gains_by_item,
+                            hipStream_t st);
 
 // ---- tu_forward.hip
 int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,

@@ -38,7 +38,10 @@ namespace dpilqr {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int N, int M, int FUSED = 0>   // FUSED: 0 tile records; 1 DoubleInt4D, one Q / R / Q_f; 2 four-state family, per-agent weights
+// FUSED: 0 tile records; 1 DoubleInt4D, one Q / R / Q_f; 2 four-state family, per-agent weights.
+// HELP (fused forms, launches of at most one wavefront per SIMD): a second wavefront per item evaluates the plugins a step ahead
+// into the other of two buffers (see the kernel).
+template <int N, int M, int FUSED = 0, bool HELP = false>
 struct MfmaCfg {
     static constexpr int NM = N + M;
     static constexpr int NP = N + 1;                   // columns of [P|p], [K|d], [Q_ux|Q_u]
@@ -71,7 +74,13 @@ struct MfmaCfg {
     static constexpr int F_W = FUSED == 2 ? F_KA : 1;
     static constexpr int oFG = N * LQ, oFH = oFG + 2 * F_NP, oFD = oFH + 4 * F_NP, oFQQ = oFD + 4 * F_KA, oFRR = oFQQ + 16 * F_W,
                          oFXf = oFRR + 4 * F_W, oFL = oFXf + N, oFA = oFL + round_up(NM, 2),
-                         szF = round_up(oFA + (FUSED == 2 ? 4 * F_KA : 0), 2);
+                         szF1 = round_up(oFA + (FUSED == 2 ? 4 * F_KA : 0), 2);
+    // HELP: the step-dependent part (pair derivatives, their sums, [l_x | l_u], the A entries, and the "some pair is near" flag
+    // at oFflag) exists twice, FB doubles apart: the helper wavefront fills one copy while the sweep reads the other.  (The copy
+    // spans the constants Q + Q^T, R + R^T, x_f too, which are only ever read at their first location.)
+    static constexpr int oFflag = szF1;
+    static constexpr int FB = HELP ? round_up(szF1 + 2 - oFG, 2) : 0;
+    static constexpr int szF = HELP ? round_up(oFG + 2 * FB, 2) : szF1;
     static constexpr int szR1 = FUSED ? szF : round_up(N * LAB > N * LQ ? N * LAB : N * LQ, 2);
     static constexpr int szT0 = N * LT > KROWS * LK + MK * N ? N * LT : KROWS * LK + MK * N;
     static constexpr int szT1 = szT0 > NM * LTB ? szT0 : NM * LTB;
@@ -247,6 +256,9 @@ __device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[K
     for (int r = 0; r < M; ++r) v_io[r] = v[r];
 }
 
+// workgroup barrier behind an LDS-only wait (global prefetches stay in flight): the two wavefronts of an item's team meet here
+__device__ __forceinline__ void wave_barrier_all() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // The lane id, optionally made opaque to the optimiser: see riccati_mfma_lane.inc.
 template <bool ON>
 __device__ __forceinline__ int phase_lane(int lane) {
@@ -282,13 +294,20 @@ struct FusedArgs {
 // padded row: its entries in the real columns are zeros), the padded rows of [K|d] are zeros, and every sum of the real
 // block only gains terms that are exact zeros: the real gains are those of an unpadded sweep.  Only the real m_rec x n_rec
 // block of K[t] and the first m_rec entries of d[t] are stored, in the real layout.
-template <int N, int M, int WAVES, int NS, int NC, int FUSED, bool PAD = false>
+// HELP (fused forms, WAVES = 4: launches that cannot give a SIMD a second item -- a job's draining tail, a single small batch):
+// a TEAM of two wavefronts per item on one SIMD (wavefronts w and w + 4 of a 512-thread workgroup).  A wavefront alone on a
+// SIMD issues at half rate, so whatever the second one takes over is nearly free.  Stage 1: the helper evaluates the step's
+// plugin data (fused_step_data: pair derivatives, their per-agent sums, [l_x | l_u], the A entries -- 12 % of a lone
+// wavefront's step, profiles/r04_phase_stamps.txt) one step AHEAD into the other of two buffers; the two meet at one
+// s_barrier per step.  Same expressions, same order: bit-identical gains.
+template <int N, int M, int WAVES, int NS, int NC, int FUSED, bool PAD = false, bool HELP = false>
 __device__ __forceinline__ void riccati_mfma_sweep(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F, int n_rec = N, int m_rec = M) {
-    using C = MfmaCfg<N, M, FUSED>;
+    using C = MfmaCfg<N, M, FUSED, HELP>;
     static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variants are written for the four-state family's blocks");
+    static_assert(!HELP || (FUSED != 0 && WAVES == 4), "the helper wavefront serves the fused forms at one item per SIMD");
     static_assert(!PAD || (NS == 0 && FUSED == 0), "padding while loading is written for the dense record-fed form");
     constexpr bool FGEN = (FUSED == 2);   // per-agent weights, per-agent model (DoubleIntDynamics4D / UnicycleDynamics4D)
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
@@ -301,7 +320,9 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     // Instead: a LAYER is one wavefront on every SIMD of every CU (4 n_cus items); n items need ceil(n / layer) layers,
     // spread as evenly as possible over the fewest rounds that hold them (five layers at WAVES = 12: a round of three
     // and a round of two, 467 + 327 us instead of 2 x 467).  Surplus wavefronts and workgroups exit at once.
-    const int wave = threadIdx.x >> 6;
+    const int wave_all = threadIdx.x >> 6;
+    const bool helper = HELP && wave_all >= 4;          // wavefronts 4..7: the helpers of the items of wavefronts 0..3
+    const int wave = HELP ? (wave_all & 3) : wave_all;
     const int n = n_items ? *n_items : B;
     constexpr int LPR = WAVES / 4;   // layers per round
     const int per_layer = 4 * n_cus;
@@ -370,6 +391,28 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     double lvc[FUSED ? RPL : 1][FUSED ? NSC : 1];
     int lv_h[FUSED ? RPL : 1];          // offset into the step's Hessian data (doubles from sFH), -1: no proximity part
     bool lv_neg[FUSED ? RPL : 1];
+    int t_cur = T;      // the step whose plugin data the lane terms point at (HELP: selects the buffer)
+    if constexpr (HELP) {
+        if (helper) {
+            const int lane = lane0;
+            wave_barrier_all();       // (A) the sweep's wavefront has zeroed the item's LDS and put the constants in place
+            {
+                t_cur = T - 1;
+#include "riccati_mfma_lane.inc"
+                fused_prefetch(T - 1);
+            }
+            for (int t = T - 1; t >= 0; --t) {
+                t_cur = t;
+#include "riccati_mfma_lane.inc"
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this step's share of (X[t], U[t])
+                fused_step_data(t, nullptr);
+                if (lane == 0) sFflag[0] = f_prox ? 1.0 : 0.0;
+                if (t > 0) fused_prefetch(t - 1);
+                wave_barrier_all();   // step t's data are in place; the sweep has finished step t + 1 (the buffer written next)
+            }
+            return;
+        }
+    }
     if constexpr (FUSED) {
         const ItemParams IP = item_params(F.D, b);
         constexpr int FKA_ = C::F_KA;
@@ -443,6 +486,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         }
         for (int e = lane; e < N; e += 64) sFXf[e] = IP.xf[e];
         DPILQR_LDS_FENCE();
+        if constexpr (HELP) wave_barrier_all();   // (A) the helper may start on step T - 1
         fused_prefetch(T);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         fused_step_data(T, IP.Qf);           // pair derivatives at X[T]; [l_x | .] with Q_f
@@ -463,7 +507,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         }
         for (int j = lane; j < N; j += 64) sP[j * LP + N] = sFL[j];
         DPILQR_LDS_FENCE();
-        fused_prefetch(T - 1);
+        if constexpr (!HELP) fused_prefetch(T - 1);
     } else {
     prefetch_ab(T - 1);
     if constexpr (BD) {
@@ -487,10 +531,15 @@ __device__ __forceinline__ void riccati_mfma_sweep(
 #endif
     for (int t = T - 1; t >= 0; --t) {
         const int tn = t > 0 ? t - 1 : 0;
+        t_cur = t;
         {   // ---- S0, S1
         const int lane = phase_lane<REMAT>(lane0);
 #include "riccati_mfma_lane.inc"
-        if constexpr (FUSED) {
+        if constexpr (HELP) {
+            // the helper wavefront has put this step's plugin data into buffer t & 1 during the previous step
+            wave_barrier_all();
+            f_prox = __builtin_amdgcn_readfirstlane((int)(sFflag[0] != 0.0)) != 0;
+        } else if constexpr (FUSED) {
             // the step's pair derivatives and [l_x | l_u]; then the next step's share of the trajectory is requested
             fused_step_data(t, nullptr);
             fused_prefetch(tn);
@@ -917,6 +966,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma(
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
     const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, FusedArgs F) {
     riccati_mfma_sweep<N, M, WAVES, NS, NC, (FUSED ? 1 : 0)>(B, T, tiles, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus, F);
+}
+
+// The fused sweeps with a helper wavefront per item (HELP above): 512-thread workgroups, wavefronts 0..3 sweep four items (one
+// per SIMD), wavefronts 4..7 are their helpers.  FUSED: 1 the DoubleInt4D form, 2 the general four-state form.
+template <int N, int M, int FUSED>
+__global__ __launch_bounds__(512, 2) void k_riccati_mfma_team(
+    int B, int T, const double* __restrict__ mu_arr, double* __restrict__ Kout, double* __restrict__ dout,
+    int32_t* __restrict__ singular, const int32_t* __restrict__ items, const int32_t* __restrict__ n_items, int gains_by_item,
+    int n_cus, FusedArgs F) {
+    riccati_mfma_sweep<N, M, 4, 4, 2, FUSED, false, true>(B, T, nullptr, mu_arr, Kout, dout, singular, items, n_items, gains_by_item,
+                                                          n_cus, F);
 }
 
 // The dense record-fed sweep for cluster sizes without an instantiation of their own: records and gains of size (n_rec, m_rec),

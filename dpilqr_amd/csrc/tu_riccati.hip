@@ -188,6 +188,14 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
+    // launches of at most one item per SIMD: a team of two wavefronts per item (tu_team.hip)
+    if (grid_items <= 1024 && max_wv >= 4 && (fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D))) {
+        const int32_t rc_team = launch_riccati_team(D, X, U, mu, K, d, singular, items, n_items, grid_items, gains_by_item, st);
+        if (rc_team != DPILQR_EUNSUPPORTED) {
+            if (rc_team == DPILQR_OK) g_sweep_waves = 4;
+            return rc_team;
+        }
+    }
     if (fused_wavefront_sweep_applies(D)) {
         DPILQR_TILED_SIZES(DPILQR_TRY_FUSED)
     }
