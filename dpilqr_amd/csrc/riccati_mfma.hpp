@@ -95,7 +95,11 @@ struct MfmaCfg {
     static constexpr int oP = oT;
     static constexpr int oG = oT + szR2;
     static constexpr int oQx = oG + MK * LG;
-    static constexpr int oEnd = oG + szG;
+    static constexpr int oEnd0 = oG + szG;
+    // HELP with two row tiles: a2 in a region of its own (riccati_mfma_team_tail.inc)
+    static constexpr bool TEAM_TAIL = HELP && (NP > 16) && (NP <= 32) && (M <= 16);
+    static constexpr int oA2 = oEnd0;
+    static constexpr int oEnd = oEnd0 + (TEAM_TAIL ? round_up(NP * LM, 2) : 0);
     static constexpr int total = round_up(oEnd + 8, 2);    // + store target of idle lanes
     static constexpr bool supported = (N % 4 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 40 * 1024);
     static constexpr int AB_PAIRS = N * NM / 2;
@@ -352,7 +356,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     double* sQ = lds + C::oQ;
     double* sG = lds + C::oG;
     double* sQx = lds + C::oQx;        // Q_x between the S1 and S2 epilogues
-    double* sMt = sG;                  // a2, after the S5 products
+    double* sMt = C::TEAM_TAIL ? lds + C::oA2 : sG;   // a2, after the S5 products
 
     const double mu = mu_arr[b];
     const double f_radius = FUSED ? F.D.radius[(int64_t)b * F.D.radius_bstride] : 0.0;
@@ -408,7 +412,23 @@ __device__ __forceinline__ void riccati_mfma_sweep(
                 fused_step_data(t, nullptr);
                 if (lane == 0) sFflag[0] = f_prox ? 1.0 : 0.0;
                 if (t > 0) fused_prefetch(t - 1);
+                if constexpr (C::TEAM_TAIL) {
+                    // ... then the helper takes the second row tile of S4 .. S6 of the step the sweep is in, t + 1
+                    if (t < T - 1) {
+                        wave_barrier_all();   // [K | d] of step t + 1 is in place (the sweep's S3)
+                        constexpr int IT = 1;
+#include "riccati_mfma_team_tail.inc"
+                    }
+                }
                 wave_barrier_all();   // step t's data are in place; the sweep has finished step t + 1 (the buffer written next)
+            }
+            if constexpr (C::TEAM_TAIL) {     // the last step's (t = 0) second row tile
+                t_cur = 0;
+#include "riccati_mfma_lane.inc"
+                wave_barrier_all();
+                constexpr int IT = 1;
+#include "riccati_mfma_team_tail.inc"
+                wave_barrier_all();
             }
             return;
         }
@@ -859,6 +879,13 @@ __device__ __forceinline__ void riccati_mfma_sweep(
 #include "riccati_mfma_lane.inc"
 
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (C::TEAM_TAIL) {
+            // S4 .. S6 by row tile: this wavefront the first, its helper the second (riccati_mfma_team_tail.inc)
+            wave_barrier_all();       // [K | d] is in place for the helper
+            constexpr int IT = 0;
+#include "riccati_mfma_team_tail.inc"
+            if (t == 0) wave_barrier_all();   // (the other steps: the barrier at the top of the next step)
+        } else {
         // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]
         // One row tile of controls (m <= 16): T3^T never goes through LDS.  The fp64 MFMA's output layout -- lane (g, c) holds rows
         // g + 4 v of column c -- IS its A-operand layout for the reduction rows 4 v .. 4 v + 3, so S4's accumulator register v of
@@ -941,6 +968,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
                 for (int jt = 0; jt < T_NP; ++jt)
                     for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { dP[16 * jt + r * LP] = vb[it][jt][v]; });   // p is in place
         }
+        }   // !TEAM_TAIL
         DPILQR_LDS_FENCE();
         MPHASE(5)
         }
