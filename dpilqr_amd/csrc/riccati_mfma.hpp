@@ -117,6 +117,15 @@ __device__ __forceinline__ double dpp_fmac_row(double acc, double a, double b) {
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(L));
     return acc;
 }
+// ... without the s_nop: for call sites where the DPP operand `a` was written at least two instructions earlier (the caller
+// arranges that; an s_nop per multiply-add was a fifth of the LU's instructions)
+template <int L>
+__device__ __forceinline__ double dpp_fmac_row_nn(double acc, double a, double b) {
+    // volatile: these keep their program order among themselves and against the callers' pins, which is what places the
+    // multiplies two instructions ahead of the reads
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(L));
+    return acc;
+}
 template <int L>
 __device__ __forceinline__ double dpp_mov_row(double a) {   // a[lane L of the row]
     double r;
@@ -134,6 +143,7 @@ __device__ __forceinline__ double dpp_mov_row(double a) {   // a[lane L of the r
     }
 // `l` is a compile-time constant after unrolling at every call site: the switch folds to one instruction
 __device__ __forceinline__ double fmac_row(double acc, double a, double b, int l) { DPILQR_ROW_SWITCH(dpp_fmac_row, acc, a, b) }
+__device__ __forceinline__ double fmac_row_nn(double acc, double a, double b, int l) { DPILQR_ROW_SWITCH(dpp_fmac_row_nn, acc, a, b) }
 __device__ __forceinline__ double mov_row(double a, int l) { DPILQR_ROW_SWITCH(dpp_mov_row, a) }
 
 __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
@@ -201,7 +211,9 @@ __device__ __forceinline__ void for_rows_p(int row0, int lo, int hi, int g, bool
 // dgetf2's partial pivoting; without, for matrices that are known not to need a row swap (see S3).
 // KEEPINV = false: the reciprocal pivots are not kept (invd has one element and is not written): the caller's substitution
 // recomputes them from U's diagonal with the same instructions (same bits), for 2 m registers less.
-template <bool SEARCH, int M, bool ROWLU, bool KEEPINV = true>
+// BATCH (ROWLU): the multipliers of three rows ahead of their three updates, no s_nop per update (needs three more doubles
+// per lane: not in the variant that runs at 168 registers).
+template <bool SEARCH, int M, bool ROWLU, bool KEEPINV = true, bool BATCH = false>
 __device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[KEEPINV ? M : 1], int& sing, int* swaps = nullptr) {
     double v[M];   // a local copy: the row swap below must stay a chain of register moves, never an indexed access
 #pragma unroll
@@ -246,8 +258,24 @@ __device__ __forceinline__ void lu_eliminate(double (&v_io)[M], double (&invd)[K
             // every lane scales its own entries; the one that matters (minus the multiplier, in lane kk of the row)
             // reaches the row inside the fused multiply-add: fma(-l, v[kk], v[r]) with l = v[r]@kk * inv, bit for bit
             const double ninv = -inv;
+            if constexpr (!BATCH) {
 #pragma unroll
-            for (int r = kk + 1; r < M; ++r) v[r] = fmac_row(v[r], v[r] * ninv, v[kk], kk);
+                for (int r = kk + 1; r < M; ++r) v[r] = fmac_row(v[r], v[r] * ninv, v[kk], kk);
+            } else {
+            // in groups of three rows: the three multipliers first, then the three updates -- every DPP read then sits two
+            // instructions behind the multiply that wrote its operand, and the group needs no s_nop (a shorter last group: one)
+#pragma unroll
+            for (int r0 = kk + 1; r0 < M; r0 += 3) {
+                double tm[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (r0 + q < M) { tm[q] = v[r0 + q] * ninv; asm volatile("" : "+v"(tm[q])); }
+                if (r0 + 2 >= M) asm volatile("s_nop 1");
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (r0 + q < M) { v[r0 + q] = fmac_row_nn(v[r0 + q], tm[q], v[kk], kk); asm volatile("" : "+v"(v[r0 + q])); }
+            }
+            }
         } else {
 #pragma unroll
             for (int r = kk + 1; r < M; ++r) {
@@ -828,14 +856,15 @@ __device__ __forceinline__ void riccati_mfma_sweep(
             const double dg = fabs(sG[s3_dg]);
             const bool dominant = !s3_lhs || dg * (1.0 - 0x1p-20) > colsum - dg;
             const bool no_swaps = __builtin_amdgcn_ballot_w64(!dominant) == 0ull;
-            if (no_swaps) lu_eliminate<false, M, ROWLU>(v, invd, sing); else lu_eliminate<true, M, ROWLU>(v, invd, sing);
+            constexpr bool LUB = ROWLU && (WAVES == 4);   // one wavefront per SIMD: the s_nops cost their full issue time there (and the two- and three-per-SIMD variants have no registers to spare)
+            if (no_swaps) lu_eliminate<false, M, ROWLU, true, LUB>(v, invd, sing); else lu_eliminate<true, M, ROWLU, true, LUB>(v, invd, sing);
             if constexpr (ROWLU) {
                 double nv[M];   // minus the solved rows: fma(-U, x, s) == fma(U, -x, s)
 #pragma unroll
                 for (int r = M - 1; r >= 0; --r) {
                     double s = v[r];
 #pragma unroll
-                    for (int c = r + 1; c < M; ++c) s = fmac_row(s, v[r], nv[c], c);
+                    for (int c = r + 1; c < M; ++c) s = fmac_row_nn(s, v[r], nv[c], c);   // (v[r]: U's row, written by the elimination long before)
                     nv[r] = -(s * invd[r]);
                 }
 #pragma unroll
@@ -896,7 +925,11 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         constexpr bool T3R = (T_M == 1) && (T_N == T_NP) && (WAVES != 12);
         v4d t3[T_M][T_N];
         zero_tiles(t3);
+#ifdef DPILQR_EXP_SKIP_BORDER   // timing experiment only (wrong results): what the products of the border tiles cost
+        mfma_product<T_M, 1, MK, LG, LK>(pGuu, pK, reinterpret_cast<v4d (&)[T_M][1]>(t3[0][0]));
+#else
         mfma_product<T_M, T_N, MK, LG, LK>(pGuu, pK, t3);
+#endif
         if constexpr (!T3R) {
 #pragma unroll
             for (int it = 0; it < T_M; ++it)
@@ -925,9 +958,17 @@ __device__ __forceinline__ void riccati_mfma_sweep(
                         for (int jt = 0; jt < T_NP; ++jt) a1[it][jt] = mfma_f64(t3[0][it][ks], b[jt], a1[it][jt]);
                 }
             } else {
+#ifdef DPILQR_EXP_SKIP_BORDER
+                mfma_product<1, 1, MK, N, LK>(pT3, pK, reinterpret_cast<v4d (&)[1][1]>(a1[0][0]));
+#else
                 mfma_product<T_NP, T_NP, MK, N, LK>(pT3, pK, a1);
+#endif
             }
+#ifdef DPILQR_EXP_SKIP_BORDER
+            mfma_product<1, 1, MK, LK, LG>(pK, pGux, reinterpret_cast<v4d (&)[1][1]>(a2[0][0]));
+#else
             mfma_product<T_NP, T_NP, MK, LK, LG>(pK, pGux, a2);
+#endif
 #pragma unroll
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll

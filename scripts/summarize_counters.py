@@ -19,6 +19,9 @@ def short(name):
     m = re.search(r"k_riccati_mfma<\d+, \d+, (\d+), \d+, \d+(, true)?>", name)
     if m:
         return f"riccati_{'fused' if m.group(2) else 'records'}_w{m.group(1)}"
+    if "k_riccati_mfma_team" in name: return "riccati_fused_team"
+    if "k_riccati_mfma_pad" in name: return "riccati_records_padded"
+    if "k_riccati_mfma_general" in name: return "riccati_fused_general"
     m = re.search(r"k_riccati_wg<(\d+), (\d+), \d+, \d+(, true)?>", name)
     if m:
         return f"riccati_wg_{'fused' if m.group(3) else 'records'}_n{m.group(1)}"
