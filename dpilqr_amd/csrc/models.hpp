@@ -64,10 +64,14 @@ template <> struct ModelDef<kDoubleInt6D> {  // x=[p(3),v(3)] u=[a(3)]
 
 template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
     static constexpr int NS = 3, NC = 2;
+    static constexpr int kHeading = 2;   // the heading angle: its rate is a control, constant over a step (see integrate)
+    template <typename R> __device__ static void f_sc(const R*, const R* u, R sn, R cs, R* o) {   // f with sin / cos of the heading given
+        o[0] = u[0] * cs; o[1] = u[0] * sn; o[2] = u[1];
+    }
     template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         R sn, cs;
         sincos_r(x[2], &sn, &cs);
-        o[0] = u[0] * cs; o[1] = u[0] * sn; o[2] = u[1];
+        f_sc(x, u, sn, cs, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
         const R s = sin(x[2]), c = cos(x[2]);
@@ -78,10 +82,14 @@ template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
 
 template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
     static constexpr int NS = 4, NC = 2;
+    static constexpr int kHeading = 3;   // the heading angle: its rate is a control, constant over a step (see integrate)
+    template <typename R> __device__ static void f_sc(const R* x, const R* u, R sn, R cs, R* o) {   // f with sin / cos of the heading given
+        o[0] = x[2] * cs; o[1] = x[2] * sn; o[2] = u[0]; o[3] = u[1];
+    }
     template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         R sn, cs;
         sincos_r(x[3], &sn, &cs);   // one argument reduction for both (same values as sin(), cos())
-        o[0] = x[2] * cs; o[1] = x[2] * sn; o[2] = u[0]; o[3] = u[1];
+        f_sc(x, u, sn, cs, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
         const R s = sin(x[3]), c = cos(x[3]);
@@ -271,12 +279,84 @@ __device__ __forceinline__ void div6_vec(float* v) {
     for (int i = 0; i < N; ++i) v[i] = v[i] / 6.0f;
 }
 
+// Models whose only transcendental argument is a heading angle with a CONTROL as its rate (Unicycle4D, Car3D: theta' = u[1],
+// held over the step): ModelDef<M>::kHeading / f_sc.
+template <int M> struct HasHeading { static constexpr bool value = false; };
+template <> struct HasHeading<kCar3D> { static constexpr bool value = true; };
+template <> struct HasHeading<kUnicycle4D> { static constexpr bool value = true; };
+
 // classical RK4 with 5 fixed sub-steps, zero-order-hold u (bbdynamics.cpp:39-93)
 template <int M, typename R>
 __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
     using D = ModelDef<M>;
     constexpr int NS = D::NS;
     const R dh = dt / 5;
+    if constexpr (HasHeading<M>::value) {
+        // The heading's slope is the same control in every stage (k0 = k1 = k2 = k3 = u[1] in that component): the heading is
+        // AFFINE in time over the step.  So (i) the second and the third stage of a sub-step are evaluated at bitwise the same
+        // heading, xa + (dh / 2) u[1], and one sincos serves both (15 instead of 20 per step, every result bit for bit what 20
+        // give: -DDPILQR_TRIG_DIRECT builds); and (ii), the default, the eleven headings of a step -- theta_0 + j (dh / 2) u[1],
+        // j = 0 .. 10 -- are rotations of one another: sincos(theta_0) and sincos((dh / 2) u[1]) once per step, then ten
+        // rotations (four multiplications and two additions each).  The rotated values sit a few ulp from the direct ones
+        // (each rotation adds one rounding of an O(1) quantity: <= 1e-15 after ten), i.e. inside the difference between this
+        // device's sincos and the reference's libm, and two orders of magnitude inside the 1e-12 at which the models are held
+        // to the reference's own numbers (G1); the whole GPU suite -- reference golden decision traces of the unicycle solves
+        // included -- passes on either build.  Why: the sincos ARE a unicycle's line search, 55-60 % of its launch time
+        // (profiles/r04_trig.txt): five unicycles' line search 28.9 -> 23.8 ms per 2048-item solve with (i), -> 13.9 ms with (ii).
+        constexpr int H = D::kHeading;
+        R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xn[i] = x[i];
+#ifndef DPILQR_TRIG_DIRECT
+        R s0, c0, sh, ch;
+        sincos_r(xn[H], &s0, &c0);
+        sincos_r((dh / R(2.0)) * u[1], &sh, &ch);
+#endif
+        for (int s = 0; s < 5; ++s) {
+            R sn, cs;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xa[i] = xn[i];
+#ifndef DPILQR_TRIG_DIRECT
+            D::f_sc(xa, u, s0, c0, k0);
+            sn = s0 * ch + c0 * sh; cs = c0 * ch - s0 * sh;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k0[i];
+            D::f_sc(xb, u, sn, cs, k1);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k1[i];
+            D::f_sc(xb, u, sn, cs, k2);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
+            s0 = sn * ch + cs * sh; c0 = cs * ch - sn * sh;
+            D::f_sc(xb, u, s0, c0, k3);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
+            div6_vec<NS>(xb);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xn[i] += xb[i];
+            continue;
+#endif
+            sincos_r(xa[H], &sn, &cs);
+            D::f_sc(xa, u, sn, cs, k0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k0[i];
+            sincos_r(xb[H], &sn, &cs);
+            D::f_sc(xb, u, sn, cs, k1);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k1[i];
+            D::f_sc(xb, u, sn, cs, k2);          // xb[H] is the previous stage's heading, bit for bit
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
+            sincos_r(xb[H], &sn, &cs);
+            D::f_sc(xb, u, sn, cs, k3);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
+            div6_vec<NS>(xb);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xn[i] += xb[i];
+        }
+        return;
+    }
     constexpr int kSubUnroll = (M == kDoubleInt4D) ? 5 : 1;
     R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
 #pragma unroll

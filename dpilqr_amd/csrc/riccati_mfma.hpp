@@ -925,11 +925,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         constexpr bool T3R = (T_M == 1) && (T_N == T_NP) && (WAVES != 12);
         v4d t3[T_M][T_N];
         zero_tiles(t3);
-#ifdef DPILQR_EXP_SKIP_BORDER   // timing experiment only (wrong results): what the products of the border tiles cost
-        mfma_product<T_M, 1, MK, LG, LK>(pGuu, pK, reinterpret_cast<v4d (&)[T_M][1]>(t3[0][0]));
-#else
         mfma_product<T_M, T_N, MK, LG, LK>(pGuu, pK, t3);
-#endif
         if constexpr (!T3R) {
 #pragma unroll
             for (int it = 0; it < T_M; ++it)
@@ -958,17 +954,9 @@ __device__ __forceinline__ void riccati_mfma_sweep(
                         for (int jt = 0; jt < T_NP; ++jt) a1[it][jt] = mfma_f64(t3[0][it][ks], b[jt], a1[it][jt]);
                 }
             } else {
-#ifdef DPILQR_EXP_SKIP_BORDER
-                mfma_product<1, 1, MK, N, LK>(pT3, pK, reinterpret_cast<v4d (&)[1][1]>(a1[0][0]));
-#else
                 mfma_product<T_NP, T_NP, MK, N, LK>(pT3, pK, a1);
-#endif
             }
-#ifdef DPILQR_EXP_SKIP_BORDER
-            mfma_product<1, 1, MK, LK, LG>(pK, pGux, reinterpret_cast<v4d (&)[1][1]>(a2[0][0]));
-#else
             mfma_product<T_NP, T_NP, MK, LK, LG>(pK, pGux, a2);
-#endif
 #pragma unroll
             for (int it = 0; it < T_NP; ++it)
 #pragma unroll
