@@ -101,9 +101,16 @@ template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
 
 template <> struct ModelDef<kQuadcopter6D> {  // x=[p(3),v(3)] u=[tau,phi,theta]
     static constexpr int NS = 6, NC = 3;
-    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+    // the transcendental arguments are CONTROLS, held over a step: pre() evaluates them once, f_tr() is f given them (integrate)
+    template <typename R> __device__ static void pre(const R* u, R* tr) { tr[0] = tan(u[2]); tr[1] = tan(u[1]); }
+    template <typename R> __device__ static void f_tr(const R* x, const R* u, const R* tr, R* o) {
         o[0] = x[3]; o[1] = x[4]; o[2] = x[5];
-        o[3] = R(kGrav) * tan(u[2]); o[4] = -R(kGrav) * tan(u[1]); o[5] = u[0] - R(kGrav);
+        o[3] = R(kGrav) * tr[0]; o[4] = -R(kGrav) * tr[1]; o[5] = u[0] - R(kGrav);
+    }
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        R tr[2];
+        pre(u, tr);
+        f_tr(x, u, tr, o);
     }
     template <typename R> __device__ static void jac(const R*, const R* u, R* A, R* B) {
         const R t2 = tan(u[2]), t1 = tan(u[1]);
@@ -116,8 +123,14 @@ template <> struct ModelDef<kQuadcopter6D> {  // x=[p(3),v(3)] u=[tau,phi,theta]
 
 template <> struct ModelDef<kHuman6D> {  // x=[px,py,pz,v,0,0] u=[heading,accel,-]
     static constexpr int NS = 6, NC = 3;
+    template <typename R> __device__ static void pre(const R* u, R* tr) { sincos_r(u[0], &tr[1], &tr[0]); }
+    template <typename R> __device__ static void f_tr(const R* x, const R* u, const R* tr, R* o) {
+        o[0] = x[3] * tr[0]; o[1] = x[3] * tr[1]; o[2] = 0.0; o[3] = u[1]; o[4] = 0.0; o[5] = 0.0;
+    }
     template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
-        o[0] = x[3] * cos(u[0]); o[1] = x[3] * sin(u[0]); o[2] = 0.0; o[3] = u[1]; o[4] = 0.0; o[5] = 0.0;
+        R tr[2];
+        pre(u, tr);
+        f_tr(x, u, tr, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
         const R s = sin(u[0]), c = cos(u[0]);
@@ -151,8 +164,10 @@ template <> struct ModelDef<kQuadcopter12D> {
     static constexpr double kCy = 95876456000597.0 / 185697971056862.0;
     static constexpr double kCz = 9976479919918.0 / 271597947137541.0;
     template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
-        const R sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
-        const R sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
+        // (sincos: one argument reduction per angle for both values -- the same values as sin(), cos())
+        R sps, cps, sth, cth, sph, cph;
+        sincos_r(x[3], &sps, &cps); sincos_r(x[4], &sth, &cth); sincos_r(x[5], &sph, &cph);
+        const R tth = tan(x[4]);
         const R vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
         o[0] = vx * cps * cth + vy * (sph * sth * cps - sps * cph) + vz * (sph * sps + sth * cph * cps);
         o[1] = vx * sps * cth + vy * (sph * sps * sth + cph * cps) + vz * (-sph * cps + sps * sth * cph);
@@ -168,6 +183,11 @@ template <> struct ModelDef<kQuadcopter12D> {
         o[11] = R(kTz) * u[2] - R(kCz) * wx * wy;
     }
     template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
+        // (sin and cos by separate calls HERE -- the Jacobians are evaluated once per step, their cost is nothing -- because
+        // sincos pairs keep some eighteen more registers live, and in the large-cluster sweep (riccati_big.hpp: 128 registers
+        // per lane, 64 of them spilled already) the build with 82 spilled registers died with an HSA memory aperture
+        // violation on config 5's heterogeneous team -- deterministically, and not under rocgdb.  tests/test_kernel_resources.py
+        // holds that kernel to the spill count it is known to run with.)
         const R sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
         const R sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
         const R c2 = cth * cth, sec2 = tth * tth + 1;
@@ -220,10 +240,16 @@ template <> struct ModelDef<kHumanPad12D> {  // x=[px,py,pz,v,0,0 | 6 padded sta
     // have x_dot = 0, so RK4 leaves them bit-for-bit where they are and the Euler Jacobians give A = 1 on their
     // diagonal and B = 0 -- what a block-diagonal embedding of the six-state model means.
     static constexpr int NS = 12, NC = 4;
-    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
-        o[0] = x[3] * cos(u[0]); o[1] = x[3] * sin(u[0]); o[2] = 0.0; o[3] = u[1];
+    template <typename R> __device__ static void pre(const R* u, R* tr) { sincos_r(u[0], &tr[1], &tr[0]); }
+    template <typename R> __device__ static void f_tr(const R* x, const R* u, const R* tr, R* o) {
+        o[0] = x[3] * tr[0]; o[1] = x[3] * tr[1]; o[2] = 0.0; o[3] = u[1];
 #pragma unroll
         for (int i = 4; i < 12; ++i) o[i] = 0.0;
+    }
+    template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
+        R tr[2];
+        pre(u, tr);
+        f_tr(x, u, tr, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
         const R s = sin(u[0]), c = cos(u[0]);
@@ -284,6 +310,12 @@ __device__ __forceinline__ void div6_vec(float* v) {
 template <int M> struct HasHeading { static constexpr bool value = false; };
 template <> struct HasHeading<kCar3D> { static constexpr bool value = true; };
 template <> struct HasHeading<kUnicycle4D> { static constexpr bool value = true; };
+
+// Models whose transcendental arguments are controls only (Quadcopter6D: tan of two; Human6D and its padded form: sin, cos of one)
+template <int M> struct HasControlTrig { static constexpr bool value = false; };
+template <> struct HasControlTrig<kQuadcopter6D> { static constexpr bool value = true; };
+template <> struct HasControlTrig<kHuman6D> { static constexpr bool value = true; };
+template <> struct HasControlTrig<kHumanPad12D> { static constexpr bool value = true; };
 
 // classical RK4 with 5 fixed sub-steps, zero-order-hold u (bbdynamics.cpp:39-93)
 template <int M, typename R>
@@ -349,6 +381,36 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
             for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
             sincos_r(xb[H], &sn, &cs);
             D::f_sc(xb, u, sn, cs, k3);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
+            div6_vec<NS>(xb);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xn[i] += xb[i];
+        }
+        return;
+    }
+    if constexpr (HasControlTrig<M>::value) {
+        // tan / sin / cos of CONTROLS: the same numbers in all twenty stage evaluations of the step, evaluated once (bit-identical
+        // results; the inlined library functions branch, and the optimiser neither hoists them out of the sub-step loop nor
+        // merges the four of a sub-step)
+        R tr[2];
+        D::pre(u, tr);
+        R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) xn[i] = x[i];
+        for (int s = 0; s < 5; ++s) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xa[i] = xn[i];
+            D::f_tr(xa, u, tr, k0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k0[i];
+            D::f_tr(xb, u, tr, k1);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k1[i];
+            D::f_tr(xb, u, tr, k2);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
+            D::f_tr(xb, u, tr, k3);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
             div6_vec<NS>(xb);

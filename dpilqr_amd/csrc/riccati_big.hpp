@@ -683,7 +683,14 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     // direct store sp[row] = vij[v] from here faulted -- HSA aperture violation on mid-solve iterates of the
                     // twelve-state family, every index in range -- in the build that still spilled 95 registers around this
                     // loop, and runs clean since the lane terms are formed per phase (45 spilled): a code-generation problem of
-                    // that build, not of the store.  The round trip through the scratch costs one barrier and is kept.)
+                    // that build, not of the store.  The round trip through the scratch costs one barrier and is kept.
+                    // Round 4 met the same error again WITHOUT any store here having changed: sincos pairs in the models' Jacobians
+                    // raised this kernel's spills from 64 to 82 registers and config 5's backward pass died on its first launch,
+                    // deterministically, in a fresh process -- and ran to the end under rocgdb.  No flat instruction in the
+                    // listing, 108 scratch loads / stores (the spills).  So what correlates is the NUMBER OF SPILLED REGISTERS
+                    // (scalar registers spilled into vector lanes that are spilled in turn is the suspicion), not an index of this
+                    // kernel; the Jacobians are back to separate sin / cos and tests/test_kernel_resources.py holds the
+                    // kernel to the spill counts it is known to run with.)
                     if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes

@@ -52,3 +52,17 @@ def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
         assert r["sgpr_spill_count"] <= 96, (k, r)                              # round 2: up to 1012
     big = table["k_riccati_wg<60, 30, 4, 2, true>"]
     assert big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 256            # cfg3's 15-unicycle clusters: two per CU
+
+
+def test_large_cluster_sweep_stays_at_its_known_good_spill_count(table):
+    """k_riccati_big (n_x > 60, fp32 arm) runs sixteen wavefronts per workgroup at 128 registers per lane and spills.  A build in
+    which the twelve-state instantiation spilled 82 registers (instead of 64: sincos pairs in the Jacobians) died on config 5's
+    heterogeneous team with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- deterministically, with every index in range, and not
+    under rocgdb (round 4; round 3 saw the same error in a build that spilled 95).  The cause is not understood (spilled scalar
+    registers restored wrongly is the suspicion); until it is, the kernel is held to the spill counts it is known to run with, here
+    where no GPU is needed, and tests/test_gpu_big.py runs config 5's passes and whole solves on the GPU."""
+    bounds = {"k_riccati_big<double, 12, 4>": 64, "k_riccati_big<double, 3, 2>": 66, "k_riccati_big<double, 4, 2>": 47,
+              "k_riccati_big<double, 6, 3>": 34, "k_riccati_big<float, 12, 4>": 40}
+    for k, b in bounds.items():
+        assert table[k]["vgpr_spill_count"] <= b, (k, table[k]["vgpr_spill_count"], b)
+        assert table[k]["vgpr_count"] <= 128, k
