@@ -5,7 +5,7 @@
 # Summaries: the *_kernel_stats.csv of the first pass is copied as it is; scripts/summarize_pmc.py turns the FETCH_SIZE /
 # WRITE_SIZE passes into profiles/r03_bench_hbm_counters.csv and profiles/riccati_traffic.json (which names the sweep's source
 # hash: bench.py reports roofline.traffic = null when the file was measured on another version of the kernel).
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_kt -- python3 bench.py --steps 20 --warmup 5 --reps 5 --no-cpu-baseline > gpurun_out/${R}_kt_bench.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_fetch -- python3 bench.py --steps 16 --warmup 1 --reps 1 --no-cpu-baseline > gpurun_out/${R}_fetch.log 2>&1

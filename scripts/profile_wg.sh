@@ -2,7 +2,7 @@
 # Counters of the mid-size sweep k_riccati_wg (profiles/r03_wg_counters.csv): run on the GPU box from the repo root through gpurun.
 # Each --pmc set in a pass of its own, never together with a trace domain.  The workload: scripts/solve_breakdown.py, one
 # windowed solve of 2048 clusters of 15 Unicycle4D / 10 Quadcopter6D agents (the fused sweep, the line search).
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for m in "uni4 15" "quad6 10"; do
   tag=$(echo $m | tr ' ' '_')

@@ -22,6 +22,8 @@ seen_wave_producer = 'k_make_tiles_wave' in open(fetch_csv).read()
 
 
 def short(name):
+    # the record-fed wavefront sweep (bench.py's separate "tiles through HBM" measurement at the end of a run) apart from the fused one
+    if "k_riccati_mfma<" in name and ", true>" not in name and "team" not in name and "general" not in name: return "riccati_records"
     if "k_riccati" in name: return "riccati"
     if "k_make_tiles_wave" in name: return "tiles"
     if "k_make_tiles" in name: return "tiles_static" if seen_wave_producer else "tiles"
@@ -39,7 +41,7 @@ def load(path, counter):
 F, Wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
 rows = []
 out = {}
-for k in [c for c in ("riccati", "tiles", "tiles_static", "forward") if c in F]:
+for k in [c for c in ("riccati", "riccati_records", "tiles", "tiles_static", "forward") if c in F]:
     gmax = max(g for g, _, _ in F[k])
     full_f = [v for g, v, _ in F[k] if g == gmax]
     full_w = [v for g, v, _ in Wr[k] if g == gmax]
@@ -64,10 +66,19 @@ js = {"kernel": name.split("(")[0].replace("void dpilqr::", ""), "window_items":
                 "bench.py --steps 16 --warmup 1 --reps 1 --no-cpu-baseline)"}
 tj = ROOT / "profiles" / "riccati_traffic.json"
 old = json.loads(tj.read_text()) if tj.exists() else {}
-if fused:      # keep the record-fed sweep's entry (bench.py reads it when DPILQR_NO_FUSED is set), add the fused one beside it
+if fused:      # the fused sweep's entry beside the record-fed sweep's (bench.py reads that one when DPILQR_NO_FUSED is set)
     old["hbm_bytes_per_subproblem_pass_fused"] = js["hbm_bytes_per_subproblem_pass"]
     old["fused"] = js
     js = old
+    if "riccati_records" in out:     # the same passes also saw bench.py's record-fed launches (full window): refresh that entry too
+        fr, wrr, nm = out["riccati_records"]
+        tot = 2 * fr * 1024 + wrr * 1024
+        js.update({"kernel": nm.split("(")[0].replace("void dpilqr::", ""), "window_items": window,
+                   "FETCH_SIZE_KB_full_window_launch": fr, "WRITE_SIZE_KB_full_window_launch": wrr,
+                   "hbm_bytes_per_full_window_launch": tot, "hbm_bytes_per_subproblem_pass": tot / window,
+                   "algorithmic_bytes_per_subproblem_pass": 619360,
+                   "source": f"profiles/{tag}_bench_hbm_counters.csv, row riccati_records: the launches of bench.py's roofline_tiles_through_hbm "
+                             "leg inside the same two passes"})
 else:
     for key in ("hbm_bytes_per_subproblem_pass_fused", "fused"):
         if key in old:
