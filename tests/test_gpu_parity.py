@@ -763,3 +763,33 @@ def test_heading_models_rotated_sincos_against_the_oracle(dp, model, ns, nc):
         xo = np.stack([orc.model_integrate(model, xo[i], u[i] * 0.2, 0.1) for i in range(256)])
     err = np.abs(xs - xo) / np.maximum(np.abs(xo), 1.0)
     assert err.max() < 1e-11, float(err.max())
+
+
+@pytest.mark.parametrize("model,k", [(0, 5), (0, 4), (3, 5), (0, 2)])
+def test_team_sweep_equals_the_one_wavefront_sweep(dp, model, k):
+    """Launches of at most 1024 items run the fused sweep with a TEAM of two wavefronts per item (the helper evaluates the plugins
+    a step ahead and takes the second 16-row tile of S4..S6; riccati_mfma.hpp HELP), larger launches one wavefront per item, two or
+    three per SIMD.  The same items through both (a 700-item batch, and as the first 700 of 1500 and of 3000): gains bit for bit.
+    DoubleIntDynamics4D (the flagship form) and UnicycleDynamics4D with per-agent weights (the general form); n_x = 8 has one
+    row tile only (the helper then serves the plugin data alone)."""
+    from dpilqr_amd.device import to_dev
+    T = 30
+    rng = np.random.default_rng(300 + 10 * model + k)
+    Bbig = 3000
+    xf = rng.normal(size=(Bbig, 4 * k)); x0 = rng.normal(size=(Bbig, 4 * k)) * 0.6
+    if model == 3:
+        x0[:, 3::4] = rng.uniform(-4, 4, size=(Bbig, k))
+    U0 = rng.normal(size=(Bbig, T, 2 * k)) * 0.3
+    Q = np.array([[1.0, 0.2, 0, 0], [0.1, 1.5, 0, 0.3], [0, 0, 0.4, 0], [0, 0.2, 0, 0.1]])
+    Qk = np.stack([Q * (1 + 0.1 * i) for i in range(k)]) if model == 3 else Q
+    R = np.array([[1.0, 0.1], [0.3, 2.0]]); Qf = 50.0 * np.eye(4) + 0.5
+    rad = rng.uniform(0.3, 0.9, size=Bbig); mu_h = rng.choice([0.0, 0.125, 1.0], size=Bbig)
+    out = {}
+    for B in (700, 1500, 3000):
+        pb = dp.ProblemBatch([model] * k, [2] * k, xf[:B], Qk, R, Qf, rad[:B], 0.1, T)
+        X, _ = pb.rollout(x0[:B], U0[:B])
+        out[B] = pb.backward_pass_fused(X, U0[:B], to_dev(mu_h[:B]))
+    K7, d7 = out[700]
+    assert bool(torch.isfinite(K7).all())
+    for B in (1500, 3000):
+        assert torch.equal(out[B][0][:700], K7) and torch.equal(out[B][1][:700], d7), B
