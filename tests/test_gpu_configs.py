@@ -2,8 +2,9 @@
 reference-generated golden tests: test_gpu_api.py::test_solver_solve[cfg1], test_gpu_parity.py, test_gpu_big.py).
 
   cfg3  15-agent UnicycleDynamics4D DP-iLQR, proximity-graph split -> variable-size sub-problem batch, T = 100
-  cfg4  Monte-Carlo random-goal seeds x 10-agent QuadcopterDynamics6D, T = 75 (1024 of the 8192 seeds here -- one rank's
-        share at 8 GPUs; all 8192 on one GPU: scripts/montecarlo.py, profiles/)
+  cfg4  Monte-Carlo random-goal seeds x 10-agent QuadcopterDynamics6D, T = 75: 1024 of the 8192 seeds -- one rank's share at
+        8 GPUs -- audited solve by solve against the oracle, and ALL 8192 on one GPU held to the size-independent properties
+        (stitched trajectory = rollout of the stitched controls bit for bit, J_full, determinism, independence of the batch)
 """
 from concurrent.futures import ThreadPoolExecutor
 
@@ -164,3 +165,42 @@ def test_cfg4_monte_carlo_1024_seeds_ten_quadcopters_T75(dp):
         _, Jo = p.rollout(x0[s], Ud[s])
         assert abs(J[s] - Jo) <= 1e-9 * abs(Jo) or not np.isfinite(Jo), (s, J[s], Jo)
     assert np.isfinite(Xd).all() and np.isfinite(J).all()
+
+
+def test_cfg4_all_8192_seeds_on_one_gpu_properties(dp):
+    """BASELINE configs[3] at its FULL size -- 8192 random-goal seeds x 10 QuadcopterDynamics6D, T = 75 -- on one GPU through the
+    many-scenario front end (the first 1024 seeds are audited solve by solve against the oracle in the test above; 81 920
+    (scenario, agent) sub-problems are too many for the CPU oracle inside a test).  Held to the properties that do not depend on
+    the size: (1) the scenarios generated on the device are the reference's (spot-checked against the host generator, bit for bit);
+    (2) the graphs of a sample of scenarios equal the oracle's; (3) every agent's stitched trajectory is the rollout of its
+    stitched controls bit for bit (dynamics decouple per agent: quirk Q11) and J_full is that rollout's cost; (4) everything
+    finite, every cluster size 1..10 accounted for; (5) the call is deterministic (a second call, bit-identical); (6) the first
+    1024 scenarios' results do not depend on the other 7168 being in the batch (bit-identical to a 1024-scenario call)."""
+    import torch
+    from oracle import oracle as orc
+    from dpilqr_amd.dispatch import solve_scenarios_distributed
+    from dpilqr_amd.util import random_setup, random_setup_batch
+    k, T, S, ns, nc = 10, 75, 8192, 6, 3
+    x0d, xfd = random_setup_batch((0, S), k, ns, var=k / 2, n_d=3, energy=10.0)
+    x0, xf = x0d.cpu().numpy(), xfd.cpu().numpy()
+    for s in (0, 1, 4095, 8191):
+        np.random.seed(s)
+        a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=3, random=True, energy=10.0)
+        assert np.array_equal(x0[s], a.ravel()) and np.array_equal(xf[s], b.ravel()), s
+    prob, (Q, R, Qf, nd) = build(dp, dp.QuadcopterDynamics6D, k, x0[0], xf[0])
+    U0 = torch.zeros((S, T, nc * k), dtype=torch.float64, device="cuda"); U0[:, :, 0::3] = G
+    Xd, Ud, J, info = solve_scenarios_distributed(prob, x0d[:, None, :], U0, 0.5, xf=xfd, device_out=True)
+    assert info["n_subproblems"] == S * k and set(info["sizes"]) == set(range(1, 11))
+    assert sum(info["sizes"].values()) == info["n_unique"] <= S * k
+    assert bool(torch.isfinite(Xd).all()) and bool(torch.isfinite(Ud).all()) and bool(torch.isfinite(J).all())
+    for s in (0, 7, 1000, 5000, 8191):
+        graph = orc.define_inter_graph_threshold(x0[s][None], 0.5, k, ns)
+        assert list(info["cluster_bits"][s]) == [sum(1 << j for j in graph[i]) for i in range(k)], s
+    full = dp.ProblemBatch([4] * k, [3] * k, xfd, Q, R, Qf, 0.5, 0.1, T)
+    Xr, Jr = full.rollout(x0d, Ud)
+    assert torch.equal(Xr, Xd), "a stitched trajectory is not the rollout of its stitched controls"
+    assert torch.equal(Jr, J)
+    Xd2, Ud2, J2, _ = solve_scenarios_distributed(prob, x0d[:, None, :], U0, 0.5, xf=xfd, device_out=True)
+    assert torch.equal(Xd2, Xd) and torch.equal(Ud2, Ud) and torch.equal(J2, J)
+    Xs, Us, Js, _ = solve_scenarios_distributed(prob, x0d[:1024, None, :], U0[:1024], 0.5, xf=xfd[:1024], device_out=True)
+    assert torch.equal(Xs, Xd[:1024]) and torch.equal(Us, Ud[:1024]) and torch.equal(Js, J[:1024])
