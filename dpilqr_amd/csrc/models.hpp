@@ -74,7 +74,12 @@ template <> struct ModelDef<kCar3D> {  // x=[px,py,theta] u=[v,omega]
         f_sc(x, u, sn, cs, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+#ifdef DPILQR_JAC_SINCOS
+        R s, c;
+        sincos_r(x[2], &s, &c);
+#else
         const R s = sin(x[2]), c = cos(x[2]);
+#endif
         A[0 * 3 + 2] = -u[0] * s; A[1 * 3 + 2] = u[0] * c;
         B[0 * 2 + 0] = c; B[1 * 2 + 0] = s; B[2 * 2 + 1] = 1.0;
     }
@@ -92,7 +97,12 @@ template <> struct ModelDef<kUnicycle4D> {  // x=[px,py,v,theta] u=[a,omega]
         f_sc(x, u, sn, cs, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
+#ifdef DPILQR_JAC_SINCOS
+        R s, c;
+        sincos_r(x[3], &s, &c);
+#else
         const R s = sin(x[3]), c = cos(x[3]);
+#endif
         A[0 * 4 + 2] = c; A[0 * 4 + 3] = -x[2] * s;
         A[1 * 4 + 2] = s; A[1 * 4 + 3] = x[2] * c;
         B[2 * 2 + 0] = 1.0; B[3 * 2 + 1] = 1.0;
@@ -133,7 +143,12 @@ template <> struct ModelDef<kHuman6D> {  // x=[px,py,pz,v,0,0] u=[heading,accel,
         f_tr(x, u, tr, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+#ifdef DPILQR_JAC_SINCOS
+        R s, c;
+        sincos_r(u[0], &s, &c);
+#else
         const R s = sin(u[0]), c = cos(u[0]);
+#endif
         A[0 * 6 + 3] = c; A[1 * 6 + 3] = s;
         B[0 * 3 + 0] = -x[3] * s; B[1 * 3 + 0] = x[3] * c; B[3 * 3 + 1] = 1.0;
     }
@@ -188,8 +203,14 @@ template <> struct ModelDef<kQuadcopter12D> {
         // per lane, 64 of them spilled already) the build with 82 spilled registers died with an HSA memory aperture
         // violation on config 5's heterogeneous team -- deterministically, and not under rocgdb.  tests/test_kernel_resources.py
         // holds that kernel to the spill count it is known to run with.)
+#ifdef DPILQR_JAC_SINCOS   // diagnostic builds only: the form that raises the large-cluster sweep's spills to 82 registers (see above)
+        R sps, cps, sth, cth, sph, cph;
+        sincos_r(x[3], &sps, &cps); sincos_r(x[4], &sth, &cth); sincos_r(x[5], &sph, &cph);
+        const R tth = tan(x[4]);
+#else
         const R sps = sin(x[3]), cps = cos(x[3]), sth = sin(x[4]), cth = cos(x[4]);
         const R sph = sin(x[5]), cph = cos(x[5]), tth = tan(x[4]);
+#endif
         const R c2 = cth * cth, sec2 = tth * tth + 1;
         const R vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
 #define A_(r, c) A[(r) * 12 + (c)]
@@ -252,7 +273,12 @@ template <> struct ModelDef<kHumanPad12D> {  // x=[px,py,pz,v,0,0 | 6 padded sta
         f_tr(x, u, tr, o);
     }
     template <typename R> __device__ static void jac(const R* x, const R* u, R* A, R* B) {
+#ifdef DPILQR_JAC_SINCOS
+        R s, c;
+        sincos_r(u[0], &s, &c);
+#else
         const R s = sin(u[0]), c = cos(u[0]);
+#endif
         A[0 * 12 + 3] = c; A[1 * 12 + 3] = s;
         B[0 * 4 + 0] = -x[3] * s; B[1 * 4 + 0] = x[3] * c; B[3 * 4 + 1] = 1.0;
     }

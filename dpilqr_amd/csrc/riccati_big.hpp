@@ -272,6 +272,8 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #define BPHASE(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[i] += now_ - bph_t; bph_t = now_; }
 #elif defined(DPILQR_PHASE_MARKS)   // assembly listings only (scripts/isa_census.py)
 #define BPHASE(i) asm volatile("; ==== end of phase " #i);
+#elif defined(DPILQR_BIG_STOP)      // diagnostic builds only: leave the kernel behind phase DPILQR_BIG_STOP of the first step (localising a fault)
+#define BPHASE(i) if (DPILQR_BIG_STOP == (i)) return;
 #else
 #define BPHASE(i)
 #endif
@@ -687,10 +689,18 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     // Round 4 met the same error again WITHOUT any store here having changed: sincos pairs in the models' Jacobians
                     // raised this kernel's spills from 64 to 82 registers and config 5's backward pass died on its first launch,
                     // deterministically, in a fresh process -- and ran to the end under rocgdb.  No flat instruction in the
-                    // listing, 108 scratch loads / stores (the spills).  So what correlates is the NUMBER OF SPILLED REGISTERS
-                    // (scalar registers spilled into vector lanes that are spilled in turn is the suspicion), not an index of this
-                    // kernel; the Jacobians are back to separate sin / cos and tests/test_kernel_resources.py holds the
-                    // kernel to the spill counts it is known to run with.)
+                    // listing, 108 scratch loads / stores (the spills).  That build (-DDPILQR_JAC_SINCOS rebuilds it) with the
+                    // kernel cut off behind each phase of the first step (-DDPILQR_BIG_STOP=i) ran clean at every cut AND uncut
+                    // on one GPU box, and the very same binaries died on the next two boxes: the failure depends on the machine's
+                    // state (what the scratch memory held, where things were mapped), not on the data, and rocgdb -- no address
+                    // randomisation, fresh mappings -- hides it.  An "aperture violation" is an address outside every GPU
+                    // aperture, i.e. a 64-bit pointer with a wrong high half: a reload of a spill slot that this path never
+                    // stored (or stored with some lanes off: scalar registers spilled into the lanes of a vector register that
+                    // is spilled in turn) is what fits all of it.  What correlates is the NUMBER OF SPILLED REGISTERS (82
+                    // vector + 132 scalar there; 64 + 108 in the build that has passed every run of rounds 3 and 4), not an
+                    // index of this kernel; the Jacobians are back to separate sin / cos and tests/test_kernel_resources.py
+                    // holds the kernel to the spill counts it is known to run with.  The cure is fewer live 64-bit pointers
+                    // (three dozen per wavefront: scratch regions, trajectory, gains, descriptor arrays).)
                     if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes
