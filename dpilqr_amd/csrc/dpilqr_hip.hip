@@ -97,15 +97,16 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
 // window, and clear the counter the NEXT iteration will push into.  ctl = {count, admitted} mailbox copy.
 // mail[2] = the finished PREFIX: items are admitted in index order, so every item below the smallest index still on the
 // list has finished and its results are final in memory (the progress callback of dpilqr_solver_set_progress).
+// want_prefix = 0: nobody listens for progress, the scan of the list for its lowest index is skipped (mail[2] = 0).
 __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window,
-                        int32_t* mail) {
+                        int32_t* mail, int want_prefix) {
     const int base = *count, first = *admitted;
     const int n_new = min(B - first, window - base);
     __shared__ int lowest;
     if (threadIdx.x == 0) lowest = first;
     __syncthreads();
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
-    if (mail) {
+    if (mail && want_prefix) {
         int lo = first;
         for (int i = threadIdx.x; i < base; i += blockDim.x) lo = min(lo, list[i]);
         for (int off = 32; off > 0; off >>= 1) lo = min(lo, __shfl_down(lo, off));
@@ -114,7 +115,7 @@ __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int3
     }
     if (threadIdx.x == 0) {
         *count = base + n_new; *admitted = first + n_new; *next_count = 0;
-        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; mail[2] = lowest; }   // pinned host memory: the host reads it after the event
+        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; mail[2] = want_prefix ? lowest : 0; }   // pinned host memory: the host reads it after the event
     }
 }
 
@@ -439,7 +440,8 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         int32_t* cur_n = counts + (it % kCountRing);
         int32_t* nxt_n = counts + ((it + 1) % kCountRing);
         int32_t* mail = solver ? solver->dev + kMailWords * (it % kMailRing) : nullptr;
-        hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail);
+        hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail,
+                           (solver && solver->progress) ? 1 : 0);
         if (solver) HIP_TRY(hipEventRecord(solver->ev[it % kMailRing], st));
         S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
         S.next_count = nxt_n;
