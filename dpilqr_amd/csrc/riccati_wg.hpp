@@ -311,14 +311,25 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
                 bad = bad || (row > Kp + j && kGjThreshold * fabs(a) > fabs(pv));
                 l[it] = (row != Kp + j) ? a * ninv : 0.0;
             }
+            // The DPP operand of these updates is the pivot row's entry, pan[itp][jj] / W[itp][jp] read from lane L.  The row
+            // tile that holds the pivot row goes LAST: every other tile's update then reads a register that was last written a
+            // whole pivot stage ago, and the pivot tile's own update reads the register it overwrites -- no update follows a
+            // write of its DPP operand within two instructions, so none needs the s_nop (6 RT per pivot, 290 per step at
+            // m = 30).  (fmac_row_nn is a volatile asm: the updates keep this order.)
 #pragma unroll
             for (int jj = j + 1; jj < 4; ++jj)
 #pragma unroll
-                for (int it = 0; it < RT; ++it) pan[it][jj] = fmac_row(pan[it][jj], pan[itp][jj], l[it], L);
+                for (int io = 1; io <= RT; ++io) {
+                    const int it = (itp + io) % RT;
+                    pan[it][jj] = fmac_row_nn(pan[it][jj], pan[itp][jj], l[it], L);
+                }
 #pragma unroll
             for (int jp = 0; jp < j; ++jp)
 #pragma unroll
-                for (int it = 0; it < RT; ++it) W[it][jp] = fmac_row(W[it][jp], W[itp][jp], l[it], L);
+                for (int io = 1; io <= RT; ++io) {
+                    const int it = (itp + io) % RT;
+                    W[it][jp] = fmac_row_nn(W[it][jp], W[itp][jp], l[it], L);
+                }
 #pragma unroll
             for (int it = 0; it < RT; ++it) W[it][j] = (16 * it + c != Kp + j) ? l[it] : W[it][j];
         }
