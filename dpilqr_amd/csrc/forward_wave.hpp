@@ -144,6 +144,13 @@ struct WaveFwdLds {
     // ... and one for twelve-state agents (Quadcopter12D's RK4 stages hold 7 x 12 doubles next to the sincos expansions: 64 .. 102
     // scratch loads per step at two; one to three agents 11 .. 18 % faster with one, five equal; scripts/bench_q12.py)
     static constexpr int OCC = ((NW > 1 && NS >= 6 && KA >= 9) || NS >= 12) ? 1 : DPILQR_LS_OCC;
+    // Steps of K[t], d[t], X[t], U[t] in flight ahead of the one being computed.  A step is a dependent chain of about the length of
+    // one trip to HBM: with one step ahead the wavefront still waits for its data at the top of every step.  Two stages where the
+    // registers allow it (four-state agents, one wavefront per item: 22 more registers of 50 spare).  DPILQR_LS_PF: A/B builds.
+#ifndef DPILQR_LS_PF
+#define DPILQR_LS_PF 2
+#endif
+    static constexpr int PF = (NW == 1 && NS == 4 && !CONST_LDS) ? DPILQR_LS_PF : 1;
     static constexpr int oQ = (octl + 2 + 1) & ~1;                 // Q [agent][NS*NS]
     static constexpr int oR = oQ + (CONST_LDS ? KA * NS * NS : 0); // R [agent][NC*NC]
     static constexpr int oXf = oR + (CONST_LDS ? KA * NC * NC : 0);
@@ -234,21 +241,35 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
     double* scr0 = lds + W::ocr + g * KA;            // + parity * NG * KA
     double* scp0 = lds + W::ocp + g * NP1;           // + parity * NG * NP1
 
-    // ---- step data: registers <- HBM one step ahead
-    v2d stK[KV];
-    double std_ = 0.0, u[NC], xold[NS], x[NS];
-    auto fetch = [&](int t) {
+    // ---- step data: registers <- HBM, PF steps ahead (one register stage per step in flight)
+    struct Stage { v2d stK[KV]; double std_, u[NC], xold[NS]; };
+    constexpr int PF = W::PF;
+    Stage stg[PF];
+    double x[NS];
+    // K[t] LAST: loads return in order and K[t] is what a step consumes first (the staging at its top), so the one wait of a step
+    // stands there, where everything outstanding is at least a step old.  With X[t] last the wait for it stood behind the
+    // candidate stores of the step and drained them too -- a store's round trip in every step of the chain.
+    auto fetch = [&](Stage& sg, int t) {
         const double* Kt = Kb + (int64_t)t * mn;
+#ifdef DPILQR_LS_K_FIRST   // A/B builds: the order of rounds 1-3
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
             const int e = min(tid + NTH * q, mn / 2 - 1);
-            stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
+            sg.stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
         }
-        std_ = db[(int64_t)t * m + min(tid, m - 1)];
+#endif
 #pragma unroll
-        for (int i = 0; i < NC; ++i) u[i] = Ub[(int64_t)t * m + a * NC + i];
+        for (int i = 0; i < NS; ++i) sg.xold[i] = Xb[(int64_t)t * n + a * NS + i];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) xold[i] = Xb[(int64_t)t * n + a * NS + i];
+        for (int i = 0; i < NC; ++i) sg.u[i] = Ub[(int64_t)t * m + a * NC + i];
+        sg.std_ = db[(int64_t)t * m + min(tid, m - 1)];
+#ifndef DPILQR_LS_K_FIRST
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+            const int e = min(tid + NTH * q, mn / 2 - 1);
+            sg.stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
+        }
+#endif
     };
     auto store_vec = [&](double* p, const double* v, int len) {   // len doubles, 16-byte aligned when len is even
         if ((len & 1) == 0) {
@@ -280,7 +301,9 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 
 #pragma unroll
     for (int i = 0; i < NS; ++i) x[i] = Xb[a * NS + i];
-    fetch(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < T) fetch(stg[s], s);
     double J = 0.0;
     double ut[NC];
 #pragma unroll
@@ -289,7 +312,11 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long w_wait = 0, w_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int t = 0; t < T; ++t) {
+    auto step = [&](Stage& sg, int t) {
+        v2d (&stK)[KV] = sg.stK;
+        double& std_ = sg.std_;
+        double (&u)[NC] = sg.u;
+        double (&xold)[NS] = sg.xold;
 #ifdef DPILQR_PHASE_STAMPS
         {
             const unsigned long long a0 = __builtin_amdgcn_s_memtime();
@@ -331,7 +358,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
             }
         }
         wave_sync<NW>();
-        if (t + 1 < T) fetch(t + 1);
+        if (t + PF < T) fetch(sg, t + PF);
         if (a == 0 && t > 0) stage_cost(J, (t & 1) ^ 1);   // stage cost of step t-1
         DPILQR_LDS_FENCE();
         // du = K[t] dx + alpha d[t] (control.py:106): this agent's NC rows, j ascending
@@ -393,6 +420,13 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = xn[i];
         wave_sync<NW>();   // everybody is done with this step's staged K, d, dx, x'
+    };
+    if constexpr (PF == 1) {
+        for (int t = 0; t < T; ++t) step(stg[0], t);
+    } else {
+        int t = 0;
+        for (; t + 1 < T; t += 2) { step(stg[0], t); step(stg[1], t + 1); }
+        if (t < T) step(stg[0], t);
     }
 #ifdef DPILQR_PHASE_STAMPS
     if (g_stamp_buf && tid == 0) {
