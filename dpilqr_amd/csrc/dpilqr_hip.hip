@@ -662,8 +662,8 @@ int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* 
     if (desc->B == 0) return DPILQR_OK;
     if (!X || !U || !mu || !K || !d) return fail(DPILQR_EINVAL, "backward_pass_fused: NULL pointer");
     if (!fused_sweep_applies(*desc))
-        return fail(DPILQR_EUNSUPPORTED, "backward_pass_fused: needs 6..15 four-state or 2..10 six-state agents, or at most five DoubleIntDynamics4D / "
-                                         "UnicycleDynamics4D agents with n_dims = 2 (uniform_model hints)");
+        return fail(DPILQR_EUNSUPPORTED, "backward_pass_fused: needs 6..15 four-state, 1..10 six-state or 1..6 CarDynamics3D agents, or at most five "
+                                         "DoubleIntDynamics4D / UnicycleDynamics4D agents with n_dims = 2 (uniform_model hints)");
     rc = launch_riccati_fused(*desc, X, U, mu, K, d, singular, nullptr, nullptr, desc->B, 0, as_stream(stream));
     return rc == DPILQR_EUNSUPPORTED ? fail(rc, "backward_pass_fused: no instantiation for n_x=%d", desc->k * desc->n_s) : rc;
 }

@@ -74,8 +74,16 @@ inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_WG") != nullptr;
     return !off && ((D.n_s == 4 && D.n_c == 2 && D.k >= 6 && D.k <= 15) || (D.n_s == 6 && D.n_c == 3 && D.k >= 2 && D.k <= 10));
 }
+// Wavefront sweep with in-sweep production (riccati_mfma.hpp, PNS; tu_inprod.hip): at most four agents of the six-state family
+// (n_x <= 24) or at most six CarDynamics3D agents (n_x <= 18) -- any models of the family, any per-agent weights, any n_dims --
+// padded into the next instantiated size.
+inline bool fused_wavefront_inprod_applies(const dpilqr_batch_desc& D) {
+    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_INPROD") != nullptr;
+    return !off && ((D.n_s == 6 && D.n_c == 3 && D.k <= 4) || (D.n_s == 3 && D.n_c == 2 && D.k <= 6));
+}
 inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
-    return fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D) || fused_workgroup_sweep_applies(D);
+    return fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D) || fused_workgroup_sweep_applies(D) ||
+           fused_wavefront_inprod_applies(D);
 }
 // The solve loop's choice where both a record-free workgroup sweep and a record-fed WAVEFRONT sweep serve a batch: at
 // n_x = 12 and 24 (two / four six-state agents: cfg4's small clusters; six four-state agents: cfg3's smallest) a wavefront
@@ -87,6 +95,8 @@ inline bool solve_prefers_records(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_WAVE_PREF") != nullptr;
     // round 4: three six-state agents (n_x = 18: 16 % of cfg4's sub-problems) through the (20, 10) wavefront sweep, padded
     // while loading (riccati_mfma.hpp, PAD; DPILQR_RICCATI_NO_PAD switches it off in the launcher)
+    // (two .. four six-state agents: records unless the in-sweep producer serves them)
+    if (fused_wavefront_inprod_applies(D)) { static const bool rec = getenv("DPILQR_INPROD_RECORDS") != nullptr; return rec; }
     return !off && ((D.n_s == 6 && D.n_c == 3 && (D.k == 2 || D.k == 3 || D.k == 4)) || (D.n_s == 4 && D.n_c == 2 && D.k == 6));
 }
 
@@ -109,6 +119,11 @@ int32_t set_stamp_buffer_riccati(void* device_buffer);
 int32_t launch_riccati_team(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
                             int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items, int gains_by_item,
                             hipStream_t st);
+
+// ---- tu_inprod.hip: the wavefront sweeps with in-sweep production (six-state family up to four agents, CarDynamics3D up to six)
+int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
+                              int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items, int gains_by_item,
+                              hipStream_t st);
 
 // ---- tu_forward.hip
 int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,

@@ -32,6 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "riccati_tiled.hpp"
 
 namespace dpilqr {
@@ -104,6 +106,28 @@ struct MfmaCfg {
     static constexpr bool supported = (N % 4 == 0) && (M % 2 == 0) && (N + M + 1 <= 64) && (total * 8 <= 40 * 1024);
     static constexpr int AB_PAIRS = N * NM / 2;
     static constexpr int AB_ROUNDS = (AB_PAIRS + 63) / 64;
+};
+
+// PNS > 0 (riccati_mfma_sweep, "in-sweep production"): what the padded sweep adds per step -- L_xx, L_uu, [l_x | l_u] in the
+// padded sizes -- and the producer's scratch, behind the sweep's own LDS (MfmaCfg::total).  PNS = the agents' state dimension.
+template <int N, int M, int PNS>
+struct InprodCfg {
+    static constexpr int PNC = PNS == 6 ? 3 : (PNS == 12 ? 4 : 2);
+    static constexpr int KA = PNS > 0 ? ((N / (PNS > 0 ? PNS : 1)) < (M / PNC) ? (N / (PNS > 0 ? PNS : 1)) : (M / PNC)) : 0;   // most agents (N, M) holds
+    static constexpr int NPR = KA * (KA - 1) / 2, NPR1 = NPR > 0 ? NPR : 1;
+    static constexpr int oLxx = 0;                                  // L_xx [N][N]: zero off the agents' blocks and the coupling blocks
+    static constexpr int oLuu = oLxx + N * N;                       // L_uu [M][M]: w_ref (R + R^T) blocks, 1 on the padded diagonal
+    static constexpr int oLxu = oLuu + M * M;                       // [l_x | l_u] [N + M]
+    static constexpr int oX = oLxu + round_up(N + M, 2);            // x     [n]
+    static constexpr int oE = oX + round_up(N, 2);                  // x - x_f
+    static constexpr int oU = oE + round_up(N, 2);                  // u     [m]
+    static constexpr int oXf = oU + round_up(M, 2);                 // x_f
+    static constexpr int oGp = oXf + round_up(N, 2);                // pair gradients [pairs][3]
+    static constexpr int oHp = oGp + round_up(3 * NPR1, 2);         // pair Hessians  [pairs][9]
+    static constexpr int oQQ = oHp + round_up(9 * NPR1, 2);         // Q + Q^T [agent][PNS * PNS]
+    static constexpr int oRR = oQQ + round_up(KA * PNS * PNS, 2);   // R + R^T [agent][PNC * PNC]
+    static constexpr int oPair = round_up(oRR + KA * PNC * PNC, 2);    // the pair table (ints)
+    static constexpr int total = PNS > 0 ? round_up(oPair + (NPR1 + 1) / 2, 2) : 0;
 };
 
 // fp64 vector operations whose FIRST operand is taken from lane L of the executing lane's 16-lane row (DPP
@@ -332,7 +356,14 @@ struct FusedArgs {
 // plugin data (fused_step_data: pair derivatives, their per-agent sums, [l_x | l_u], the A entries -- 12 % of a lone
 // wavefront's step, profiles/r04_phase_stamps.txt) one step AHEAD into the other of two buffers; the two meet at one
 // s_barrier per step.  Same expressions, same order: bit-identical gains.
-template <int N, int M, int WAVES, int NS, int NC, int FUSED, bool PAD = false, bool HELP = false>
+// PNS > 0 (with PAD): IN-SWEEP PRODUCTION, the record-free form for the cluster sizes and models the fused forms above are not
+// written for (the six-state family, CarDynamics3D; PNS = the agents' state dimension, any models of that family, any per-agent
+// weights, any n_dims).  There are no tile records: at the top of a step the wavefront evaluates MultiDynamicalModel.linearize
+// and GameCost.quadraticize of (X[t], U[t]) itself -- the sparse tile producer's expressions and summation orders (tiles.hpp) --
+// straight into the padded [A|B] operand and into padded L_xx / L_uu / [l_x | l_u] arrays in LDS, which the S1 / S2 epilogues
+// read where the record-fed form reads its prefetch registers.  The gains are those of the record-fed padded sweep bit for bit;
+// per pass and item the sweep reads 8 ((T + 1) n_x + T n_u) bytes of trajectory instead of (T + 1) records.
+template <int N, int M, int WAVES, int NS, int NC, int FUSED, bool PAD = false, bool HELP = false, int PNS = 0>
 __device__ __forceinline__ void riccati_mfma_sweep(
     int B, int T, const double* __restrict__ tiles, const double* __restrict__ mu_arr, double* __restrict__ Kout,
     double* __restrict__ dout, int32_t* __restrict__ singular, const int32_t* __restrict__ items,
@@ -341,6 +372,9 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     static_assert(!FUSED || (NS == 4 && NC == 2), "the fused variants are written for the four-state family's blocks");
     static_assert(!HELP || (FUSED != 0 && WAVES == 4), "the helper wavefront serves the fused forms at one item per SIMD");
     static_assert(!PAD || (NS == 0 && FUSED == 0), "padding while loading is written for the dense record-fed form");
+    static_assert(PNS == 0 || (NS == 0 && FUSED == 0 && !HELP), "in-sweep production builds on the dense form (padded, or of the exact size: n_rec = N, m_rec = M)");
+    constexpr bool INP = PNS > 0;
+    using IC = InprodCfg<N, M, PNS>;
     constexpr bool FGEN = (FUSED == 2);   // per-agent weights, per-agent model (DoubleIntDynamics4D / UnicycleDynamics4D)
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, LAB = C::LAB, LT = C::LT, LP = C::LP, LQ = C::LQ, LG = C::LG;
     constexpr int LK = C::LK, LM = C::LM, T_NM = C::T_NM, T_NP = C::T_NP, T_N = C::T_N, T_M = C::T_M;
@@ -375,7 +409,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
     const TileLayout L(PAD ? n_rec : N, PAD ? m_rec : M);
 
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    double* lds = lds_all + wave * C::total;
+    double* lds = lds_all + wave * (C::total + IC::total);
     double* sAB = lds + C::oAB;
     double* sT = lds + C::oT;
     double* sK = lds + C::oK;          // [K | d], KROWS rows (rows >= M zero), after S2
@@ -388,7 +422,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
 
     const double mu = mu_arr[b];
     const double f_radius = FUSED ? F.D.radius[(int64_t)b * F.D.radius_bstride] : 0.0;
-    const double* base = FUSED ? nullptr : tiles + (int64_t)slot * (T + 1) * L.stride;
+    const double* base = (FUSED || INP) ? nullptr : tiles + (int64_t)slot * (T + 1) * L.stride;
     int sing = 0;
     unsigned long long* const stamps = g_stamp_buf;
     unsigned long long t_start = 0;
@@ -493,11 +527,25 @@ __device__ __forceinline__ void riccati_mfma_sweep(
             }
         }
     }
+#include "riccati_mfma_inprod.inc"
     {
     const int lane = lane0;
-    for (int e = lane; e < C::total; e += 64) lds[e] = 0.0;
+    for (int e = lane; e < C::total + IC::total; e += 64) lds[e] = 0.0;
     DPILQR_LDS_FENCE();
-    if constexpr (!FUSED) {
+    if constexpr (INP) {
+        // the constants; then the terminal condition P = l_xx(T), p = l_x(T) (control.py:125-129) from the producer's own arrays
+        inp_constants();
+        inp_prefetch(T);
+        inp_produce(T, true);
+        for (int e = lane; e < N * N; e += 64) {
+            const int i = e / N, j = e - i * N;
+            sP[i * LP + j] = sLxx[e];
+        }
+        for (int i = lane; i < N; i += 64) sP[i * LP + N] = sLxu[i];
+        DPILQR_LDS_FENCE();
+        inp_lxx_blocks(false, true);     // the agents' whole blocks again, with Q in place of Q_f
+        inp_prefetch(T - 1);
+    } else if constexpr (!FUSED) {
         const double* rec = base + (int64_t)T * L.stride;
         for (int e = lane; e < N * N; e += 64) {
             const int i = e / N, j = e - i * N;
@@ -556,6 +604,7 @@ __device__ __forceinline__ void riccati_mfma_sweep(
         for (int j = lane; j < N; j += 64) sP[j * LP + N] = sFL[j];
         DPILQR_LDS_FENCE();
         if constexpr (!HELP) fused_prefetch(T - 1);
+    } else if constexpr (INP) {
     } else {
     prefetch_ab(T - 1);
     if constexpr (BD) {
@@ -591,6 +640,10 @@ __device__ __forceinline__ void riccati_mfma_sweep(
             // the step's pair derivatives and [l_x | l_u]; then the next step's share of the trajectory is requested
             fused_step_data(t, nullptr);
             fused_prefetch(tn);
+        } else if constexpr (INP) {
+            // this step's [A|B], L_xx, [l_x | l_u] from (X[t], U[t]); then the next step's share of the trajectory is requested
+            inp_produce(t, false);
+            inp_prefetch(tn);
         } else {
 #pragma unroll
         for (int q = 0; q < C::AB_ROUNDS; ++q) *reinterpret_cast<v2d*>(ab_dst[q]) = nAB[q];
@@ -714,13 +767,17 @@ __device__ __forceinline__ void riccati_mfma_sweep(
                     });
                     // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
                     if (16 * jt <= N && N < 16 * jt + 16) {
-                        for_rows(16 * it, 0, N, g, colP[jt], [&](int v, int r) { sQx[g + r] = nLxu[it][v] + acc[it][jt][v]; });
-                        for_rows(16 * it, N, NM, g, colP[jt], [&](int v, int r) { dG[M + N + r * LG] = nLxu[it][v] + acc[it][jt][v]; });
+                        for_rows(16 * it, 0, N, g, colP[jt], [&](int v, int r) {
+                            sQx[g + r] = (INP ? sLxu[g + r] : nLxu[it][v]) + acc[it][jt][v];
+                        });
+                        for_rows(16 * it, N, NM, g, colP[jt], [&](int v, int r) {
+                            dG[M + N + r * LG] = (INP ? sLxu[N + g + r] : nLxu[it][v]) + acc[it][jt][v];
+                        });
                     }
                 }
         }
         DPILQR_LDS_FENCE();
-        if constexpr (!BD && !FUSED) prefetch_lxu(tn);
+        if constexpr (!BD && !FUSED && !INP) prefetch_lxu(tn);
         MPHASE(1)
         }
         {
@@ -823,13 +880,24 @@ __device__ __forceinline__ void riccati_mfma_sweep(
             for (int it = 0; it < T_NM; ++it)
 #pragma unroll
                 for (int jt = 0; jt < T_NM; ++jt) {
+                    if constexpr (INP) {   // the l-values from the producer's arrays: L_xx[i][j]; row a of [L_ux | L_uu] (L_ux = 0)
+                        const int j = 16 * jt + c16;
+                        for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) {
+                            dQ[16 * jt + r * LQ] = sLxx[(g + r) * N + j] + acc[it][jt][v];
+                        });
+                        for_rows(16 * it, N, NM, g, colNM[jt], [&](int v, int r) {
+                            const double luu = sLuu[(g + r) * M + max(j - N, 0)];
+                            dG[colG[jt] + r * LG] = (j >= N ? luu : 0.0) + acc[it][jt][v];
+                        });
+                    } else {
                     for_rows(16 * it, 0, N, g, colN[jt], [&](int v, int r) { dQ[16 * jt + r * LQ] = nL[it][jt][v] + acc[it][jt][v]; });
                     for_rows(16 * it, N, NM, g, colNM[jt], [&](int v, int r) { dG[colG[jt] + r * LG] = nL[it][jt][v] + acc[it][jt][v]; });
+                    }
                 }
         }
         DPILQR_LDS_FENCE();
         if (lane < N) sQ[lane * LQ + N] = sQx[lane];   // Q_x joins Q_xx now that [A|B] is dead
-        if constexpr (FUSED) {} else if constexpr (BD) { prefetch_bd_x(tn); if constexpr (!LATE_L) prefetch_bd_l(tn); } else prefetch_l(tn);
+        if constexpr (FUSED || INP) {} else if constexpr (BD) { prefetch_bd_x(tn); if constexpr (!LATE_L) prefetch_bd_l(tn); } else prefetch_l(tn);
         // sT is dead from here on and becomes [K | d] + T3^T: the reduction-padding rows of [K | d] must read as zero
         for (int e = lane; e < (C::KROWS - M) * LK; e += 64) sK[M * LK + e] = 0.0;
         MPHASE(2)
@@ -1045,6 +1113,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma_pad(
     const int32_t* __restrict__ n_items, int gains_by_item, int n_cus, int n_rec, int m_rec) {
     riccati_mfma_sweep<N, M, WAVES, 0, 0, 0, true>(B, T, tiles, mu_arr, Kout, dout, singular, items, n_items, gains_by_item, n_cus,
                                                    FusedArgs{}, n_rec, m_rec);
+}
+
+// In-sweep production (PNS above): the record-free sweep for clusters of the six-state family and of CarDynamics3D, (n_rec, m_rec)
+// = k (PNS, PNC) padded into (N, M) (PAD), or of exactly that size.
+template <int N, int M, int WAVES, int PNS, bool PAD>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void k_riccati_mfma_inprod(
+    int B, int T, const double* __restrict__ mu_arr, double* __restrict__ Kout, double* __restrict__ dout,
+    int32_t* __restrict__ singular, const int32_t* __restrict__ items, const int32_t* __restrict__ n_items, int gains_by_item,
+    int n_cus, FusedArgs F, int n_rec, int m_rec) {
+    riccati_mfma_sweep<N, M, WAVES, 0, 0, 0, PAD, false, PNS>(B, T, nullptr, mu_arr, Kout, dout, singular, items, n_items,
+                                                              gains_by_item, n_cus, F, PAD ? n_rec : N, PAD ? m_rec : M);
 }
 
 // The record-free sweep's general form for the four-state family (FUSED = 2 above): at most five agents of one model --

@@ -188,6 +188,11 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
         HIP_TRY(hipGetLastError());                                                                                \
         return DPILQR_OK;                                                                                          \
     }
+    // the six-state family up to four agents, CarDynamics3D up to six: in-sweep production (tu_inprod.hip)
+    {
+        const int32_t rc_ip = launch_riccati_inprod(D, X, U, mu, K, d, singular, items, n_items, grid_items, gains_by_item, st);
+        if (rc_ip != DPILQR_EUNSUPPORTED) return rc_ip;
+    }
     // launches of at most one item per SIMD: a team of two wavefronts per item (tu_team.hip)
     if (grid_items <= 1024 && max_wv >= 4 && (fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D))) {
         const int32_t rc_team = launch_riccati_team(D, X, U, mu, K, d, singular, items, n_items, grid_items, gains_by_item, st);

@@ -451,6 +451,43 @@ def test_sweep_six_state_family(dp, k):
         assert relerr(K[i].cpu().numpy(), Ko) < TOL_PASS and relerr(d[i].cpu().numpy(), do) < TOL_PASS, i
 
 
+@pytest.mark.parametrize("models", [[4], [4, 4], [4, 4, 4], [4, 4, 4, 4], [1, 5, 6], [4, 1], [5, 6, 4, 1],
+                                    [2], [2, 2], [2, 2, 2], [2] * 4, [2] * 5, [2] * 6])
+def test_in_sweep_production_equals_the_record_fed_sweep(dp, models):
+    """Clusters of at most four agents of the six-state family and at most six CarDynamics3D agents: the record-free wavefront
+    sweep evaluates linearize / quadraticize inside the sweep, straight into the padded operands (riccati_mfma.hpp, PNS), where the
+    record-fed padded sweep reads the tile producer's records.  Same expressions, same orders: the gains bit for bit -- any
+    models of the family (mixed), per-agent Q / R / Q_f, per-item radius and mu, n_dims 2 and 3 mixed, near and far pairs; a
+    37-item batch (one wavefront per SIMD) and the same items as the first 37 of 1300 (two per SIMD)."""
+    from dpilqr_amd.device import to_dev
+    k = len(models); ns = 6 if models[0] != 2 else 3; nc = 3 if ns == 6 else 2
+    T = 14
+    rng = np.random.default_rng(900 + 7 * k + ns)
+    Bbig = 1300
+    xf = rng.normal(size=(Bbig, ns * k)); x0 = rng.normal(size=(Bbig, ns * k)) * 0.7
+    x0[:, 0::ns] += 0.8 * np.arange(k)        # agents apart on average, some pairs inside the radius
+    U0 = rng.normal(size=(Bbig, T, nc * k)) * 0.2
+    if ns == 6:
+        for a, mdl in enumerate(models):
+            if mdl == 4: U0[:, :, nc * a] += 9.80665
+    Q = np.stack([np.diag(rng.uniform(0.5, 2.0, ns)) + 0.05 * rng.normal(size=(ns, ns)) for _ in range(k)])
+    R = np.stack([np.diag(rng.uniform(0.5, 2.0, nc)) + 0.05 * rng.normal(size=(nc, nc)) for _ in range(k)])
+    Qf = np.stack([30.0 * np.eye(ns) + rng.normal(size=(ns, ns)) for _ in range(k)])
+    n_dims = [3 if (ns == 6 and a % 2 == 0) else 2 for a in range(k)]
+    rad = rng.uniform(0.4, 1.5, size=Bbig); mu_h = rng.choice([0.0, 0.125, 1.0], size=Bbig)
+    out = {}
+    for B in (37, Bbig):
+        pb = dp.ProblemBatch(models, n_dims, xf[:B], Q, R, Qf, rad[:B], 0.1, T)
+        X, _ = pb.rollout(x0[:B], U0[:B])
+        mu = to_dev(mu_h[:B])
+        Kf, df = pb.backward_pass_fused(X, U0[:B], mu)
+        Kr, dr = pb.backward_pass(X, U0[:B], mu)
+        assert bool(torch.isfinite(Kf).all()) and float(Kf.abs().max()) > 0
+        assert torch.equal(Kf, Kr) and torch.equal(df, dr), B
+        out[B] = (Kf, df)
+    assert torch.equal(out[Bbig][0][:37], out[37][0]) and torch.equal(out[Bbig][1][:37], out[37][1])
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 5])
 def test_sweep_twelve_state_family(dp, k):
     """Quadcopter12D clusters (n_x = 12 k) through the workgroup-per-item sweep (k >= 2) and the size-generic one
