@@ -29,6 +29,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "riccati_mfma.hpp"
 
 namespace dpilqr {
@@ -232,21 +235,29 @@ __device__ __attribute__((noinline)) int lu_fallback_wg(const double* __restrict
 //
 // Pivoting: threshold pivoting that prefers the diagonal.  The diagonal entry is the pivot as long as no entry below it in its
 // column is more than 8 times larger (the threshold rule of sparse LU with a diagonal preference -- UMFPACK / MA48 use 0.1
-// there, KLU 0.001; element growth per step is bounded by 1 + 8 instead of partial pivoting's 2).  A looser threshold declines
-// less often -- 7 % / 4 % / 2 % / 1.5 % of the steps of 15-unicycle iterates at 8 / 16 / 32 / 64 (scripts/threshold_study.py),
-// each decline a 50 k-cycle register LU all four wavefronts wait for, 4..7 k cycles per step on average -- and at 64 a 2048-item
-// sweep is 12..14 % faster; but the end-to-end envelope (oracle/parity.py) sees the price: over cfg4's 8077 audited solves the
-// worst cost error sits at 2.6 / 4.7 / 7.5 / 12.9 ensemble spreads (allowed: 10; scripts/envelope_tail.py,
-// profiles/r03_gj_threshold_tails.txt).  8 stays.  (DPILQR_GJ_THRESHOLD: A/B builds.)
-// Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is
-// NOT always positive definite away from a minimum (half of the steps of a fresh 15-unicycle iterate have a negative pivot),
-// which is why the rule looks at magnitudes.  If the rule fails anywhere, or a pivot is zero / not finite, nothing has been
-// written and the caller runs LAPACK-order partial pivoting (lu_eliminate<true>) instead.  Every wavefront factorises the
-// same Q_uu with the same instructions, so all of them take the same decision.
+// there, KLU 0.001; element growth per step is bounded by 1 + 8 instead of partial pivoting's 2); where the rule fails -- 7 % of
+// the steps of 15-unicycle iterates have such a column (scripts/threshold_study.py) -- the largest entry below the diagonal comes
+// up (dgetf2's choice among those rows): the two rows change places in the panel, in W's finished columns and, before the
+// panel's update, in the tiles it touches (see the swap block below).  Round 3 declined the whole step instead and ran a
+// 50 k-cycle register LU all four wavefronts waited for; a looser threshold declined less often but the end-to-end envelope
+// (oracle/parity.py) saw the price (worst cost error 2.6 / 4.7 / 7.5 / 12.9 ensemble spreads at 8 / 16 / 32 / 64,
+// profiles/r03_gj_threshold_tails.txt), so 8 stays.  With the swaps, on 2048 real iterates (profiles/r04_gj_row_swaps.txt): the
+// record-fed sweep 8.39 -> 7.51 ms (ten quadcopters, T = 75) and 11.27 -> 9.73 ms (fifteen unicycles, T = 100), the fused one
+// 9.04 -> 8.73 and 12.27 -> 11.53.  (DPILQR_GJ_THRESHOLD, DPILQR_GJ_NO_SWAP: A/B builds.)
+// Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is NOT always positive definite away from a minimum (half
+// of the steps of a fresh 15-unicycle iterate have a negative pivot), which is why the rule looks at magnitudes.  Only a pivot
+// that is zero or not finite after the search (a singular or poisoned Q_uu) makes the caller run the register LU with
+// LAPACK-order partial pivoting (lu_eliminate<true>), which reports the singularity; nothing has been written by then.  Every
+// wavefront factorises the same Q_uu with the same instructions, so all of them take the same decisions.
 #ifndef DPILQR_GJ_THRESHOLD
 #define DPILQR_GJ_THRESHOLD 8
 #endif
 constexpr double kGjThreshold = 1.0 / DPILQR_GJ_THRESHOLD;
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N_, typename F>
+__device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_integer_sequence<int, N_>{}); }
 
 template <int M, int MO, int LG, int LK, int NP>
 __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double* __restrict__ sK, double* __restrict__ sPan,
@@ -270,9 +281,11 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
             acc[it][RT][v] = (row < M && q < NP) ? y : 0.0;
         }
     bool bad = false;
-#pragma unroll
-    for (int p = 0; p < NPAN; ++p) {
-        const int Kp = 4 * p, itp = Kp / 16, vp = (Kp % 16) / 4, cp = Kp % 16;
+    // (the panels by instantiation, not by `#pragma unroll`: with the row swaps the loop outgrew the size up to which the pragma is
+    // honoured, and a panel index that is not a constant puts `acc` into scratch memory -- the sweep ran 3.8 times slower)
+    auto panel = [&](auto p_tag) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_tag)::value;
+        constexpr int Kp = 4 * p, itp = Kp / 16, vp = (Kp % 16) / 4, cp = Kp % 16;
         // 1. the panel's columns -> row layout
         if (c >= cp && c < cp + 4) {
 #pragma unroll
@@ -293,9 +306,64 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
         DPILQR_LDS_FENCE();
         // 2. Gauss-Jordan on the panel, W alongside
         double invs[4];
+        int sw_r[4] = {-1, -1, -1, -1};     // row that changed places with row Kp + j, if any
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int L = cp + j;
+#ifndef DPILQR_GJ_NO_SWAP   // (A/B builds: the round-3 form, which declined the whole step instead)
+            {   // the threshold rule; where it fails (a few per cent of the steps), the largest entry below comes up: rows swapped
+                const double pv0 = mov_row(pan[itp][j], L);
+                bool viol = false;
+#pragma unroll
+                for (int it = 0; it < RT; ++it)
+                    viol = viol || (16 * it + c > Kp + j && kGjThreshold * fabs(pan[it][j]) > fabs(pv0));
+                if (__builtin_amdgcn_ballot_w64(viol) != 0ull) {
+                    // first largest |entry| of column Kp + j below the diagonal (dgetf2's idamax over those rows): every 16-lane row
+                    // of the wavefront holds the same copy of the panel, so the reduction stays inside a row
+                    double best = 0.0;
+                    int brow = 0;
+#pragma unroll
+                    for (int it = 0; it < RT; ++it) {
+                        const double av = fabs(pan[it][j]);
+                        const bool take = (16 * it + c > Kp + j) && av > best;
+                        best = take ? av : best;
+                        brow = take ? 16 * it + c : brow;
+                    }
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        const double ob = __shfl_xor(best, off, 16);
+                        const int orow = __shfl_xor(brow, off, 16);
+                        const bool take = ob > best || (ob == best && ob > 0.0 && orow < brow);
+                        best = take ? ob : best;
+                        brow = take ? orow : brow;
+                    }
+                    const int r = __builtin_amdgcn_readfirstlane(brow);
+                    if (r > Kp + j) {
+                        // rows Kp + j and r change places: in the panel (all four columns) and in W's finished columns (the multipliers
+                        // are attributes of the rows; the unit entries of the columns still to come belong to the positions) now; in
+                        // the tiles the panel's update will touch -- its B operand is then the rows that are pivots now -- before
+                        // that update (sw_r)
+                        const int itB = r >> 4, cB = r & 15;
+                        const int cA = L;
+                        const int srcB = (lane & 48) | cB, srcA = (lane & 48) | cA;
+                        auto swap_row_layout = [&](double (&x)[RT][4], int col) {
+                            double vb = x[0][col];
+#pragma unroll
+                            for (int it = 1; it < RT; ++it) vb = (it == itB) ? x[it][col] : vb;
+                            const double fromB = __shfl(vb, srcB), fromA = __shfl(x[itp][col], srcA);
+#pragma unroll
+                            for (int it = 0; it < RT; ++it) x[it][col] = (it == itB && c == cB) ? fromA : x[it][col];
+                            x[itp][col] = (c == cA) ? fromB : x[itp][col];
+                        };
+#pragma unroll
+                        for (int col = 0; col < 4; ++col) swap_row_layout(pan, col);
+#pragma unroll
+                        for (int jp = 0; jp < j; ++jp) swap_row_layout(W, jp);
+                        sw_r[j] = r;
+                    }
+                }
+            }
+#endif
             const double pv = mov_row(pan[itp][j], L);
             double inv = __builtin_amdgcn_rcp(pv);
             inv = fma(fma(-pv, inv, 1.0), inv, inv);
@@ -308,7 +376,9 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
             for (int it = 0; it < RT; ++it) {
                 const int row = 16 * it + c;
                 const double a = pan[it][j];
+#ifdef DPILQR_GJ_NO_SWAP
                 bad = bad || (row > Kp + j && kGjThreshold * fabs(a) > fabs(pv));
+#endif
                 l[it] = (row != Kp + j) ? a * ninv : 0.0;
             }
             // The DPP operand of these updates is the pivot row's entry, pan[itp][jj] / W[itp][jp] read from lane L.  The row
@@ -340,6 +410,39 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) W[itp][jp] = W[itp][jp] * sc;
         }
+#ifndef DPILQR_GJ_NO_SWAP
+        // the panel's row swaps, in their order, on the tiles the update is about to touch.  Row Kp + s is register vp of lane
+        // group s of row tile itp; its partner r is found at run time (a loop, not unrolled: rare, and four copies of it per panel
+        // made the kernel too large for the compiler to keep its arrays in registers)
+        if (max(max(sw_r[0], sw_r[1]), max(sw_r[2], sw_r[3])) >= 0) {
+#pragma unroll 1
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int r = sidx == 0 ? sw_r[0] : (sidx == 1 ? sw_r[1] : (sidx == 2 ? sw_r[2] : sw_r[3]));
+                if (r < 0) continue;
+                const int itB = r >> 4, vB = (r & 15) >> 2, gB = r & 3;
+#pragma unroll
+                for (int jt = 0; jt < CT; ++jt) {
+                    if (jt < itp) continue;
+                    double y = 0.0;
+#pragma unroll
+                    for (int it = 0; it < RT; ++it)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) y = (it == itB && v == vB) ? acc[it][jt][v] : y;
+                    const double x = acc[itp][jt][vp];
+                    const double yA = __shfl(y, 16 * gB + c), xB = __shfl(x, 16 * sidx + c);
+#pragma unroll
+                    for (int it = 0; it < RT; ++it)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            double e = acc[it][jt][v];
+                            e = (it == itB && v == vB && g == gB) ? xB : e;
+                            e = (it == itp && v == vp && g == sidx) ? yA : e;
+                            acc[it][jt][v] = e;
+                        }
+                }
+            }
+        }
+#endif
         // 3. everything from the panel's tile on: += W * (the panel's rows), the panel's rows themselves replaced
         // (W pinned first: seen through, the selects that built W and this one are merged into control flow -- seven
         // branches per panel)
@@ -363,7 +466,8 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
 #pragma unroll
             for (int it = 0; it < RT; ++it) acc[it][jt] = mfma_f64(a_op[it], b, acc[it][jt]);
         }
-    }
+    };
+    static_for<NPAN>(panel);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return true;
 #pragma unroll
     for (int it = 0; it < RT; ++it)

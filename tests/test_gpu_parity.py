@@ -386,11 +386,12 @@ def test_sweep_dominance_shortcut_boundary(dp, k, blocks):
 @pytest.mark.parametrize("k,blocks", [(12, (4, 2)), (15, (4, 2)), (8, (6, 3)), (10, (6, 3))])
 def test_sweep_blocked_elimination_and_its_fallback(dp, k, blocks):
     """From n_u = 24 on the mid-size sweep solves Q_uu [K|d] = -[Q_ux|Q_u] by blocks (riccati_wg.hpp, gj_blocked): Gauss-Jordan
-    on 4-column panels with threshold pivoting that keeps the diagonal while no entry below it is more than 8 times larger,
-    and LAPACK-order partial pivoting in registers when that rule fails.  One launch mixes items that take either route --
-    dominant; diagonal the largest of its column; an entry 6 times the diagonal below it (blocks accept, dgesv would swap);
-    an entry 12 times the diagonal (blocks decline); an exactly zero diagonal entry -- and every one must give the oracle's
-    (dgesv-ordered) gains.  B = 0 makes Q_uu = L_uu at every step, so the test controls the matrix exactly."""
+    on 4-column panels with threshold pivoting that keeps the diagonal while no entry below it is more than 8 times larger
+    and swaps the largest entry up when one is (rows exchanged in the panel, in the multipliers and in the tiles the panel's
+    update touches); LAPACK-order partial pivoting in registers only for a singular or non-finite Q_uu.  One launch mixes items
+    that take every route -- dominant; diagonal the largest of its column; an entry 6 times the diagonal below it (kept, dgesv
+    would swap); an entry 12 times the diagonal (swapped); an exactly zero diagonal entry (swapped) -- and every one must give
+    the oracle's (dgesv-ordered) gains.  B = 0 makes Q_uu = L_uu at every step, so the test controls the matrix exactly."""
     from oracle import oracle as orc
     ns, nc = blocks
     rng = np.random.default_rng(300 + k + ns)
