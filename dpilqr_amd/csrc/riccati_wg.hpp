@@ -311,8 +311,9 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
         for (int j = 0; j < 4; ++j) {
             const int L = cp + j;
 #ifndef DPILQR_GJ_NO_SWAP   // (A/B builds: the round-3 form, which declined the whole step instead)
+            double pv = mov_row(pan[itp][j], L);
             {   // the threshold rule; where it fails (a few per cent of the steps), the largest entry below comes up: rows swapped
-                const double pv0 = mov_row(pan[itp][j], L);
+                const double pv0 = pv;
                 bool viol = false;
 #pragma unroll
                 for (int it = 0; it < RT; ++it)
@@ -360,11 +361,13 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
 #pragma unroll
                         for (int jp = 0; jp < j; ++jp) swap_row_layout(W, jp);
                         sw_r[j] = r;
+                        pv = mov_row(pan[itp][j], L);
                     }
                 }
             }
-#endif
+#else
             const double pv = mov_row(pan[itp][j], L);
+#endif
             double inv = __builtin_amdgcn_rcp(pv);
             inv = fma(fma(-pv, inv, 1.0), inv, inv);
             inv = fma(fma(-pv, inv, 1.0), inv, inv);

@@ -42,16 +42,28 @@ def test_bench_path_kernels_do_not_spill(table):
 def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
     """cfg3 / cfg4's sweeps (the solve loop's default is the FUSED form): at most a handful of loop-invariant values in
     scratch (reloaded a few times per step), no spilled register inside the phases; the scratch the metadata reports is the
-    stack of the out-of-line register LU (lu_fallback_wg), which runs on the few per cent of steps the blocked elimination
-    declines."""
+    stack of the out-of-line register LU (lu_fallback_wg: singular Q_uu only since round 4).  Round 4's first build of the row
+    swaps inside the blocked elimination put the accumulator tiles into scratch (336 B per lane at n_u = 24: a loop the
+    `#pragma unroll` no longer unrolled) and ran 3.8 times slower without any other symptom: the scratch bound below is that
+    build's tripwire."""
     wg = {k: r for k, r in table.items() if k.startswith("k_riccati_wg<")}
     assert len(wg) >= 40
     for k, r in wg.items():
         fused = k.endswith("true>")
         assert r["vgpr_spill_count"] <= 16, (k, r)                              # round 2: up to 48
-        assert r["sgpr_spill_count"] <= 96, (k, r)                              # round 2: up to 1012
+        assert r["sgpr_spill_count"] <= 128, (k, r)                             # round 2: up to 1012 (round 4's swap bookkeeping: <= 113, into lanes of a vector register)
+        assert r["private_segment_fixed_size"] <= 256, (k, r)                   # the fall-back's stack (<= 228 B); arrays in scratch: 336+
     big = table["k_riccati_wg<60, 30, 4, 2, true>"]
     assert big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 256            # cfg3's 15-unicycle clusters: two per CU
+
+
+def test_in_sweep_production_kernels_do_not_spill(table):
+    """The record-free wavefront sweeps of the six-state family and CarDynamics3D (k_riccati_mfma_inprod): no spilled vector
+    register and no scratch at either occupancy (they hold an agent's whole Jacobian, 54 doubles, in registers for a moment)."""
+    ip = {k: r for k, r in table.items() if k.startswith("k_riccati_mfma_inprod<")}
+    assert len(ip) == 20
+    for k, r in ip.items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (k, r)
 
 
 def test_large_cluster_sweep_stays_at_its_known_good_spill_count(table):
