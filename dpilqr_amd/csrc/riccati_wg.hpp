@@ -496,6 +496,11 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
     constexpr int NM = C::NM, NP = C::NP, MK = C::MK, KA = C::KA, NSC = C::NSC, NSCP = C::NSCP, LP = C::LP, LQ = C::LQ;
     constexpr int LG = C::LG, LK = C::LK, LM = C::LM, MO = C::MO, T_NP = C::T_NP, T_N = C::T_N;
     constexpr bool AL = C::AL, ALA = C::ALA;
+#ifndef DPILQR_WG_NO_STRUCT4   // (A/B builds)
+    constexpr bool STRUCT4 = FUSED && NS == 4 && NC == 2;   // the library's own four-state models: S1 / S2 by the blocks' structure
+#else
+    constexpr bool STRUCT4 = false;
+#endif
     const int slot = blockIdx.x;
     if (slot >= (n_items ? *n_items : B)) return;
     const int b = items ? items[slot] : slot;
@@ -758,6 +763,29 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         for (int r = 0; r < C::R1R; ++r) {
             const int ag = ag1[r], j0 = j01[r];
             double acc[NSC * 2];   // [i][c]
+            if constexpr (STRUCT4) {
+                // The four-state family's blocks (DoubleIntDynamics4D, UnicycleDynamics4D; models.hpp jac): A = I + dt A_c with
+                // A_c's entries (0,2), (1,2), (0,3), (1,3) free and nothing else, B = dt [0; 0; I].  Of the four-term chains of the
+                // general form below only these terms are not a multiplication by an exact 0 or 1 -- dropped or written as what
+                // they are, the results are the chains' bit for bit (a zero's sign apart): 8 instead of 48 multiply-adds per item.
+                double pr4[4][2];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) ld_row<2, true>(sP + (NS * ag + l) * LP + j0, pr4[l]);
+                const double* ab0 = sAB + (NS * ag) * NSCP;
+                double r0[2], r1[2];
+                ld_row<2, true>(ab0 + 2, r0);              // a02, a03
+                ld_row<2, true>(ab0 + NSCP + 2, r1);       // a12, a13
+                const double b20 = ab0[2 * NSCP + 4], b31 = ab0[3 * NSCP + 5];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[0 + c] = pr4[0][c];
+                    acc[2 + c] = pr4[1][c];
+                    acc[4 + c] = fma(r1[0], pr4[1][c], r0[0] * pr4[0][c]) + pr4[2][c];
+                    acc[6 + c] = fma(r1[1], pr4[1][c], r0[1] * pr4[0][c]) + pr4[3][c];
+                    acc[8 + c] = b20 * pr4[2][c];
+                    acc[10 + c] = b31 * pr4[3][c];
+                }
+            } else {
             double ab[2][NSC], pr[2][2];   // the operand rows of l and l + 1
             ld_row<NSC, true>(sAB + (NS * ag) * NSCP, ab[0]);
             ld_row<2, true>(sP + (NS * ag) * LP + j0, pr[0]);
@@ -773,6 +801,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                     for (int c = 0; c < 2; ++c)
                         acc[2 * i + c] = (l == 0) ? ab[l & 1][i] * pr[l & 1][c] : fma(ab[l & 1][i], pr[l & 1][c], acc[2 * i + c]);
                 pin_regs(acc);
+            }
             }
             // T2 rows: + mu B[j][c]   (quirk Q6: B^T (P + mu I) = B^T P + mu B^T); row j of B is zero outside agent j / NS
 #pragma unroll
@@ -891,6 +920,22 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                         if (!xrow && own) nL[r][q][NS + lj] = wr * w[lj];
                 }
             }
+            if constexpr (STRUCT4) {   // see S1: columns 0, 1 of T A are T's, 2 and 3 two free terms plus T's own, T B = T_2 b20, T_3 b31
+                const double* ab0 = sAB + (NS * ag) * NSCP;
+                double r0[2], r1[2];
+                ld_row<2, true>(ab0 + 2, r0);
+                ld_row<2, true>(ab0 + NSCP + 2, r1);
+                const double b20 = ab0[2 * NSCP + 4], b31 = ab0[3 * NSCP + 5];
+#pragma unroll
+                for (int q = 0; q < C::RPL; ++q) {
+                    acc[q * NSC + 0] = tv[q][0];
+                    acc[q * NSC + 1] = tv[q][1];
+                    acc[q * NSC + 2] = fma(tv[q][1], r1[0], tv[q][0] * r0[0]) + tv[q][2];
+                    acc[q * NSC + 3] = fma(tv[q][1], r1[1], tv[q][0] * r0[1]) + tv[q][3];
+                    acc[q * NSC + 4] = tv[q][2] * b20;
+                    acc[q * NSC + 5] = tv[q][3] * b31;
+                }
+            } else {
             double ab[2][NSC];
             ld_row<NSC, true>(sAB + (NS * ag) * NSCP, ab[0]);
 #pragma unroll
@@ -902,6 +947,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                     for (int c = 0; c < NSC; ++c)
                         acc[q * NSC + c] = (l == 0) ? tv[q][l] * ab[l & 1][c] : fma(tv[q][l], ab[l & 1][c], acc[q * NSC + c]);
                 pin_regs(acc);
+            }
             }
             if (tid_p + kWgThreads * r < C::NI2) {
 #pragma unroll
