@@ -79,7 +79,13 @@ inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
 // padded into the next instantiated size.
 inline bool fused_wavefront_inprod_applies(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_INPROD") != nullptr;
-    return !off && ((D.n_s == 6 && D.n_c == 3 && D.k <= 4) || (D.n_s == 3 && D.n_c == 2 && D.k <= 6));
+    static const bool no4 = getenv("DPILQR_NO_INPROD4") != nullptr;   // A/B switch: the four-state clusters' previous routes
+    if (off) return false;
+    // ... and what is left of the four-state family at n_x <= 24: at most five agents WITHOUT the hints the forms above need (a
+    // proximity cost over three dimensions, mixed models unannounced), and six agents (n_x = 24)
+    if (D.n_s == 4 && D.n_c == 2 && D.k <= 6 && !no4)
+        return !fused_wavefront_sweep_applies(D) && !fused_wavefront_general_applies(D);
+    return (D.n_s == 6 && D.n_c == 3 && D.k <= 4) || (D.n_s == 3 && D.n_c == 2 && D.k <= 6);
 }
 inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
     return fused_wavefront_sweep_applies(D) || fused_wavefront_general_applies(D) || fused_workgroup_sweep_applies(D) ||

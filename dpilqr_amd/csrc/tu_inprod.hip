@@ -1,5 +1,6 @@
 // tu_inprod.hip -- K2, the wavefront sweeps with in-sweep production (riccati_mfma.hpp, PNS): the record-free form for clusters
-// of at most four agents of the six-state family and at most six CarDynamics3D agents, padded into the next instantiated size.
+// of at most four agents of the six-state family, at most six CarDynamics3D agents (padded into the next instantiated size) and
+// the four-state clusters the fused forms of tu_riccati.hip do not serve.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -41,6 +42,9 @@ int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const
     // five (15, 10) -> (20, 10); six (18, 12) -> (24, 12)
     DPILQR_TRY_INPROD(4, 2, 3) DPILQR_TRY_INPROD(8, 4, 3) DPILQR_TRY_INPROD(12, 6, 3) DPILQR_TRY_INPROD(16, 8, 3)
     DPILQR_TRY_INPROD(20, 10, 3) DPILQR_TRY_INPROD(24, 12, 3)
+    // four-state family (exact sizes): clusters of at most five agents without the fused forms' hints; six agents
+    DPILQR_TRY_INPROD(4, 2, 4) DPILQR_TRY_INPROD(8, 4, 4) DPILQR_TRY_INPROD(12, 6, 4) DPILQR_TRY_INPROD(16, 8, 4)
+    DPILQR_TRY_INPROD(20, 10, 4) DPILQR_TRY_INPROD(24, 12, 4)
 #undef DPILQR_TRY_INPROD
     return DPILQR_EUNSUPPORTED;
 }

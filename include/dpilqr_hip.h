@@ -173,9 +173,12 @@ int32_t dpilqr_backward_pass(const dpilqr_batch_desc* desc, const double* X, con
  * (12 KB instead of 535 KB per cfg2 pass); (a') at most five agents of the planar four-state models -- DoubleIntDynamics4D
  * and UnicycleDynamics4D, mixed or not (the descriptor's model hint or its bit 17) -- with n_dims = 2 everywhere and ANY
  * per-agent, per-item Q, R, Q_f;
- * (b) 6..15 agents of the four-state family or 2..10 of the six-state family, any
- * models of the family, any weights (cfg3 / cfg4 clusters: 90 doubles instead of a 94 KB record per step at n_x = 60).
- * DPILQR_EUNSUPPORTED for any other batch (CarDynamics3D and six-state agents at n_x <= 20, twelve-state agents).  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
+ * (b) 6..15 agents of the four-state family or 5..10 of the six-state family, any
+ * models of the family, any weights (cfg3 / cfg4 clusters: 90 doubles instead of a 94 KB record per step at n_x = 60);
+ * (c) 1..4 agents of the six-state family or 1..6 CarDynamics3D agents, any models of the family, any weights, any n_dims
+ * (the plugins evaluated inside the padded wavefront sweep).
+ * DPILQR_EUNSUPPORTED for any other batch (twelve-state agents, four-state clusters of at most five agents without
+ * the hints).  dpilqr_solve_batch picks it by itself, and its workspace then holds no records. */
 int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc* desc, const double* X, const double* U, const double* mu, double* K,
                                    double* d, int32_t* singular, void* stream);
 /* ilqrSolver._forward_pass (control.py:95-114) for n_alpha step sizes at once:

@@ -453,15 +453,17 @@ def test_sweep_six_state_family(dp, k):
 
 
 @pytest.mark.parametrize("models", [[4], [4, 4], [4, 4, 4], [4, 4, 4, 4], [1, 5, 6], [4, 1], [5, 6, 4, 1],
-                                    [2], [2, 2], [2, 2, 2], [2] * 4, [2] * 5, [2] * 6])
+                                    [2], [2, 2], [2, 2, 2], [2] * 4, [2] * 5, [2] * 6,
+                                    [3] * 6, [0] * 6, [0, 3, 0, 3, 3, 0], [3], [0, 3], [3, 0, 3], [0] * 4, [3, 3, 0, 0, 3]])
 def test_in_sweep_production_equals_the_record_fed_sweep(dp, models):
-    """Clusters of at most four agents of the six-state family and at most six CarDynamics3D agents: the record-free wavefront
+    """Clusters of at most four agents of the six-state family, at most six CarDynamics3D agents, and the four-state clusters the
+    fused forms do not serve (six agents; fewer with a proximity cost over mixed dimensions): the record-free wavefront
     sweep evaluates linearize / quadraticize inside the sweep, straight into the padded operands (riccati_mfma.hpp, PNS), where the
     record-fed padded sweep reads the tile producer's records.  Same expressions, same orders: the gains bit for bit -- any
     models of the family (mixed), per-agent Q / R / Q_f, per-item radius and mu, n_dims 2 and 3 mixed, near and far pairs; a
     37-item batch (one wavefront per SIMD) and the same items as the first 37 of 1300 (two per SIMD)."""
     from dpilqr_amd.device import to_dev
-    k = len(models); ns = 6 if models[0] != 2 else 3; nc = 3 if ns == 6 else 2
+    k = len(models); ns = {0: 4, 3: 4, 2: 3}.get(models[0], 6); nc = 3 if ns == 6 else 2
     T = 14
     rng = np.random.default_rng(900 + 7 * k + ns)
     Bbig = 1300
@@ -474,7 +476,9 @@ def test_in_sweep_production_equals_the_record_fed_sweep(dp, models):
     Q = np.stack([np.diag(rng.uniform(0.5, 2.0, ns)) + 0.05 * rng.normal(size=(ns, ns)) for _ in range(k)])
     R = np.stack([np.diag(rng.uniform(0.5, 2.0, nc)) + 0.05 * rng.normal(size=(nc, nc)) for _ in range(k)])
     Qf = np.stack([30.0 * np.eye(ns) + rng.normal(size=(ns, ns)) for _ in range(k)])
-    n_dims = [3 if (ns == 6 and a % 2 == 0) else 2 for a in range(k)]
+    n_dims = [3 if (ns != 3 and a % 2 == 0) else 2 for a in range(k)]
+    if ns == 4:
+        x0[:, 3::4] = rng.uniform(-3, 3, size=(Bbig, k))     # headings of the unicycles among them
     rad = rng.uniform(0.4, 1.5, size=Bbig); mu_h = rng.choice([0.0, 0.125, 1.0], size=Bbig)
     out = {}
     for B in (37, Bbig):
