@@ -81,9 +81,12 @@ inline bool fused_wavefront_inprod_applies(const dpilqr_batch_desc& D) {
     static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_INPROD") != nullptr;
     static const bool no4 = getenv("DPILQR_NO_INPROD4") != nullptr;   // A/B switch: the four-state clusters' previous routes
     if (off) return false;
-    // ... and what is left of the four-state family at n_x <= 24: at most five agents WITHOUT the hints the forms above need (a
-    // proximity cost over three dimensions, mixed models unannounced), and six agents (n_x = 24)
-    if (D.n_s == 4 && D.n_c == 2 && D.k <= 6 && !no4)
+    // ... and what is left of the four-state family at n_x <= 20: at most five agents WITHOUT the hints the forms above need (a
+    // proximity cost over three dimensions, mixed models unannounced).  (Six agents, n_x = 24, keep the producer + the
+    // record-fed wavefront sweep: a full 2048-item pass is 2.18 ms in-sweep against 1.94 + 1.22, but a whole solve 81.5 against
+    // 72.6 ms -- fifteen pairs' derivatives at the top of each of T = 100 steps of a lone wavefront in the solve's long tail;
+    // profiles/r04_inprod_four_state.txt)
+    if (D.n_s == 4 && D.n_c == 2 && D.k <= 5 && !no4)
         return !fused_wavefront_sweep_applies(D) && !fused_wavefront_general_applies(D);
     return (D.n_s == 6 && D.n_c == 3 && D.k <= 4) || (D.n_s == 3 && D.n_c == 2 && D.k <= 6);
 }

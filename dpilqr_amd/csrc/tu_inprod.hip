@@ -42,9 +42,9 @@ int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const
     // five (15, 10) -> (20, 10); six (18, 12) -> (24, 12)
     DPILQR_TRY_INPROD(4, 2, 3) DPILQR_TRY_INPROD(8, 4, 3) DPILQR_TRY_INPROD(12, 6, 3) DPILQR_TRY_INPROD(16, 8, 3)
     DPILQR_TRY_INPROD(20, 10, 3) DPILQR_TRY_INPROD(24, 12, 3)
-    // four-state family (exact sizes): clusters of at most five agents without the fused forms' hints; six agents
+    // four-state family (exact sizes): clusters of at most five agents without the fused forms' hints
     DPILQR_TRY_INPROD(4, 2, 4) DPILQR_TRY_INPROD(8, 4, 4) DPILQR_TRY_INPROD(12, 6, 4) DPILQR_TRY_INPROD(16, 8, 4)
-    DPILQR_TRY_INPROD(20, 10, 4) DPILQR_TRY_INPROD(24, 12, 4)
+    DPILQR_TRY_INPROD(20, 10, 4)
 #undef DPILQR_TRY_INPROD
     return DPILQR_EUNSUPPORTED;
 }

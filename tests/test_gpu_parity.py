@@ -456,8 +456,9 @@ def test_sweep_six_state_family(dp, k):
                                     [2], [2, 2], [2, 2, 2], [2] * 4, [2] * 5, [2] * 6,
                                     [3] * 6, [0] * 6, [0, 3, 0, 3, 3, 0], [3], [0, 3], [3, 0, 3], [0] * 4, [3, 3, 0, 0, 3]])
 def test_in_sweep_production_equals_the_record_fed_sweep(dp, models):
-    """Clusters of at most four agents of the six-state family, at most six CarDynamics3D agents, and the four-state clusters the
-    fused forms do not serve (six agents; fewer with a proximity cost over mixed dimensions): the record-free wavefront
+    """Clusters of at most four agents of the six-state family, at most six CarDynamics3D agents, and the four-state clusters of
+    at most five agents the fused forms do not serve (a proximity cost over mixed dimensions; six agents take the fused workgroup
+    sweep here): the record-free wavefront
     sweep evaluates linearize / quadraticize inside the sweep, straight into the padded operands (riccati_mfma.hpp, PNS), where the
     record-fed padded sweep reads the tile producer's records.  Same expressions, same orders: the gains bit for bit -- any
     models of the family (mixed), per-agent Q / R / Q_f, per-item radius and mu, n_dims 2 and 3 mixed, near and far pairs; a

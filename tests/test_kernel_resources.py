@@ -58,10 +58,10 @@ def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
 
 
 def test_in_sweep_production_kernels_do_not_spill(table):
-    """The record-free wavefront sweeps of the six-state family and CarDynamics3D (k_riccati_mfma_inprod): no spilled vector
+    """The record-free wavefront sweeps of the six-state family, CarDynamics3D and unhinted four-state clusters (k_riccati_mfma_inprod): no spilled vector
     register and no scratch at either occupancy (they hold an agent's whole Jacobian, 54 doubles, in registers for a moment)."""
     ip = {k: r for k, r in table.items() if k.startswith("k_riccati_mfma_inprod<")}
-    assert len(ip) == 20
+    assert len(ip) == 30          # six-state 4 sizes, CarDynamics3D 6, four-state 5; one and two wavefronts per SIMD
     for k, r in ip.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (k, r)
 
