@@ -396,7 +396,9 @@ def test_sweep_blocked_elimination_and_its_fallback(dp, k, blocks):
     ns, nc = blocks
     rng = np.random.default_rng(300 + k + ns)
     n, m, T = ns * k, nc * k, 3
-    kinds = ["dominant", "diag_is_max", "ratio_6", "ratio_12", "zero_diag"] * 2
+    # ... and symmetric indefinite matrices with small diagonals: several swaps per panel, partners in either row tile, in the
+    # pivot's own lane group and register or not
+    kinds = ["dominant", "diag_is_max", "ratio_6", "ratio_12", "zero_diag"] * 2 + ["indefinite"] * 8
     B = len(kinds)
     A = np.zeros((B, T, n, n)); Bm = np.zeros((B, T, n, m))
     for a in range(k):
@@ -416,9 +418,12 @@ def test_sweep_blocked_elimination_and_its_fallback(dp, k, blocks):
                 off[m - 2, 5] = 6.0                        # column 5: 6 x its diagonal, in a later row
             elif kind == "ratio_12":
                 off[m - 1, m // 2] = 12.0
-            else:
+            elif kind == "zero_diag":
                 diag[7] = 0.0                              # an exactly zero pivot candidate; dgesv brings another row up
                 off[m - 3, 7] = 0.8
+            else:
+                S_ = rng.uniform(-1.0, 1.0, size=(m, m)); off = 0.5 * (S_ + S_.T); np.fill_diagonal(off, 0.0)
+                diag = rng.uniform(-0.06, 0.06, size=m)
             Luu[b, t] = off + np.diag(diag)
     Lux = 0.2 * rng.normal(size=(B, T + 1, m, n))
     Lx = rng.normal(size=(B, T + 1, n)); Lu = rng.normal(size=(B, T + 1, m))
