@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace dpilqr {
 
 constexpr double kGrav = 9.80665;  // bbdynamics.cpp:11
@@ -444,6 +446,53 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
             for (int i = 0; i < NS; ++i) xn[i] += xb[i];
         }
         return;
+    }
+    if constexpr (M == kDoubleInt4D && sizeof(R) == 8) {
+#ifndef DPILQR_DIV6_PER_SUBSTEP   // (A/B builds: one guard per sub-step, the form of rounds 2-4a)
+        // The double integrator (cfg2's model): ONE sub-normal guard for the step's twenty divisions by 6 instead of one per
+        // sub-step.  The five sub-steps run with the reciprocal form (correctly rounded for every normal quotient) while the
+        // smallest binary exponent among the operands is tracked; only if some lane met an operand small enough for a sub-normal
+        // quotient is the whole step redone with the division (correctly rounded everywhere).  Either way every quotient is
+        // RN(v / 6): the results are those of a guard per sub-step, bit for bit; the fast path loses four ballots / branches
+        // and the register copies that the rare branch's merges cost it (72 v_mov_b64 per step).
+        auto rk4 = [&](auto exact_tag, int& emin) {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            double k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) xn[i] = x[i];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xa[i] = xn[i];
+                D::f(xa, u, k0);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k0[i];
+                D::f(xb, u, k1);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xb[i] = xa[i] + (dh / R(2.0)) * k1[i];
+                D::f(xb, u, k2);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) xb[i] = xa[i] + dh * k2[i];
+                D::f(xb, u, k3);
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double v = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
+                    if constexpr (EXACT) {
+                        asm volatile("" : "+v"(v));
+                        v = v / 6.0;
+                    } else {
+                        emin = min(emin, __builtin_amdgcn_frexp_exp(v));
+                        v = div6_fast(v);
+                    }
+                    xn[i] += v;
+                }
+            }
+        };
+        int emin = 0;
+        rk4(std::false_type{}, emin);
+        if (__builtin_amdgcn_ballot_w64(emin <= -1000) != 0ull) rk4(std::true_type{}, emin);
+        return;
+#endif
     }
     constexpr int kSubUnroll = (M == kDoubleInt4D) ? 5 : 1;
     R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
