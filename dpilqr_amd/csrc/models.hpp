@@ -333,6 +333,46 @@ __device__ __forceinline__ void div6_vec(float* v) {
     for (int i = 0; i < N; ++i) v[i] = v[i] / 6.0f;
 }
 
+// The step's divisions by 6 under ONE sub-normal guard (integrate below): MODE 1 the reciprocal form while the smallest binary
+// exponent among the operands is tracked, MODE 2 the division (for the redo of a step in which some lane met an operand small
+// enough for a sub-normal quotient), MODE 0 a guard per call (div6_vec: the fp32 arm, A/B builds).  Every quotient is RN(v / 6)
+// whichever way: bit-identical results.
+template <int MODE, int N, typename R>
+__device__ __forceinline__ void div6_sel(R* v, int& emin) {
+    if constexpr (MODE == 0 || sizeof(R) == 4) {
+        div6_vec<N>(v);
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            emin = min(emin, __builtin_amdgcn_frexp_exp(v[i]));
+            v[i] = div6_fast(v[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double xs = v[i];
+            asm volatile("" : "+v"(xs));
+            v[i] = xs / 6.0;
+        }
+    }
+}
+#ifdef DPILQR_DIV6_PER_SUBSTEP
+#define DPILQR_ONE_GUARD(R) false
+#else
+#define DPILQR_ONE_GUARD(R) (sizeof(R) == 8)
+#endif
+// run(mode, emin) is a whole RK4 step: once on the fast form, again with divisions if a sub-normal quotient was met
+template <typename R, typename F>
+__device__ __forceinline__ void rk4_one_guard(F&& run) {
+    int emin = 0;
+    if constexpr (DPILQR_ONE_GUARD(R)) {
+        run(std::integral_constant<int, 1>{}, emin);
+        if (__builtin_amdgcn_ballot_w64(emin <= -1000) != 0ull) run(std::integral_constant<int, 2>{}, emin);
+    } else {
+        run(std::integral_constant<int, 0>{}, emin);
+    }
+}
+
 // Models whose only transcendental argument is a heading angle with a CONTROL as its rate (Unicycle4D, Car3D: theta' = u[1],
 // held over the step): ModelDef<M>::kHeading / f_sc.
 template <int M> struct HasHeading { static constexpr bool value = false; };
@@ -364,6 +404,8 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
         // included -- passes on either build.  Why: the sincos ARE a unicycle's line search, 55-60 % of its launch time
         // (profiles/r04_trig.txt): five unicycles' line search 28.9 -> 23.8 ms per 2048-item solve with (i), -> 13.9 ms with (ii).
         constexpr int H = D::kHeading;
+        rk4_one_guard<R>([&](auto mode_tag, int& emin) {
+        constexpr int MODE = decltype(mode_tag)::value;
         R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) xn[i] = x[i];
@@ -391,7 +433,7 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
             D::f_sc(xb, u, s0, c0, k3);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
-            div6_vec<NS>(xb);
+            div6_sel<MODE, NS>(xb, emin);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xn[i] += xb[i];
             continue;
@@ -411,10 +453,11 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
             D::f_sc(xb, u, sn, cs, k3);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
-            div6_vec<NS>(xb);
+            div6_sel<MODE, NS>(xb, emin);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xn[i] += xb[i];
         }
+        });
         return;
     }
     if constexpr (HasControlTrig<M>::value) {
@@ -423,6 +466,8 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
         // merges the four of a sub-step)
         R tr[2];
         D::pre(u, tr);
+        rk4_one_guard<R>([&](auto mode_tag, int& emin) {
+        constexpr int MODE = decltype(mode_tag)::value;
         R k0[NS], k1[NS], k2[NS], k3[NS], xa[NS], xb[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) xn[i] = x[i];
@@ -441,10 +486,11 @@ __device__ inline void integrate(const R* x, const R* u, R dt, R* xn) {
             D::f_tr(xb, u, tr, k3);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xb[i] = dh * (k0[i] + R(2.0) * k1[i] + R(2.0) * k2[i] + k3[i]);
-            div6_vec<NS>(xb);
+            div6_sel<MODE, NS>(xb, emin);
 #pragma unroll
             for (int i = 0; i < NS; ++i) xn[i] += xb[i];
         }
+        });
         return;
     }
     if constexpr (M == kDoubleInt4D && sizeof(R) == 8) {
