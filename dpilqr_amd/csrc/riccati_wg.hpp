@@ -294,125 +294,154 @@ __device__ __forceinline__ bool gj_blocked(const double* __restrict__ sG, double
                 for (int v = 0; v < 4; ++v) sPan[(16 * it + g + 4 * v) * 4 + (c - cp)] = acc[it][itp][v];
         }
         DPILQR_LDS_FENCE();
-        double pan[RT][4], W[RT][4];
-#pragma unroll
-        for (int it = 0; it < RT; ++it) {
-            const v2d x = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4);
-            const v2d y = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4 + 2);
-            pan[it][0] = x.x; pan[it][1] = x.y; pan[it][2] = y.x; pan[it][3] = y.y;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) W[it][j] = (16 * it + c == Kp + j) ? 1.0 : 0.0;
-        }
-        DPILQR_LDS_FENCE();
-        // 2. Gauss-Jordan on the panel, W alongside
-        double invs[4];
+        // 2. Gauss-Jordan on the panel, W alongside -- first WITHOUT the row swaps, the threshold rule only noted per lane: one
+        // ballot per panel instead of one per pivot on the common path; a panel in which the rule failed somewhere (a few per
+        // cent of the steps have one) is done again from its copy in LDS with the swaps (nothing outside pan / W has changed)
+        double W[RT][4];
         int sw_r[4] = {-1, -1, -1, -1};     // row that changed places with row Kp + j, if any
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int L = cp + j;
-#ifndef DPILQR_GJ_NO_SWAP   // (A/B builds: the round-3 form, which declined the whole step instead)
-            double pv = mov_row(pan[itp][j], L);
-            {   // the threshold rule; where it fails (a few per cent of the steps), the largest entry below comes up: rows swapped
-                const double pv0 = pv;
-                bool viol = false;
-#pragma unroll
-                for (int it = 0; it < RT; ++it)
-                    viol = viol || (16 * it + c > Kp + j && kGjThreshold * fabs(pan[it][j]) > fabs(pv0));
-                if (__builtin_amdgcn_ballot_w64(viol) != 0ull) {
-                    // first largest |entry| of column Kp + j below the diagonal (dgetf2's idamax over those rows): every 16-lane row
-                    // of the wavefront holds the same copy of the panel, so the reduction stays inside a row
-                    double best = 0.0;
-                    int brow = 0;
-#pragma unroll
-                    for (int it = 0; it < RT; ++it) {
-                        const double av = fabs(pan[it][j]);
-                        const bool take = (16 * it + c > Kp + j) && av > best;
-                        best = take ? av : best;
-                        brow = take ? 16 * it + c : brow;
-                    }
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) {
-                        const double ob = __shfl_xor(best, off, 16);
-                        const int orow = __shfl_xor(brow, off, 16);
-                        const bool take = ob > best || (ob == best && ob > 0.0 && orow < brow);
-                        best = take ? ob : best;
-                        brow = take ? orow : brow;
-                    }
-                    const int r = __builtin_amdgcn_readfirstlane(brow);
-                    if (r > Kp + j) {
-                        // rows Kp + j and r change places: in the panel (all four columns) and in W's finished columns (the multipliers
-                        // are attributes of the rows; the unit entries of the columns still to come belong to the positions) now; in
-                        // the tiles the panel's update will touch -- its B operand is then the rows that are pivots now -- before
-                        // that update (sw_r)
-                        const int itB = r >> 4, cB = r & 15;
-                        const int cA = L;
-                        const int srcB = (lane & 48) | cB, srcA = (lane & 48) | cA;
-                        auto swap_row_layout = [&](double (&x)[RT][4], int col) {
-                            double vb = x[0][col];
-#pragma unroll
-                            for (int it = 1; it < RT; ++it) vb = (it == itB) ? x[it][col] : vb;
-                            const double fromB = __shfl(vb, srcB), fromA = __shfl(x[itp][col], srcA);
-#pragma unroll
-                            for (int it = 0; it < RT; ++it) x[it][col] = (it == itB && c == cB) ? fromA : x[it][col];
-                            x[itp][col] = (c == cA) ? fromB : x[itp][col];
-                        };
-#pragma unroll
-                        for (int col = 0; col < 4; ++col) swap_row_layout(pan, col);
-#pragma unroll
-                        for (int jp = 0; jp < j; ++jp) swap_row_layout(W, jp);
-                        sw_r[j] = r;
-                        pv = mov_row(pan[itp][j], L);
-                    }
-                }
-            }
-#else
-            const double pv = mov_row(pan[itp][j], L);
-#endif
-            double inv = __builtin_amdgcn_rcp(pv);
-            inv = fma(fma(-pv, inv, 1.0), inv, inv);
-            inv = fma(fma(-pv, inv, 1.0), inv, inv);
-            invs[j] = inv;
-            bad = bad || !(fabs(pv) > 0.0) || !(fabs(pv) < 1.0e300);
-            const double ninv = -inv;
-            double l[RT];
+        auto gj_panel = [&](auto swaps_tag, bool& bad_p) __attribute__((always_inline)) -> bool {
+            constexpr bool SWAPS = decltype(swaps_tag)::value;
+            bool viol_any = false;
+            double pan[RT][4];
 #pragma unroll
             for (int it = 0; it < RT; ++it) {
-                const int row = 16 * it + c;
-                const double a = pan[it][j];
-#ifdef DPILQR_GJ_NO_SWAP
-                bad = bad || (row > Kp + j && kGjThreshold * fabs(a) > fabs(pv));
-#endif
-                l[it] = (row != Kp + j) ? a * ninv : 0.0;
+                const v2d x = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4);
+                const v2d y = *reinterpret_cast<const v2d*>(sPan + (16 * it + c) * 4 + 2);
+                pan[it][0] = x.x; pan[it][1] = x.y; pan[it][2] = y.x; pan[it][3] = y.y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) W[it][j] = (16 * it + c == Kp + j) ? 1.0 : 0.0;
             }
-            // The DPP operand of these updates is the pivot row's entry, pan[itp][jj] / W[itp][jp] read from lane L.  The row
-            // tile that holds the pivot row goes LAST: every other tile's update then reads a register that was last written a
-            // whole pivot stage ago, and the pivot tile's own update reads the register it overwrites -- no update follows a
-            // write of its DPP operand within two instructions, so none needs the s_nop (6 RT per pivot, 290 per step at
-            // m = 30).  (fmac_row_nn is a volatile asm: the updates keep this order.)
+            DPILQR_LDS_FENCE();
+            // (the panel itself)
+            double invs[4];
 #pragma unroll
-            for (int jj = j + 1; jj < 4; ++jj)
+            for (int j = 0; j < 4; ++j) {
+                const int L = cp + j;
+                double pv = mov_row(pan[itp][j], L);
+                if constexpr (!SWAPS) {   // the threshold rule, noted only (one decision per panel, see below)
 #pragma unroll
-                for (int io = 1; io <= RT; ++io) {
-                    const int it = (itp + io) % RT;
-                    pan[it][jj] = fmac_row_nn(pan[it][jj], pan[itp][jj], l[it], L);
+                    for (int it = 0; it < RT; ++it)
+                        viol_any = viol_any || (16 * it + c > Kp + j && kGjThreshold * fabs(pan[it][j]) > fabs(pv));
+                } else {   // the threshold rule; where it fails, the largest entry below comes up: rows swapped
+                    const double pv0 = pv;
+                    bool viol = false;
+#pragma unroll
+                    for (int it = 0; it < RT; ++it)
+                        viol = viol || (16 * it + c > Kp + j && kGjThreshold * fabs(pan[it][j]) > fabs(pv0));
+                    if (__builtin_amdgcn_ballot_w64(viol) != 0ull) {
+                        // first largest |entry| of column Kp + j below the diagonal (dgetf2's idamax over those rows): every 16-lane row
+                        // of the wavefront holds the same copy of the panel, so the reduction stays inside a row
+                        double best = 0.0;
+                        int brow = 0;
+#pragma unroll
+                        for (int it = 0; it < RT; ++it) {
+                            const double av = fabs(pan[it][j]);
+                            const bool take = (16 * it + c > Kp + j) && av > best;
+                            best = take ? av : best;
+                            brow = take ? 16 * it + c : brow;
+                        }
+#pragma unroll
+                        for (int off = 1; off < 16; off <<= 1) {
+                            const double ob = __shfl_xor(best, off, 16);
+                            const int orow = __shfl_xor(brow, off, 16);
+                            const bool take = ob > best || (ob == best && ob > 0.0 && orow < brow);
+                            best = take ? ob : best;
+                            brow = take ? orow : brow;
+                        }
+                        const int r = __builtin_amdgcn_readfirstlane(brow);
+                        if (r > Kp + j) {
+                            // rows Kp + j and r change places: in the panel (all four columns) and in W's finished columns (the multipliers
+                            // are attributes of the rows; the unit entries of the columns still to come belong to the positions) now; in
+                            // the tiles the panel's update will touch -- its B operand is then the rows that are pivots now -- before
+                            // that update (sw_r)
+                            const int itB = r >> 4, cB = r & 15;
+                            const int cA = L;
+                            const int srcB = (lane & 48) | cB, srcA = (lane & 48) | cA;
+                            auto swap_row_layout = [&](double (&x)[RT][4], int col) {
+                                double vb = x[0][col];
+#pragma unroll
+                                for (int it = 1; it < RT; ++it) vb = (it == itB) ? x[it][col] : vb;
+                                const double fromB = __shfl(vb, srcB), fromA = __shfl(x[itp][col], srcA);
+#pragma unroll
+                                for (int it = 0; it < RT; ++it) x[it][col] = (it == itB && c == cB) ? fromA : x[it][col];
+                                x[itp][col] = (c == cA) ? fromB : x[itp][col];
+                            };
+#pragma unroll
+                            for (int col = 0; col < 4; ++col) swap_row_layout(pan, col);
+#pragma unroll
+                            for (int jp = 0; jp < j; ++jp) swap_row_layout(W, jp);
+                            sw_r[j] = r;
+                            pv = mov_row(pan[itp][j], L);
+                        }
+                    }
                 }
+                double inv = __builtin_amdgcn_rcp(pv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                invs[j] = inv;
+                bad_p = bad_p || !(fabs(pv) > 0.0) || !(fabs(pv) < 1.0e300);
+                const double ninv = -inv;
+                double l[RT];
 #pragma unroll
-            for (int jp = 0; jp < j; ++jp)
-#pragma unroll
-                for (int io = 1; io <= RT; ++io) {
-                    const int it = (itp + io) % RT;
-                    W[it][jp] = fmac_row_nn(W[it][jp], W[itp][jp], l[it], L);
+                for (int it = 0; it < RT; ++it) {
+                    const int row = 16 * it + c;
+                    const double a = pan[it][j];
+                    l[it] = (row != Kp + j) ? a * ninv : 0.0;
                 }
+                // The DPP operand of these updates is the pivot row's entry, pan[itp][jj] / W[itp][jp] read from lane L.  The row
+                // tile that holds the pivot row goes LAST: every other tile's update then reads a register that was last written a
+                // whole pivot stage ago, and the pivot tile's own update reads the register it overwrites -- no update follows a
+                // write of its DPP operand within two instructions, so none needs the s_nop (6 RT per pivot, 290 per step at
+                // m = 30).  (fmac_row_nn is a volatile asm: the updates keep this order.)
 #pragma unroll
-            for (int it = 0; it < RT; ++it) W[it][j] = (16 * it + c != Kp + j) ? l[it] : W[it][j];
+                for (int jj = j + 1; jj < 4; ++jj)
+#pragma unroll
+                    for (int io = 1; io <= RT; ++io) {
+                        const int it = (itp + io) % RT;
+                        pan[it][jj] = fmac_row_nn(pan[it][jj], pan[itp][jj], l[it], L);
+                    }
+#pragma unroll
+                for (int jp = 0; jp < j; ++jp)
+#pragma unroll
+                    for (int io = 1; io <= RT; ++io) {
+                        const int it = (itp + io) % RT;
+                        W[it][jp] = fmac_row_nn(W[it][jp], W[itp][jp], l[it], L);
+                    }
+#pragma unroll
+                for (int it = 0; it < RT; ++it) W[it][j] = (16 * it + c != Kp + j) ? l[it] : W[it][j];
+            }
+            {   // the pivot rows, scaled: the diagonal becomes 1
+                double sc = 1.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc = (c == cp + j) ? invs[j] : sc;
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) W[itp][jp] = W[itp][jp] * sc;
+            }
+            return viol_any;
+        };
+#ifdef DPILQR_GJ_CHECK_PER_PIVOT   // (A/B builds: the swap form on every panel -- a ballot per pivot)
+        {
+            bool bad_slow = false;
+            (void)gj_panel(std::true_type{}, bad_slow);
+            bad = bad || bad_slow;
         }
-        {   // the pivot rows, scaled: the diagonal becomes 1
-            double sc = 1.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sc = (c == cp + j) ? invs[j] : sc;
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) W[itp][jp] = W[itp][jp] * sc;
+#else
+        {
+            bool bad_fast = false;
+            const bool viol = gj_panel(std::false_type{}, bad_fast);
+#ifdef DPILQR_GJ_NO_SWAP   // (A/B builds: the round-3 form, which declined the whole step instead)
+            bad = bad || bad_fast || viol;
+#else
+            if (__builtin_amdgcn_ballot_w64(viol) != 0ull) {
+                bool bad_slow = false;
+                (void)gj_panel(std::true_type{}, bad_slow);
+                bad = bad || bad_slow;
+            } else {
+                bad = bad || bad_fast;
+            }
+#endif
         }
+#endif
 #ifndef DPILQR_GJ_NO_SWAP
         // the panel's row swaps, in their order, on the tiles the update is about to touch.  Row Kp + s is register vp of lane
         // group s of row tile itp; its partner r is found at run time (a loop, not unrolled: rare, and four copies of it per panel
