@@ -51,7 +51,7 @@ def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
     for k, r in wg.items():
         fused = k.endswith("true>")
         assert r["vgpr_spill_count"] <= 16, (k, r)                              # round 2: up to 48
-        assert r["sgpr_spill_count"] <= 128, (k, r)                             # round 2: up to 1012 (round 4's swap bookkeeping: <= 113, into lanes of a vector register)
+        assert r["sgpr_spill_count"] <= 160, (k, r)                             # round 2: up to 1012 (round 4's swap bookkeeping, two forms of the panel: <= 130, into lanes of a vector register)
         assert r["private_segment_fixed_size"] <= 256, (k, r)                   # the fall-back's stack (<= 228 B); arrays in scratch: 336+
     big = table["k_riccati_wg<60, 30, 4, 2, true>"]
     assert big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 256            # cfg3's 15-unicycle clusters: two per CU
