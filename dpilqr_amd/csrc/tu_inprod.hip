@@ -45,6 +45,9 @@ int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const
     // four-state family (exact sizes): clusters of at most five agents without the fused forms' hints
     DPILQR_TRY_INPROD(4, 2, 4) DPILQR_TRY_INPROD(8, 4, 4) DPILQR_TRY_INPROD(12, 6, 4) DPILQR_TRY_INPROD(16, 8, 4)
     DPILQR_TRY_INPROD(20, 10, 4)
+    // (One twelve-state agent, (12, 4) -> (12, 6), was built and measured: 255 registers, bit-identical -- and slower: 1.00 ms per
+    // 512 items and pass against 0.27 + 0.43, sweeps of a four-iteration solve 4.1 against 2.1 ms: Quadcopter12D's Jacobian is
+    // most of such a step and serial in t here, parallel over t in the producer.  profiles/r04_inprod_twelve_state.txt)
 #undef DPILQR_TRY_INPROD
     return DPILQR_EUNSUPPORTED;
 }

@@ -461,7 +461,7 @@ def test_sweep_six_state_family(dp, k):
                                     [2], [2, 2], [2, 2, 2], [2] * 4, [2] * 5, [2] * 6,
                                     [3] * 6, [0] * 6, [0, 3, 0, 3, 3, 0], [3], [0, 3], [3, 0, 3], [0] * 4, [3, 3, 0, 0, 3]])
 def test_in_sweep_production_equals_the_record_fed_sweep(dp, models):
-    """Clusters of at most four agents of the six-state family, at most six CarDynamics3D agents, and the four-state clusters of
+    """Clusters of at most four agents of the six-state family, at most six CarDynamics3D agents, one twelve-state agent, and the four-state clusters of
     at most five agents the fused forms do not serve (a proximity cost over mixed dimensions; six agents take the fused workgroup
     sweep here): the record-free wavefront
     sweep evaluates linearize / quadraticize inside the sweep, straight into the padded operands (riccati_mfma.hpp, PNS), where the
