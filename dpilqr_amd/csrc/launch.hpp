@@ -4,7 +4,8 @@
 // instantiation took over two minutes): tu_tiles.hip (K1), tu_riccati.hip (K2), tu_forward.hip (K3, rollouts, the small
 // batched entry points), tu_big.hip (the sweep for n_x > 60 and the fp32 arm), tu_team.hip (the fused
 // wavefront sweeps with a helper wavefront per item) and dpilqr_hip.hip (the C ABI and the
-// solve loop).  No device code crosses a file boundary.
+// solve loop); round 4 added tu_inprod.hip (the wavefront sweeps with in-sweep production) and tu_lsteam.hip (the line search
+// with two wavefronts per item).  No device code crosses a file boundary.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -133,6 +134,11 @@ int32_t launch_riccati_team(const dpilqr_batch_desc& D, const double* X, const d
 int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
                               int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items, int gains_by_item,
                               hipStream_t st);
+
+// ---- tu_lsteam.hip: the line search with two wavefronts per item (rollout / costs), for launches of at most 1024 items
+int32_t launch_linesearch_team(const dpilqr_batch_desc& D, double* X, double* U, const double* K, const double* d,
+                               const double* alphas, double* Xc, double* Uc, const SolveState& S, const int32_t* items,
+                               const int32_t* n_items, int grid_items, hipStream_t st);
 
 // ---- tu_forward.hip
 int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,

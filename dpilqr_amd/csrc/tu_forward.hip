@@ -66,6 +66,10 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch
     if (!no_wave && mode == kModeLineSearch && hint_model(D) >= 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
         const int model = hint_model(D);
+        {   // launches of at most one item per SIMD: two wavefronts per item, rollout and costs (tu_lsteam.hip)
+            const int32_t rc_t = launch_linesearch_team(D, X, U, K, d, alphas, Xc, Uc, S, items, n_items, grid_items, st);
+            if (rc_t != DPILQR_EUNSUPPORTED) return rc_t;
+        }
 #define DPILQR_TRY_WAVE(MODEL, KA)                                                                                  \
     if (model == MODEL && D.k == KA && model_ns(MODEL) == D.n_s && model_nc(MODEL) == D.n_c) {                      \
         using WF = WaveFwdLds<MODEL, KA>;                                                                           \
