@@ -12,7 +12,7 @@
 // after barrier t + 1, which the cost wavefront reaches only when it has finished step t).  The same expressions on the same
 // values in the same order: costs, decisions, trajectories bit-identical to k_linesearch_wave
 // (tests/test_gpu_parity.py::test_line_search_team_equals_the_one_wavefront_line_search).  For the sizes with one wavefront per
-// item (k n_alpha <= 64 lanes: up to six agents); instantiated for the four-state models and QuadcopterDynamics6D.
+// item (k n_alpha <= 64 lanes: up to six agents); instantiated for the four-state models, QuadcopterDynamics6D, DoubleIntDynamics6D and CarDynamics3D.
 #pragma once
 #include <hip/hip_runtime.h>
 

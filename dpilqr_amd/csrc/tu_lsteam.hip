@@ -32,6 +32,8 @@ int32_t launch_linesearch_team(const dpilqr_batch_desc& D, double* X, double* U,
     DPILQR_LSTEAM_6(kDoubleInt4D)
     DPILQR_LSTEAM_6(kUnicycle4D)
     DPILQR_LSTEAM_6(kQuadcopter6D)
+    DPILQR_LSTEAM_6(kDoubleInt6D)
+    DPILQR_LSTEAM_6(kCar3D)
 #undef DPILQR_LSTEAM_6
 #undef DPILQR_TRY_LSTEAM
     return DPILQR_EUNSUPPORTED;

@@ -224,7 +224,7 @@ def test_window_invariance(dp):
     assert (g["X"] == full["X"]).all().item()
 
 
-@pytest.mark.parametrize("model,k", [(0, 5), (0, 1), (3, 3), (3, 6), (0, 6), (4, 2), (4, 5)])
+@pytest.mark.parametrize("model,k", [(0, 5), (0, 1), (3, 3), (3, 6), (0, 6), (4, 2), (4, 5), (1, 3), (2, 4)])
 def test_line_search_team_equals_the_one_wavefront_line_search(dp, model, k):
     """Launches of at most 1024 items run the line search with a TEAM of two wavefronts per item -- one rolls the candidates out,
     the other evaluates their costs a step behind (forward_team.hpp) -- larger launches one wavefront per item.  Pure scheduling:
@@ -233,7 +233,7 @@ def test_line_search_team_equals_the_one_wavefront_line_search(dp, model, k):
     included."""
     from dpilqr_amd.util import random_setup
     B, Bbig, T = 700, 2600, 40
-    ns, nc, nd = (6, 3, 3) if model == 4 else (4, 2, 2)
+    ns, nc, nd = {4: (6, 3, 3), 1: (6, 3, 3), 2: (3, 2, 2)}.get(model, (4, 2, 2))
     x0 = np.zeros((Bbig, ns * k)); xf = np.zeros((Bbig, ns * k))
     if k == 1:      # (random_setup normalises by the agents' mutual distances: undefined for one agent)
         rng = np.random.default_rng(91000)
@@ -242,9 +242,9 @@ def test_line_search_team_equals_the_one_wavefront_line_search(dp, model, k):
         np.random.seed(91000 + s)
         a, b = random_setup(k, ns, is_rotation=False, rel_dist=max(k, 2), var=max(k, 2) / 2, n_d=nd, random=True, energy=10.0)
         x0[s], xf[s] = a.ravel(), b.ravel()
-    Q = (50.0 * np.eye(6)) if ns == 6 else np.diag([1.0, 1, 0, 0]); R = np.eye(nc); Qf = 1000.0 * np.eye(ns)
+    Q = (50.0 * np.eye(6)) if ns == 6 else (np.diag([1.0, 1, 0, 0]) if ns == 4 else np.diag([1.0, 1, 0])); R = np.eye(nc); Qf = 1000.0 * np.eye(ns)
     U0 = np.zeros((Bbig, T, nc * k))
-    if ns == 6: U0[:, :, 0::3] = 9.80665
+    if model == 4: U0[:, :, 0::3] = 9.80665
     small = dp.ProblemBatch([model] * k, [nd] * k, xf[:B], Q, R, Qf, 0.5, 0.1, T).solve(x0[:B], U0[:B], trace=True, window=B)
     big = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, Qf, 0.5, 0.1, T).solve(x0, U0, trace=True, window=Bbig)
     for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):

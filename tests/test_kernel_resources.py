@@ -61,7 +61,7 @@ def test_line_search_team_kernels_do_not_spill(table):
     """The two-wavefront line search (k_linesearch_team): the per-agent constants live in the cost wavefront's registers, the
     rollout's state in the other's -- no spills at any size (the one-wavefront quadcopter kernels spill from five agents on)."""
     lt = {k: r for k, r in table.items() if k.startswith("k_linesearch_team<")}
-    assert len(lt) == 18
+    assert len(lt) == 30
     for k, r in lt.items():
         # (36 B of scratch at one unicycle: the trigonometric argument reduction's table lookup, as in the one-wavefront kernel)
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= 36 and r["vgpr_count"] <= 192, (k, r)
