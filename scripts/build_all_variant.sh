@@ -7,6 +7,7 @@ tag=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/dpilqr_amd/variants $root/build/variants
 flags=$(cd $root && python -c "import __graft_entry__ as g; print(' '.join(g.HIPCC_FLAGS))" | tail -1)
+cd $root   # the flags name include paths relative to the repository
 objs=""; pids=""
 for src in $root/dpilqr_amd/csrc/*.hip; do
   u=$(basename $src .hip); o=$root/build/variants/${u}_$tag.o

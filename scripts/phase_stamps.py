@@ -1,5 +1,5 @@
 """Diagnostic: per-phase shader cycles of the wavefront sweep (record-fed or fused), from in-kernel s_memtime stamps.
-Needs a -DDPILQR_PHASE_STAMPS build of the library: `python scripts/phase_stamps.py --build` makes build/libdpilqr_stamps.so
+Needs a -DDPILQR_PHASE_STAMPS build of the library: `python scripts/phase_stamps.py --build` makes dpilqr_amd/variants/libdpilqr_stamps.so
 (no GPU needed); then, on the GPU box, `python scripts/phase_stamps.py [B] [--fused]`.  `--wg B k [quad6|uni4]`: the workgroup sweep;
 `--s3split` (at --build and at run time): its S3 split into blocked elimination / fall-back / barrier + store."""
 import subprocess
@@ -10,14 +10,15 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-so = ROOT / "build" / "libdpilqr_stamps.so"
+so = ROOT / "dpilqr_amd" / "variants" / "libdpilqr_stamps.so"     # variants/ travels to the GPU box, build/ does not
 if "--build" in sys.argv:
     so.parent.mkdir(exist_ok=True)
+    (ROOT / "build").mkdir(exist_ok=True)
     csrc = ROOT / "dpilqr_amd" / "csrc"
     objs = []
     procs = []
     for src in sorted(csrc.glob("*.hip")):
-        obj = so.parent / f"stamps_{src.stem}.o"
+        obj = ROOT / "build" / f"stamps_{src.stem}.o"
         objs.append(str(obj))
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                                        "-DDPILQR_PHASE_STAMPS", *(["-DDPILQR_S3_SPLIT"] if "--s3split" in sys.argv else []),
