@@ -14,7 +14,8 @@ i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOGPU, EWORKSPACE = 0, -1, -2, -3, -4, -5
 N_ALPHA = 10
-STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STATUS_SINGULAR = 0, 1, 2, 3, 4
+ABI_VERSION = 3          # DPILQR_ABI_VERSION of include/dpilqr_hip.h
+STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STATUS_SINGULAR, STATUS_KILLED = 0, 1, 2, 3, 4, 5
 
 
 class BatchDesc(C.Structure):
@@ -57,15 +58,15 @@ SIGNATURES = {
     "dpilqr_solver_create": (i32, [C.POINTER(vp)]),
     "dpilqr_solver_destroy": (i32, [vp]),
     "dpilqr_solver_set_progress": (i32, [vp, vp, vp]),
-    "dpilqr_solve_batch": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "dpilqr_solve_enqueue": (i32, [_DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "dpilqr_solve_batch": (i32, [vp, _DP, vp, vp, i32, f64, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_solve_enqueue": (i32, [_DP, vp, vp, i32, f64, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "dpilqr_solve_iterations_bound": (i64, [_DP, i32, i32]),
     "dpilqr_rollout_f32": (i32, [_DP, vp, vp, vp, vp, vp]),
     "dpilqr_backward_pass_workspace_bytes": (i64, [_DP, i32]),
     "dpilqr_backward_pass_f32": (i32, [_DP, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_forward_pass_f32": (i32, [_DP, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "dpilqr_solve_workspace_bytes_f32": (i64, [_DP, i32, i32]),
-    "dpilqr_solve_batch_f32": (i32, [vp, _DP, vp, vp, i32, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dpilqr_solve_batch_f32": (i32, [vp, _DP, vp, vp, i32, f64, f64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dpilqr_debug_stamps": (i32, [vp]),
     "dpilqr_profile_enable": (i32, [vp, i32]),
     "dpilqr_profile_read": (i32, [vp, C.POINTER(f64 * 4), C.POINTER(i64 * 4), C.POINTER(i64 * 4), i32]),
@@ -103,8 +104,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.dpilqr_abi_version() != 2:
-            raise ImportError("libdpilqr_hip.so ABI version mismatch")
+        if lib.dpilqr_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.dpilqr_abi_version()}, this binding is for {ABI_VERSION}")
         _lib = lib
     return _lib
 

@@ -310,7 +310,7 @@ class ProblemBatch:
         return int(min(self.B, 6144, w))
 
     def solve(self, x0, U0, n_lqr_iter=50, tol=1e-3, trace=False, gains=False, window=None, dtype=torch.float64, out=None,
-              progress=None):
+              progress=None, t_kill=None):
         """ilqrSolver.solve (control.py:150-225) for all B items.
 
         window: most items in flight at once (default: default_window()); finished items are retired on the device and
@@ -319,6 +319,9 @@ class ProblemBatch:
         write the results into (sharding.ResultBuffers: the solve then writes straight into the collective's send buffer).
         progress: callable(n_finished, n_items), called from inside the solve as a PREFIX of the batch finishes (X, U,
         status, n_bwd, n_fwd of items below n_finished are final; see dpilqr_solver_set_progress).
+        t_kill: seconds of solve time each item may use (control.py:213-218, every item's clock starts when it is admitted
+        to the window); an item whose time is up after an accepted, unconverged step ends with status STATUS_KILLED and
+        that step's iterate.  None / 0: no limit.
         Returns a dict of device tensors: X, U, J, status, n_bwd, n_fwd (+ trace, K, d on request).
         """
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
@@ -343,7 +346,8 @@ class ProblemBatch:
         ok = False
         try:
             with _lib.progress_callback(progress):
-                _lib.check(fn(_lib.solver(), self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), window, ptr(ws), ws.numel(),
+                _lib.check(fn(_lib.solver(), self._d, ptr(x0), ptr(U), int(n_lqr_iter), float(tol), float(t_kill or 0.0), window,
+                              ptr(ws), ws.numel(),
                               ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd), ptr(tr), ptr(K), ptr(d), stream_handle()))
             ok = True
         finally:
@@ -357,7 +361,7 @@ class ProblemBatch:
             out["K"], out["d"] = K, d
         return out
 
-    def solve_enqueue(self, x0, U0, n_global_iter, n_lqr_iter=50, tol=1e-3, window=None, state=None):
+    def solve_enqueue(self, x0, U0, n_global_iter, n_lqr_iter=50, tol=1e-3, window=None, state=None, t_kill=None):
         """The same solve as pure enqueue on torch's current stream (dpilqr_solve_enqueue): nothing is waited for.
         Returns (results dict, state); pass `state` back to continue with another n_global_iter iterations.  An item is
         finished when its status is no longer 0 (STATUS_ACTIVE)."""
@@ -371,7 +375,7 @@ class ProblemBatch:
             state = dict(r=r, ws=ws, x0=x0, window=window, resume=0)
         r, ws = state["r"], state["ws"]
         _lib.check(self._lib.dpilqr_solve_enqueue(self._d, ptr(state["x0"]), ptr(r["U"]), int(n_lqr_iter), float(tol),
-                                                  state["window"], ptr(ws), ws.numel(), ptr(r["X"]), ptr(r["J"]),
+                                                  float(t_kill or 0.0), state["window"], ptr(ws), ws.numel(), ptr(r["X"]), ptr(r["J"]),
                                                   ptr(r["status"]), ptr(r["n_bwd"]), ptr(r["n_fwd"]), None, None, None,
                                                   int(n_global_iter), state["resume"], stream_handle()))
         state["resume"] = 1

@@ -116,12 +116,12 @@ class ilqrSolver:
             raise ValueError
         x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
         self._reset_regularization()
-        if self.on_device and not t_kill:
-            return self._solve_device(x0, U, n_lqr_iter, tol, verbose)
+        if self.on_device:      # t_kill is honoured on the device (its own clock, include/dpilqr_hip.h section 5)
+            return self._solve_device(x0, U, n_lqr_iter, tol, verbose, t_kill)
         return self._solve_host_loop(x0, U, n_lqr_iter, tol, t_kill, verbose)
 
-    def _solve_device(self, x0, U, n_lqr_iter, tol, verbose):
-        r = self._pb(self.N).solve(x0[None], U[None], n_lqr_iter=n_lqr_iter, tol=tol, trace=True)
+    def _solve_device(self, x0, U, n_lqr_iter, tol, verbose, t_kill=None):
+        r = self._pb(self.N).solve(x0[None], U[None], n_lqr_iter=n_lqr_iter, tol=tol, trace=True, t_kill=t_kill)
         tr = r["trace"][0].cpu().numpy(); nb = int(r["n_bwd"][0])
         for i in range(nb):  # leave the solver object in the state the reference would be in
             if tr[i, 1] >= 0:
@@ -131,6 +131,8 @@ class ilqrSolver:
                 if tr[i, 1] >= 0:
                     print(f"{i + 1}/{n_lqr_iter}\tJ: {tr[i, 3]:g}")
         self.status = int(r["status"][0]); self.n_bwd = nb; self.n_fwd = int(r["n_fwd"][0])
+        if verbose and self.status == _lib.STATUS_KILLED:
+            print(f"Killing due to exceeded computation time > {t_kill} s.")
         if self.status == _lib.STATUS_SINGULAR:
             raise np.linalg.LinAlgError("Singular matrix")     # what np.linalg.solve raises in the reference
         return r["X"][0].cpu().numpy(), r["U"][0].cpu().numpy(), float(r["J"][0])

@@ -98,14 +98,20 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
 // mail[2] = the finished PREFIX: items are admitted in index order, so every item below the smallest index still on the
 // list has finished and its results are final in memory (the progress callback of dpilqr_solver_set_progress).
 // want_prefix = 0: nobody listens for progress, the scan of the list for its lowest index is skipped (mail[2] = 0).
+// t_admit (null without t_kill): the admitted items' own t0 of control.py:167 -- the device's constant-rate clock now,
+// just before their first backward pass.
 __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window,
-                        int32_t* mail, int want_prefix) {
+                        int32_t* mail, int want_prefix, int64_t* t_admit) {
     const int base = *count, first = *admitted;
     const int n_new = min(B - first, window - base);
     __shared__ int lowest;
     if (threadIdx.x == 0) lowest = first;
     __syncthreads();
     for (int i = threadIdx.x; i < n_new; i += blockDim.x) list[base + i] = first + i;
+    if (t_admit && n_new > 0) {
+        const int64_t now = (int64_t)__builtin_amdgcn_s_memrealtime();
+        for (int i = threadIdx.x; i < n_new; i += blockDim.x) t_admit[first + i] = now;
+    }
     if (mail && want_prefix) {
         int lo = first;
         for (int i = threadIdx.x; i < base; i += blockDim.x) lo = min(lo, list[i]);
@@ -141,7 +147,7 @@ struct SolveShape {
 struct SolveWorkspace {
     // W = window = most sub-problems in flight at once: the big per-iteration buffers (tile records or sweep scratch,
     // gains, line-search candidates) are indexed by position in the active list and sized by W, not by B.
-    size_t tiles, K, d, Xc, Uc, mu, delta, J_star, J_last, alphas, singular, lists, counts, total;
+    size_t tiles, K, d, Xc, Uc, mu, delta, J_star, J_last, alphas, singular, lists, counts, t_admit, total;
     SolveWorkspace(const dpilqr_batch_desc& D, int W, bool gains_in_ws, SolveShape sh) {
         const size_t B = D.B, n = (size_t)D.k * D.n_s, m = (size_t)D.k * D.n_c, T = D.T, Wn = W, e = sh.elem;
         const TileLayout L((int)n, (int)m);
@@ -162,6 +168,7 @@ struct SolveWorkspace {
         singular = o; o = al(o + sizeof(int32_t) * B);
         lists = o;    o = al(o + sizeof(int32_t) * 2 * Wn);
         counts = o;   o = al(o + sizeof(int32_t) * (kCountRing + 1));   // ring + the `admitted` counter
+        t_admit = o;  o = al(o + sizeof(int64_t) * B);                  // t_kill: every item's admission stamp
         total = o;
     }
 };
@@ -340,7 +347,7 @@ SolveShape shape_of(const dpilqr_batch_desc& D) {
 // enqueue-only form -- exactly n_global_iter iterations of launches, no host read, no synchronisation.
 template <typename R>
 int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R* x0, R* U, int32_t n_lqr_iter, double tol,
-                   int32_t window, void* workspace, int64_t workspace_bytes, R* X, double* J, int32_t* status,
+                   double t_kill, int32_t window, void* workspace, int64_t workspace_bytes, R* X, double* J, int32_t* status,
                    int32_t* n_bwd, int32_t* n_fwd, double* trace, R* K_out, R* d_out, int32_t n_global_iter,
                    int32_t resume, hipStream_t st) {
     int32_t rc = check_desc(desc);
@@ -381,6 +388,18 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     S.J_last = reinterpret_cast<double*>(ws + W.J_last);
     S.status = status; S.n_bwd = n_bwd; S.n_fwd = n_fwd; S.trace = trace; S.singular = singular;
     S.n_lqr_iter = n_lqr_iter; S.tol = tol; S.gains_by_item = gains_by_item ? 1 : 0;
+    // t_kill in ticks of the constant-rate clock the kernels read (s_memrealtime; the runtime reports its rate in kHz)
+    int64_t* t_admit = nullptr;
+    S.t_admit = nullptr; S.t_kill_ticks = 0;
+    if (t_kill > 0.0) {
+        int dev_now = 0, khz = 0;
+        HIP_TRY(hipGetDevice(&dev_now));
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev_now) != hipSuccess || khz <= 0) khz = 100000;
+        const double ticks = t_kill * 1e3 * (double)khz;
+        S.t_kill_ticks = ticks < 1.0 ? 1 : (ticks > 9e18 ? (int64_t)9e18 : (int64_t)ticks);
+        t_admit = reinterpret_cast<int64_t*>(ws + W.t_admit);
+        S.t_admit = t_admit;
+    }
     const int n = D.k * D.n_s, m = D.k * D.n_c;
     Profiler none;
     Profiler& prof = solver ? solver->prof : none;
@@ -441,7 +460,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         int32_t* nxt_n = counts + ((it + 1) % kCountRing);
         int32_t* mail = solver ? solver->dev + kMailWords * (it % kMailRing) : nullptr;
         hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail,
-                           (solver && solver->progress) ? 1 : 0);
+                           (solver && solver->progress) ? 1 : 0, t_admit);
         if (solver) HIP_TRY(hipEventRecord(solver->ev[it % kMailRing], st));
         S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
         S.next_count = nxt_n;
@@ -752,32 +771,32 @@ int32_t dpilqr_solver_set_progress(dpilqr_solver* solver, dpilqr_progress_fn fn,
 }
 
 int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const double* x0, double* U,
-                           int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                           int32_t n_lqr_iter, double tol, double t_kill, int32_t window, void* workspace, int64_t workspace_bytes,
                            double* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
                            double* K_out, double* d_out, void* stream) {
     if (!solver) {
         const int32_t rc = default_solver(&solver);
         if (rc) return rc;
     }
-    return solve_impl<double>(solver, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+    return solve_impl<double>(solver, desc, x0, U, n_lqr_iter, tol, t_kill, window, workspace, workspace_bytes, X, J, status, n_bwd,
                               n_fwd, trace, K_out, d_out, 0, 0, as_stream(stream));
 }
 int32_t dpilqr_solve_batch_f32(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const float* x0, float* U,
-                               int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                               int32_t n_lqr_iter, double tol, double t_kill, int32_t window, void* workspace, int64_t workspace_bytes,
                                float* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
                                float* K_out, float* d_out, void* stream) {
     if (!solver) {
         const int32_t rc = default_solver(&solver);
         if (rc) return rc;
     }
-    return solve_impl<float>(solver, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+    return solve_impl<float>(solver, desc, x0, U, n_lqr_iter, tol, t_kill, window, workspace, workspace_bytes, X, J, status, n_bwd,
                              n_fwd, trace, K_out, d_out, 0, 0, as_stream(stream));
 }
 int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
-                             int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J, int32_t* status,
+                             double t_kill, int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J, int32_t* status,
                              int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out, double* d_out,
                              int32_t n_global_iter, int32_t resume, void* stream) {
-    return solve_impl<double>(nullptr, desc, x0, U, n_lqr_iter, tol, window, workspace, workspace_bytes, X, J, status, n_bwd,
+    return solve_impl<double>(nullptr, desc, x0, U, n_lqr_iter, tol, t_kill, window, workspace, workspace_bytes, X, J, status, n_bwd,
                               n_fwd, trace, K_out, d_out, n_global_iter, resume, as_stream(stream));
 }
 int64_t dpilqr_solve_iterations_bound(const dpilqr_batch_desc* desc, int32_t window, int32_t n_lqr_iter) {

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(
             if (mu <= 1e-6) mu = 0.0;
             S.delta[b] = delta; S.mu[b] = mu; S.J_star[b] = J_new;
             if (conv) status = DPILQR_STATUS_CONVERGED;
+            else if (solve_time_is_up(S, b)) status = DPILQR_STATUS_KILLED;   // control.py:213-218, checked before the loop bound
             else if (iter + 1 >= S.n_lqr_iter) status = DPILQR_STATUS_MAX_ITER;
         } else {
             status = DPILQR_STATUS_LINESEARCH_FAILED;  // control.py:195-198

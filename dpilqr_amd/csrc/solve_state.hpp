@@ -22,6 +22,17 @@ struct SolveState {  // per-item solver state, device arrays of length B
     int32_t n_lqr_iter;
     int32_t gains_by_item;    // K, d indexed by item id (caller asked for them) instead of list position
     double tol;
+    // t_kill (control.py:213-218): per-item admission stamps of the constant-rate clock and the limit in its ticks (0: none)
+    const int64_t* t_admit;
+    int64_t t_kill_ticks;
 };
+
+// The reference's real-time bail-out, decided where the accept / converge decision is: called for an item whose step was
+// accepted and did not converge.  perf_counter() - t0 > t_kill with t0 = the item's admission (just before its first
+// backward pass, as control.py:167 takes it after the initial rollout).
+__device__ inline bool solve_time_is_up(const SolveState& S, int b) {
+    if (S.t_kill_ticks <= 0) return false;
+    return (int64_t)__builtin_amdgcn_s_memrealtime() - S.t_admit[b] > S.t_kill_ticks;
+}
 
 }  // namespace dpilqr

@@ -24,11 +24,24 @@ from .lowering import describe, is_lowerable, lower_problems
 _bucket_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="dpilqr-bucket")
 
 
+SOLVE_KWARGS = ("n_lqr_iter", "tol", "t_kill")       # ilqrSolver.solve's keyword arguments that reach the device solve
+
+
+def solve_kwargs(kwargs, where="solve"):
+    """The keyword arguments of ilqrSolver.solve (control.py:150) among `kwargs`; anything else is named in a warning
+    instead of being dropped silently (`verbose` is the reference's print switch and means nothing to a batched solve)."""
+    unknown = sorted(k for k in kwargs if k not in SOLVE_KWARGS and k != "verbose")
+    if unknown:
+        import warnings
+        warnings.warn(f"{where}: keyword arguments {unknown} are not arguments of the batched solve and are ignored", stacklevel=3)
+    return {k: v for k, v in kwargs.items() if k in SOLVE_KWARGS}
+
+
 def solve_problem_list(problems, x0s, U0s, keys=None, window=None, **kwargs):
     """Solve problems[i] from (x0s[i], U0s[i]); returns [(X, U, J, info)] in input order.
 
     keys[i] (hashable, optional): problems with equal keys are declared identical and solved once.
-    kwargs: n_lqr_iter, tol (t_kill forces the per-problem host loop, as in control.ilqrSolver)."""
+    kwargs: n_lqr_iter, tol, t_kill (every item's own solve-time limit, decided on the device: control.py:213-218)."""
     n = len(problems)
     out = [None] * n
     first_of = {}
@@ -44,13 +57,13 @@ def solve_problem_list(problems, x0s, U0s, keys=None, window=None, **kwargs):
     for i in todo:
         p = problems[i]
         T = np.asarray(U0s[i]).shape[0]
-        if is_lowerable(p) and not kwargs.get("t_kill"):
+        if is_lowerable(p):
             d = describe(p)
             buckets[(d["k"], p.dynamics.n_x // d["k"], T, d["dt"], d["w_ref"], d["w_prox"])].append(i)
         else:  # host plugins: the solver's own loop, sweep on the GPU
             X, U, J = ilqrSolver(p, T).solve(np.asarray(x0s[i]), np.asarray(U0s[i]), verbose=False, **kwargs)
             out[i] = (X, U, J, dict(status=None))
-    solve_kw = {k: v for k, v in kwargs.items() if k in ("n_lqr_iter", "tol")}
+    solve_kw = solve_kwargs(kwargs)
     for shape, idx in buckets.items():
         T = shape[2]
         pb = lower_problems([problems[i] for i in idx], T)
@@ -221,7 +234,7 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
     if ignore_ids:
         ids = list(problem.ids)
         ignore = [1 if id_ in ignore_ids else 0 for id_ in ids]
-    solve_kw = {key: v for key, v in kwargs.items() if key in ("n_lqr_iter", "tol")}
+    solve_kw = solve_kwargs(kwargs, "solve_scenarios_distributed")
     from time import perf_counter as pc
     t0 = pc()
     fe = ScenarioFrontEnd(d, X, U, radius, xf, ignore)

@@ -11,7 +11,7 @@ from time import perf_counter as pc
 import numpy as np
 
 from .control import ilqrSolver
-from .dispatch import solve_problem_list, solve_scenarios_distributed  # noqa: F401
+from .dispatch import solve_kwargs, solve_problem_list, solve_scenarios_distributed  # noqa: F401
 from .util import compute_pairwise_distance, split_graph
 
 
@@ -158,7 +158,7 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
     S = x0.shape[0]
     xf_h = np.broadcast_to(d["xf"], (S, n_x)).copy() if xf is None else np.asarray(xf, dtype=np.float64).reshape(S, n_x)
     U_h = np.stack([np.random.rand(N, n_u) * 0.01 for _ in range(S)]) if U0 is None else np.array(U0, dtype=np.float64)
-    solve_kw = {key: v for key, v in kwargs.items() if key in ("n_lqr_iter", "tol")}
+    solve_kw = solve_kwargs(kwargs, "solve_rhc_scenarios")
     xf_d, U, xi = to_dev(xf_h), to_dev(U_h), to_dev(x0)
     X = None                                       # first round: the graph is built from x0 alone (distributed.py:152)
     J = torch.full((S,), float("inf"), dtype=torch.float64, device=xi.device)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPILQR_ABI_VERSION 2
+#define DPILQR_ABI_VERSION 3   /* 3: t_kill in dpilqr_solve_batch[_f32] / dpilqr_solve_enqueue, DPILQR_STATUS_KILLED */
 
 /* error codes */
 #define DPILQR_OK 0
@@ -67,6 +67,8 @@ extern "C" {
 #define DPILQR_STATUS_LINESEARCH_FAILED 2 /* all alphas rejected, control.py:195-198             */
 #define DPILQR_STATUS_MAX_ITER 3          /* n_lqr_iter exhausted                                 */
 #define DPILQR_STATUS_SINGULAR 4          /* exactly zero pivot in Q_uu (np.linalg.solve would raise) */
+#define DPILQR_STATUS_KILLED 5            /* t_kill: the item's own solve time ran out after an accepted, not yet
+                                             converged iteration, control.py:213-218; X, U = that accepted iterate   */
 
 #define DPILQR_N_ALPHA 10 /* ilqrSolver.N_LS_ITER, control.py:51 */
 
@@ -204,6 +206,15 @@ int32_t dpilqr_alphas(double* alphas_host);
  *   from the not-yet-started items of the batch: every launch stays near `window` items, and the large
  *   per-iteration buffers (tile records, gains, line-search candidates) are sized by `window`, not B.
  *   Hand the solver the whole Monte-Carlo batch and let `window` bound the memory.
+ * t_kill (seconds; <= 0 or NaN: none): the reference's real-time bail-out (control.py:213-218; scripts/analysis.py:145-147
+ *   runs its default study with t_kill = dt).  There the check sits at the end of an iteration whose step was accepted
+ *   and did not converge: `perf_counter() - t0 > t_kill` -> break, t0 taken after the initial rollout.  Here every item has
+ *   its own t0 -- the device's constant-rate clock (s_memrealtime) at the moment the item is ADMITTED to the window, i.e.
+ *   just before its first backward pass -- and the line-search kernel that takes the item's accept / converge decision
+ *   reads the same clock: elapsed > t_kill -> status DPILQR_STATUS_KILLED, the item is retired with the iterate it has
+ *   just accepted (so every item runs at least one iteration, as in the reference, and J/X/U are exactly what a solve
+ *   with n_lqr_iter = n_bwd[item] returns).  The decision is taken on the device: no host read, no launch-ahead lag,
+ *   and dpilqr_solve_enqueue honours it as well.
  * workspace: dpilqr_solve_workspace_bytes(desc, window, K_out == NULL) bytes of device memory.           */
 int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
 /* Host-side state of the synchronous solve: a pinned mailbox (a few words the device posts its active-list counters
@@ -228,7 +239,7 @@ int32_t dpilqr_solver_set_progress(dpilqr_solver* solver, dpilqr_progress_fn fn,
 /* Synchronous, adaptive: launches iterations until the device reports that every item has finished (it follows the
  * device's counters a few iterations late, so launches are always queued ahead), then waits for `stream`. */
 int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const double* x0, double* U,
-                           int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                           int32_t n_lqr_iter, double tol, double t_kill, int32_t window, void* workspace, int64_t workspace_bytes,
                            double* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
                            double* K_out, double* d_out, void* stream);
 /* Enqueue-only: no host-side state, no allocation, no host read, no synchronisation -- it can be queued behind other
@@ -239,7 +250,7 @@ int32_t dpilqr_solve_batch(dpilqr_solver* solver, const dpilqr_batch_desc* desc,
  * smaller number plus a second call with resume = 1 (same arguments, same workspace) continues where the first
  * stopped.  resume = 0 initialises the solver state and rolls out (x0, U); J, X, U, status ... hold the state reached. */
 int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc* desc, const double* x0, double* U, int32_t n_lqr_iter, double tol,
-                             int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
+                             double t_kill, int32_t window, void* workspace, int64_t workspace_bytes, double* X, double* J,
                              int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace, double* K_out,
                              double* d_out, int32_t n_global_iter, int32_t resume, void* stream);
 int64_t dpilqr_solve_iterations_bound(const dpilqr_batch_desc* desc, int32_t window, int32_t n_lqr_iter);
@@ -256,7 +267,7 @@ int32_t dpilqr_forward_pass_f32(const dpilqr_batch_desc* desc, const float* X, c
                                 const double* alphas, int32_t n_alpha, float* Xn, float* Un, double* Jn, void* stream);
 int64_t dpilqr_solve_workspace_bytes_f32(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
 int32_t dpilqr_solve_batch_f32(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const float* x0, float* U,
-                               int32_t n_lqr_iter, double tol, int32_t window, void* workspace, int64_t workspace_bytes,
+                               int32_t n_lqr_iter, double tol, double t_kill, int32_t window, void* workspace, int64_t workspace_bytes,
                                float* X, double* J, int32_t* status, int32_t* n_bwd, int32_t* n_fwd, double* trace,
                                float* K_out, float* d_out, void* stream);
 

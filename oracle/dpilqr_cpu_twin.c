@@ -271,10 +271,12 @@ int32_t dpilqr_solver_set_progress(dpilqr_solver *sv, dpilqr_progress_fn fn, voi
     return DPILQR_OK;
 }
 int32_t dpilqr_solve_batch(dpilqr_solver *sv, const dpilqr_batch_desc *D, const double *x0, double *U, int32_t n_lqr_iter, double tol,
-                           int32_t window, void *ws, int64_t ws_bytes, double *X, double *J, int32_t *status, int32_t *n_bwd,
+                           double t_kill, int32_t window, void *ws, int64_t ws_bytes, double *X, double *J, int32_t *status, int32_t *n_bwd,
                            int32_t *n_fwd, double *trace, double *K_out, double *d_out, void *s)
 {
     (void)window; (void)ws; (void)ws_bytes; (void)s;
+    if (t_kill > 0.0) return fail(DPILQR_EUNSUPPORTED, "solve_batch: the CPU twin has no clock-driven bail-out (t_kill); "
+                                                       "oracle_solve with n_lqr_iter = the killed item's n_bwd is the same solve");
     if (!sv) sv = &default_solver;
     if (check_desc(D) || !x0 || !U || !X || !J || !status || !n_bwd || !n_fwd) return fail(DPILQR_EINVAL, "solve_batch: bad argument");
     if (K_out || d_out) return fail(DPILQR_EUNSUPPORTED, "solve_batch: the CPU twin does not return the last gains");
@@ -314,10 +316,10 @@ int32_t dpilqr_pairwise_graph(int32_t S, int32_t N, int32_t k, int32_t n_s, cons
 /* ---- declared by the header, device-only or measurement hooks: present (the symbol set is identical), not implemented */
 int32_t dpilqr_backward_pass_fused(const dpilqr_batch_desc *D, const double *X, const double *U, const double *mu, double *K, double *d,
                                    int32_t *sg, void *s) { (void)D; (void)X; (void)U; (void)mu; (void)K; (void)d; (void)sg; (void)s; UNSUPPORTED("backward_pass_fused"); }
-int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc *D, const double *x0, double *U, int32_t a, double b, int32_t c, void *ws, int64_t wb,
+int32_t dpilqr_solve_enqueue(const dpilqr_batch_desc *D, const double *x0, double *U, int32_t a, double b, double tk, int32_t c, void *ws, int64_t wb,
                              double *X, double *J, int32_t *st, int32_t *nb, int32_t *nf, double *tr, double *K, double *d, int32_t g,
                              int32_t r, void *s)
-{ (void)D; (void)x0; (void)U; (void)a; (void)b; (void)c; (void)ws; (void)wb; (void)X; (void)J; (void)st; (void)nb; (void)nf; (void)tr; (void)K; (void)d; (void)g; (void)r; (void)s; UNSUPPORTED("solve_enqueue"); }
+{ (void)D; (void)x0; (void)U; (void)a; (void)b; (void)tk; (void)c; (void)ws; (void)wb; (void)X; (void)J; (void)st; (void)nb; (void)nf; (void)tr; (void)K; (void)d; (void)g; (void)r; (void)s; UNSUPPORTED("solve_enqueue"); }
 int64_t dpilqr_solve_iterations_bound(const dpilqr_batch_desc *D, int32_t w, int32_t n) { (void)D; (void)w; (void)n; UNSUPPORTED("solve_iterations_bound"); }
 int32_t dpilqr_rollout_f32(const dpilqr_batch_desc *D, const float *a, const float *b, float *c, double *J, void *s) { (void)D; (void)a; (void)b; (void)c; (void)J; (void)s; UNSUPPORTED("rollout_f32"); }
 int32_t dpilqr_backward_pass_f32(const dpilqr_batch_desc *D, const float *a, const float *b, const double *mu, float *K, float *d, void *w, void *s)
@@ -326,9 +328,9 @@ int32_t dpilqr_forward_pass_f32(const dpilqr_batch_desc *D, const float *a, cons
                                 int32_t na, float *Xn, float *Un, double *Jn, void *s)
 { (void)D; (void)a; (void)b; (void)K; (void)d; (void)al; (void)na; (void)Xn; (void)Un; (void)Jn; (void)s; UNSUPPORTED("forward_pass_f32"); }
 int64_t dpilqr_solve_workspace_bytes_f32(const dpilqr_batch_desc *D, int32_t w, int32_t g) { (void)D; (void)w; (void)g; UNSUPPORTED("solve_workspace_bytes_f32"); }
-int32_t dpilqr_solve_batch_f32(dpilqr_solver *sv, const dpilqr_batch_desc *D, const float *x0, float *U, int32_t a, double b, int32_t c, void *ws,
+int32_t dpilqr_solve_batch_f32(dpilqr_solver *sv, const dpilqr_batch_desc *D, const float *x0, float *U, int32_t a, double b, double tk, int32_t c, void *ws,
                                int64_t wb, float *X, double *J, int32_t *st, int32_t *nb, int32_t *nf, double *tr, float *K, float *d, void *s)
-{ (void)sv; (void)D; (void)x0; (void)U; (void)a; (void)b; (void)c; (void)ws; (void)wb; (void)X; (void)J; (void)st; (void)nb; (void)nf; (void)tr; (void)K; (void)d; (void)s; UNSUPPORTED("solve_batch_f32"); }
+{ (void)sv; (void)D; (void)x0; (void)U; (void)a; (void)b; (void)tk; (void)c; (void)ws; (void)wb; (void)X; (void)J; (void)st; (void)nb; (void)nf; (void)tr; (void)K; (void)d; (void)s; UNSUPPORTED("solve_batch_f32"); }
 int32_t dpilqr_profile_enable(dpilqr_solver *sv, int32_t e) { (void)sv; (void)e; return 0; }
 int32_t dpilqr_debug_stamps(void *b) { (void)b; UNSUPPORTED("debug_stamps"); }
 int32_t dpilqr_profile_read(dpilqr_solver *sv, double ms[4], int64_t l[4], int64_t it[4], int32_t r) { (void)sv; (void)ms; (void)l; (void)it; (void)r; UNSUPPORTED("profile_read"); }

@@ -33,7 +33,7 @@ def test_every_symbol_exported(lib):
     L = lib.load()
     for name in declared_symbols():
         assert hasattr(L, name), f"{name} declared in dpilqr_hip.h but not exported"
-    assert L.dpilqr_abi_version() == 2
+    assert L.dpilqr_abi_version() == 3
 
 
 def test_host_only_entry_points(lib):

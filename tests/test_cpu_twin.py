@@ -55,10 +55,10 @@ def test_same_symbols_and_never_a_device(twin):
     L, _lib = twin
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert L.dpilqr_abi_version() == 2
+    assert L.dpilqr_abi_version() == 3
     arch = C.create_string_buffer(32)
     assert L.dpilqr_device_info(0, None, None, arch, 32) == _lib.ENOGPU and arch.value == b"cpu-twin"
-    assert L.dpilqr_solve_enqueue(*([None] * 3), 0, 0.0, 0, None, 0, *([None] * 8), 0, 0, None) == _lib.EUNSUPPORTED
+    assert L.dpilqr_solve_enqueue(*([None] * 3), 0, 0.0, 0.0, 0, None, 0, *([None] * 8), 0, 0, None) == _lib.EUNSUPPORTED
     assert L.dpilqr_random_setup(0, 0, 1, 4, 2, 1.0, 1.0, None, None, None) == _lib.EUNSUPPORTED
     # nothing of the product names the twin
     for f in (ROOT / "dpilqr_amd").rglob("*.py"):
@@ -160,7 +160,7 @@ def test_solve_batch_through_the_abi(twin, golden):
     seen = []
     cb = _lib.PROGRESS_FN(lambda user, done, total: seen.append((done, total)))
     assert L.dpilqr_solver_set_progress(sv, C.cast(cb, C.c_void_p), None) == 0
-    assert L.dpilqr_solve_batch(sv, D.ref(), hp(x0), hp(U), n_iter, 1e-3, 0, None, 0, hp(X), hp(J), hp(st), hp(nb), hp(nf), hp(trace), None, None, None) == 0
+    assert L.dpilqr_solve_batch(sv, D.ref(), hp(x0), hp(U), n_iter, 1e-3, 0.0, 0, None, 0, hp(X), hp(J), hp(st), hp(nb), hp(nf), hp(trace), None, None, None) == 0
     assert seen and seen[-1] == (B, B)         # the header: "a last time with n_finished = n_items"
     assert L.dpilqr_solver_set_progress(sv, None, None) == 0
     assert L.dpilqr_solver_destroy(sv) == 0
