@@ -133,7 +133,7 @@ def solve_rhc(problem, x0, N, *args, centralized=True, n_d=2, step_size=1, J_con
 
 
 def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=False, n_d=2, step_size=1,
-                        J_converge=None, dist_converge=None, t_diverge=None, window=None, **kwargs):
+                        J_converge=None, dist_converge=None, t_diverge=None, window=None, i_trial=None, rows=None, **kwargs):
     """solve_rhc (distributed.py:106-221) for S Monte-Carlo scenarios of one k-agent problem in lock step: every
     receding-horizon round is ONE batched solve over the scenarios still running (solve_scenarios_distributed, or one
     ProblemBatch when centralized), with the reference's warm-start shift and stopping rules applied per scenario.
@@ -142,6 +142,10 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
 
     x0 (S, n_x); xf (S, n_x) goals (default: the problem's own); U0 (S, N, n_u) warm starts (default: drawn per
     scenario, in order, as solve_rhc draws them: np.random.rand(N, n_u) * 0.01).
+    rows: a list to fill with S lists of CSV rows -- for every scenario exactly the rows solve_rhc logs for it
+    (distributed.py:190-194,215-219: one per receding-horizon round and the closing one), in its format (rhc_log_row);
+    i_trial: their trial numbers (a sequence of S, or one value).  The `times` field is wall-clock there and here: each
+    agent is given its share of the round's batched solve.  kwargs: n_lqr_iter, tol, t_kill reach every solve.
     Returns a list of S tuples (X_full, U_full, J_full, converged), what solve_rhc returns plus its `converged` flag."""
     import torch
     from .batch import ProblemBatch
@@ -162,19 +166,33 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
     xf_d, U, xi = to_dev(xf_h), to_dev(U_h), to_dev(x0)
     X = None                                       # first round: the graph is built from x0 alone (distributed.py:152)
     J = torch.full((S,), float("inf"), dtype=torch.float64, device=xi.device)
-    t = np.zeros(S)
+    t = [0] * S                                    # the reference's t: the int 0 until the first `t += step_size * dt`
     converged = np.ones(S, dtype=bool)
     X_parts = [[] for _ in range(S)]; U_parts = [[] for _ in range(S)]
+    want_rows = rows is not None
+    ids = list(problem.ids)
+    model_name = type(problem.dynamics.submodels[0]).__name__
+    trial_of = list(i_trial) if isinstance(i_trial, (list, tuple, np.ndarray)) else [i_trial] * S
+    row_log = [[] for _ in range(S)]
+    last_fields = [([], [], None) for _ in range(S)]       # (times, subgraphs, distance left) of a scenario's last round
+
+    def distance_left(idx):
+        return torch.linalg.vector_norm((xi[idx] - xf_d[idx]).reshape(len(idx), k, n_s)[:, :, :n_d], dim=2)
+
+    if want_rows:                                  # what solve_rhc holds before any round (a loop that never runs)
+        left0 = distance_left(torch.arange(S, device=xi.device)).cpu().numpy()
+        last_fields = [([], [], left0[s].tolist()) for s in range(S)]
 
     def keep_going(idx):      # one small device -> host read per round: the stopping flags
         if J_converge:
             return (J[idx] >= J_converge).cpu().numpy()
-        left = torch.linalg.vector_norm((xi[idx] - xf_d[idx]).reshape(len(idx), k, n_s)[:, :, :n_d], dim=2)
-        return (left > dist_converge).any(dim=1).cpu().numpy()
+        return (distance_left(idx) > dist_converge).any(dim=1).cpu().numpy()
 
     active = np.nonzero(keep_going(torch.arange(S, device=xi.device)))[0]
     while active.size:
         ia = torch.as_tensor(active, device=xi.device)
+        t_round = pc()
+        bits = None
         if centralized:
             pb = ProblemBatch(d["model"], d["n_dims"], xf_d[ia], d["Q"], d["R"], d["Qf"], d["radius"], dt, N,
                               w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(active))
@@ -182,8 +200,9 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
             Xa, Ua, Ja = r["X"], r["U"], r["J"]
         else:
             Xin = xi[ia][:, None, :] if X is None else X[ia]
-            Xa, Ua, Ja, _ = solve_scenarios_distributed(problem, Xin, U[ia], radius, xf=xf_d[ia], window=window, device_out=True,
-                                                        **solve_kw)
+            Xa, Ua, Ja, info = solve_scenarios_distributed(problem, Xin, U[ia], radius, xf=xf_d[ia], window=window, device_out=True,
+                                                           **solve_kw)
+            bits = info["cluster_bits"]
         if X is None:
             X = torch.zeros((S, N + 1, n_x), dtype=torch.float64, device=xi.device)
         # what the round contributes to the executed trajectory: ONE (|active|, step_size, .) copy per round.  (Views into
@@ -196,11 +215,24 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
         X[ia] = torch.cat([Xa[:, step_size:], Xa[:, -1:].expand(-1, step_size, -1)], dim=1)
         U[ia] = torch.cat([Ua[:, step_size:], torch.zeros((len(active), step_size, n_u), dtype=torch.float64, device=xi.device)], dim=1)
         J[ia] = Ja
+        if want_rows:
+            share = (pc() - t_round) / (len(active) * k)
+            J_h, left_h = Ja.cpu().numpy(), distance_left(ia).cpu().numpy()
+            for j, s in enumerate(active):
+                if centralized:
+                    subgraphs = [ids] * k                                    # solve_centralized: {id: (dt, ids)}
+                else:      # the agent's own id as a Python int, its neighbours as NumPy ints (quirk Q10, as the rows print them)
+                    subgraphs = [sorted([ids[i]] + [np.int64(ids[q]) for q in range(k) if q != i and (int(bits[j, i]) >> q) & 1])
+                                 for i in range(k)]
+                last_fields[s] = ([share] * k, subgraphs, left_h[j].tolist())
+                row_log[s].append(rhc_log_row(model_name, k, trial_of[s], centralized, False, t[s], float(J_h[j]), N, dt,
+                                              bool(converged[s]), ids, *last_fields[s]))
         diverged = np.zeros(len(active), dtype=bool)
         if t_diverge:
-            diverged = t[active] >= t_diverge
+            diverged = np.array([t[s] >= t_diverge for s in active])
             converged[active[diverged]] = False
-        t[active[~diverged]] += step_size * dt
+        for s in active[~diverged]:
+            t[s] += step_size * dt
         still = keep_going(ia) & ~diverged
         active = active[still]
     out = []
@@ -213,4 +245,9 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
                            w_ref=d["w_ref"], w_prox=d["w_prox"], B=1)
         _, Jf = pbs.rollout(x0[s:s + 1], Uf[None])
         out.append((Xf, Uf, float(Jf.cpu().numpy()[0]), bool(converged[s])))
+        if want_rows:
+            row_log[s].append(rhc_log_row(model_name, k, trial_of[s], centralized, True, Uf.shape[0] * dt, out[-1][2], N, dt,
+                                          bool(converged[s]), ids, *last_fields[s]))
+    if want_rows:
+        rows.extend(row_log)
     return out
