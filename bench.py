@@ -164,13 +164,45 @@ def launch_ranks(n):
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     procs = []
+
+    def die_with_parent():       # runs in the child between fork and exec: nothing here has touched a GPU
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)      # PR_SET_PDEATHSIG: a SIGKILLed launcher still takes its ranks down
+        except OSError:
+            pass
+
     for r in range(n):
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), start_new_session=True))
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), start_new_session=True,
+                                      preexec_fn=die_with_parent))
+
+    def stop_all(sig=signal.SIGTERM):
+        for p_ in procs:                 # exact process groups we started, nothing by pattern
+            if p_.poll() is None:
+                try:
+                    os.killpg(p_.pid, sig)
+                except ProcessLookupError:
+                    pass
+
+    def on_signal(signum, frame):        # the driver's timeout, a closed terminal: the ranks must not outlive the launcher
+        stop_all()
+        deadline = time.time() + 10.0
+        while time.time() < deadline and any(p_.poll() is None for p_ in procs):
+            time.sleep(0.05)
+        stop_all(signal.SIGKILL)
+        raise SystemExit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     rc = 0
     live = set(range(n))
+    t_stop = None                        # when the survivors of a failed rank were told to stop
     try:
         while live:
+            if t_stop is not None and time.time() - t_stop > 15.0:
+                stop_all(signal.SIGKILL)         # a rank that ignores SIGTERM (stuck in a collective) is not waited for for ever
+                t_stop = time.time()
             for r in sorted(live):
                 code = procs[r].poll()
                 if code is None:
@@ -179,18 +211,11 @@ def launch_ranks(n):
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
                     print(f"bench.py: rank {r} of {n} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
-                    for q in live:          # exact process groups we started, nothing by pattern
-                        try:
-                            os.killpg(procs[q].pid, signal.SIGTERM)
-                        except ProcessLookupError:
-                            pass
+                    stop_all()
+                    t_stop = time.time()
             time.sleep(0.05)
     except KeyboardInterrupt:
-        for q in live:
-            try:
-                os.killpg(procs[q].pid, signal.SIGTERM)
-            except ProcessLookupError:
-                pass
+        stop_all()
         rc = 130
     return rc
 
@@ -214,6 +239,8 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    if args.gather_path and args.gpus != 1:
+        raise SystemExit("--gather-path is the N = 1 diagnostic of the N > 1 path; with --gpus > 1 that path runs anyway")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks, one per GPU, BEFORE anything here
         # has imported torch or touched a GPU (a process that has initialised HIP must never be replaced or forked)
@@ -289,13 +316,15 @@ def main():
     for w in (12, 8, 4):
         _lib.profile_read_sweep(w, reset=True)
     times = []
+    own_times = []                      # this rank's own clock around the same region (per-rank values of the JSON line)
     r0 = None
     for rep in range(reps):
         fence()
         t0 = time.perf_counter()
         r = run(jobs[rep], rb)
         fence()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        own_times.append(time.perf_counter() - t0)
+        dt = torch.tensor([own_times[-1]], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         times.append(float(dt.item()))
@@ -314,6 +343,31 @@ def main():
     elapsed = times[order[(reps - 1) // 2]] if reps % 2 else 0.5 * (times[order[reps // 2 - 1]] + times[order[reps // 2]])
     total_units = B * world * args.steps
     value = total_units / elapsed
+
+    # Who ran this: every rank's device as the runtime names it, and its own median throughput.  A multi-GPU line validates
+    # itself -- the rank count is the process group's, the devices must be pairwise distinct (two ranks on one GPU would
+    # still print a plausible number), and the N = 1 line says which code path produced it.
+    props = torch.cuda.get_device_properties(local_rank)
+    own_sorted = sorted(own_times)
+    own_med = own_sorted[(reps - 1) // 2] if reps % 2 else 0.5 * (own_sorted[reps // 2 - 1] + own_sorted[reps // 2])
+    me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "device_name": props.name,
+          "pci_bus": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xFF,
+                                         getattr(props, "pci_device_id", -1) & 0xFF),
+          "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+          "value": args.steps * B / own_med, "ms_per_step": own_med / args.steps * 1e3}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    else:
+        ranks = [me]
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        if ranks_seen != args.gpus or len(ranks) != args.gpus or sorted(r_["rank"] for r_ in ranks) != list(range(args.gpus)):
+            raise SystemExit(f"bench.py: the process group has {ranks_seen} ranks, --gpus asked for {args.gpus}")
+        if backend == "nccl" and world > 1:
+            ident = [(r_["uuid"] or r_["pci_bus"], r_["device_index"]) for r_ in ranks]
+            if len(set(ident)) != world:
+                raise SystemExit(f"bench.py: {world} ranks but their devices are not pairwise distinct: {ident}")
 
     if rank == 0:
         # roofline = the dominant kernel: the sweep variant (wavefronts per workgroup) that ran the full-window launches,
@@ -399,6 +453,11 @@ def main():
                  "read_only": {"achieved": gbs_r, "frac": gbs_r / HBM_PEAK_GBS, "bytes_per_subproblem_pass": BWD_READ_BYTES,
                                "note": "the north star's '>= 40 % HBM-read roofline' counts the tile reads alone"},
                  "items": nw, "launch_ms": ms_t, "launches_back_to_back": sweep_reps,
+                 "method_version": 2,      # 1 (rounds 1-3): launch_ms / achieved / frac = median of ISOLATED launches (idle chip);
+                                           # 2 (round 4 on): mean of the back-to-back launches; version 1's figure is isolated_launch_ms
+                 "isolated": {"launch_ms": float(np.median(ms_list)),
+                              "frac": nw * (BWD_READ_BYTES + BWD_WRITE_BYTES) / (float(np.median(ms_list)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "read_only_frac": nw * BWD_READ_BYTES / (float(np.median(ms_list)) * 1e-3) / 1e9 / HBM_PEAK_GBS},
                  "isolated_launch_ms": {"median": float(np.median(ms_list)), "min_max": [min(ms_list), max(ms_list)],
                                         "note": "one launch at a time, each after a device synchronisation (idle chip)"},
                  "bytes_per_subproblem_pass": BWD_READ_BYTES + BWD_WRITE_BYTES,
@@ -421,6 +480,9 @@ def main():
         nb = r0["n_bwd"].cpu().numpy(); nf = r0["n_fwd"].cpu().numpy(); st = r0["status"].cpu().numpy()
         out = {
             "metric": "ilqr_subproblems_per_sec", "value": value, "unit": "subproblems/s", "n_gpus": world,
+            "ranks_seen": ranks_seen, "backend": (backend if world > 1 else None),
+            "ranks": ranks,          # per rank: device index / PCI bus / uuid as the runtime reports them, its own value
+            "n1_path": ("plain" if rb is None else "gather-path (diagnostic)") if world == 1 else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repetitions": {"n": reps, "statistic": "median", "ms_per_step": [t / args.steps * 1e3 for t in times],
@@ -463,7 +525,7 @@ def main():
                 "all_items_envelope": dict(rep["summary"], violating_items=[int(i) for i in np.where(~rep["ok"])[0][:8]],
                                            reasons=[w for w in rep["why"] if w][:4]),
                 "note": "all_items_envelope: every item of the first 2048, through every iteration of its solve, against the oracle "
-                        "replayed along the GPU's own decisions from x0 and from 8 perturbed copies of x0 (+-1e-13..5e-13): accepted costs, "
+                        "replayed along the GPU's own decisions from x0 and from 32 perturbed copies of x0 (+-1e-14..5e-13): accepted costs, "
                         "final X, U, J within 10 x the ensemble's spread, every decision that is not the oracle's own verdict on the "
                         "same iterate undetermined in the ensemble too (oracle/parity.py; calibrated in tests/test_parity_envelope.py)"}
         print(json.dumps(out), flush=True)

@@ -152,6 +152,7 @@ struct WaveFwdLds {
 #define DPILQR_LS_PF 2
 #endif
     static constexpr int PF = (NW == 1 && NS == 4 && !CONST_LDS) ? DPILQR_LS_PF : 1;
+    static_assert(PF == 1 || PF == 2, "the horizon loop is written out for one or two register stages (step t, step t + 1)");
     static constexpr int oQ = (octl + 2 + 1) & ~1;                 // Q [agent][NS*NS]
     static constexpr int oR = oQ + (CONST_LDS ? KA * NS * NS : 0); // R [agent][NC*NC]
     static constexpr int oXf = oR + (CONST_LDS ? KA * NC * NC : 0);

@@ -27,7 +27,10 @@
 
 namespace dpilqr {
 
-constexpr int kBigThreads = 1024;   // sixteen wavefronts per sub-problem: the phases below are latency-bound loops over L2-resident data
+#ifndef DPILQR_BIG_THREADS
+#define DPILQR_BIG_THREADS 1024
+#endif
+constexpr int kBigThreads = DPILQR_BIG_THREADS;   // sixteen wavefronts per sub-problem: the phases below are latency-bound loops over L2-resident data
 
 __host__ __device__ constexpr int big_round_up(int x, int q) { return (x + q - 1) / q * q; }
 

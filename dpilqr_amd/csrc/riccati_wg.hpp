@@ -796,7 +796,10 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                 // The four-state family's blocks (DoubleIntDynamics4D, UnicycleDynamics4D; models.hpp jac): A = I + dt A_c with
                 // A_c's entries (0,2), (1,2), (0,3), (1,3) free and nothing else, B = dt [0; 0; I].  Of the four-term chains of the
                 // general form below only these terms are not a multiplication by an exact 0 or 1 -- dropped or written as what
-                // they are, the results are the chains' bit for bit (a zero's sign apart): 8 instead of 48 multiply-adds per item.
+                // they are, the results are the chains' bit for bit for FINITE P (a zero's sign apart): 8 instead of 48 multiply-adds
+                // per item.  A non-finite P is another matter: the general chain turns 0 * Inf into NaN in every entry of the row,
+                // the structured form only where P's non-finite entry really enters -- a diverged sweep's garbage spreads
+                // differently (the item's status is the same: its costs are NaN either way and the line search rejects them).
                 double pr4[4][2];
 #pragma unroll
                 for (int l = 0; l < 4; ++l) ld_row<2, true>(sP + (NS * ag + l) * LP + j0, pr4[l]);

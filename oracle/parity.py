@@ -13,7 +13,8 @@ holds EVERY item, through EVERY iteration of its solve, to an envelope the oracl
   r    = the oracle REPLAYED along g's decisions from x0 (oracle_solve_replay): the oracle's numbers for the same
          iterates -- also after a decision on which g and the oracle's own choice differ -- plus, per iteration, the
          oracle's own verdict and how far from equality every comparison that went the other way sat
-  r_e  = the same replay from x0 (1 + delta_e), e = 1..32, |delta| log-spaced over 1e-13..5e-13, both signs: the ensemble
+  r_e  = the same replay from x0 (1 + delta_e), e = 1..32, |delta| log-spaced over 1e-14..5e-13 (16 magnitudes, both
+         signs -- half of them below 1e-13: a perturbation of a few ulp of x0 is the gentlest question one can ask): the ensemble
          (ONE fixed size for every item; round 3 looked at failing items again with a larger ensemble, a strictly looser
          second chance -- removed)
   spread_J[j] = max over e and over iterations <= j of |J*_e - J*_r| / |J*_r| (accepted costs and the last evaluated

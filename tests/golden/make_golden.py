@@ -21,6 +21,8 @@ Manifest:
   g6_scenarios.npz   np.random.seed(s); random_setup(...)
   g7_callers.npz     solve_rhc (centralized and distributed branch, with the logging rows), selfish_warmstart,
                      solve_subproblem
+  g9_chaos_*.npz     the reference on items the GPU decides differently from the oracle: x0 and 32 perturbed copies
+                     (python tests/golden/make_golden.py g9; needs gpurun_out/flips/ from scripts/find_flips.py)
   g8_hetero_*.npz    the zero-padded human model (12 states / 4 controls) mixed with Quadcopter12D: a shim class
                      built from reference calls (the reference itself cannot mix 12- and 6-state agents)
 
@@ -599,11 +601,83 @@ def g8_hetero():
     np.savez_compressed(OUT / "g8_hetero_k20.npz", **out)
 
 
+# --------------------------------------------------------------------------- G9
+# Does the reference determine its own result?  For items the GPU decides differently from the CPU oracle (seeds found on
+# the GPU box by scripts/find_flips.py; the lists are copied into the fixture) the REAL reference solves x0 and 32 copies
+# of x0 perturbed by 1e-14 .. 5e-13 (oracle/parity.py's ensemble): per member the decision trace, the accepted costs, the
+# returned J and how far its final trajectory lies from the unperturbed member's.
+G9_FAMILIES = {   # name: (model class name, k, T, hover warm start, how many flipped items, how many controls)
+    "cfg2": ("DoubleIntDynamics4D", 5, 50, False, 48, 4),
+    "uni8": ("UnicycleDynamics4D", 8, 100, False, 8, 2),
+    "quad10": ("QuadcopterDynamics6D", 10, 75, True, 5, 1),
+}
+G9_DELTAS = tuple(float(sg * v) for v in np.geomspace(1e-14, 5e-13, 16) for sg in (1.0, -1.0))   # = oracle/parity.py DELTAS
+
+
+def _g9_member(task):
+    fam, seed, delta = task
+    cls_name, k, T, hover, _, _ = G9_FAMILIES[fam]
+    cls = getattr(dp, cls_name)
+    prob, meta = analysis_problem(cls, k, seed)
+    U0 = warm_U([cls] * k, T) if hover else np.zeros((T, k * cls(0.1).n_u))
+    x0 = meta["x0"] * (1.0 + delta)
+    with redirect_stdout(io.StringIO()):
+        r = traced_solve(prob, x0, U0, T)
+    return fam, seed, delta, r, meta
+
+
+def g9_chaos(flips_dir=None):
+    import multiprocessing as mp
+    flips_dir = Path(flips_dir) if flips_dir else OUT.parent.parent / "gpurun_out" / "flips"
+    tasks, chosen = [], {}
+    for fam, (_, k, T, hover, n_flip, n_ctl) in G9_FAMILIES.items():
+        z = np.load(flips_dir / f"{fam}.npz")
+        fl = np.nonzero(z["flipped"])[0]; ct = np.nonzero(~z["flipped"])[0]
+        # spread the flipped items over the seed range instead of taking the first ones
+        take = np.concatenate([fl[np.linspace(0, len(fl) - 1, min(n_flip, len(fl))).round().astype(int)], ct[:n_ctl]])
+        chosen[fam] = (z, take)
+        for i in take:
+            for delta in (0.0,) + G9_DELTAS:
+                tasks.append((fam, int(z["seeds"][i]), delta))
+    with mp.Pool(8) as pool:
+        results = pool.map(_g9_member, tasks, chunksize=1)
+    by = {}
+    for fam, seed, delta, r, meta in results:
+        by.setdefault((fam, seed), {})[delta] = (r, meta)
+    ROWS = 50
+    for fam, (z, take) in chosen.items():
+        seeds = [int(z["seeds"][i]) for i in take]
+        M = 1 + len(G9_DELTAS)
+        n_bwd = np.zeros((len(seeds), M), dtype=np.int16); acc = np.full((len(seeds), M, ROWS), -9, dtype=np.int8)
+        Jstar = np.full((len(seeds), M, ROWS), np.nan); Jlast = np.full((len(seeds), M, ROWS), np.nan)
+        J = np.zeros((len(seeds), M)); J0 = np.zeros((len(seeds), M)); dX = np.zeros((len(seeds), M)); dU = np.zeros((len(seeds), M))
+        Xb, Ub, x0s, xfs = [], [], [], []
+        for a, seed in enumerate(seeds):
+            base, meta = by[(fam, seed)][0.0]
+            Xb.append(base["X"]); Ub.append(base["U"]); x0s.append(meta["x0"]); xfs.append(meta["xf"])
+            for b, delta in enumerate((0.0,) + G9_DELTAS):
+                r, _ = by[(fam, seed)][delta]
+                nb = len(r["mu_trace"])
+                n_bwd[a, b] = nb; acc[a, b, :nb] = r["acc_trace"]; Jstar[a, b, :nb] = r["Jstar_trace"]; Jlast[a, b, :nb] = r["Jlast_trace"]
+                J[a, b] = r["J"]; J0[a, b] = r["J0"]
+                dX[a, b] = np.max(np.abs(r["X"] - base["X"])) / np.max(np.abs(base["X"]))
+                dU[a, b] = np.max(np.abs(r["U"] - base["U"])) / max(np.max(np.abs(base["U"])), 1e-300)
+        cls_name, k, T, hover, _, _ = G9_FAMILIES[fam]
+        np.savez_compressed(OUT / f"g9_chaos_{fam}.npz", seeds=np.array(seeds), flipped_on_gpu=z["flipped"][take],
+                            deltas=np.array((0.0,) + G9_DELTAS), n_bwd=n_bwd, acc_trace=acc, Jstar_trace=Jstar.astype(np.float32),
+                            J=J, J0=J0, dX_vs_base=dX, dU_vs_base=dU, X_base=np.array(Xb), x0=np.array(x0s),
+                            xf=np.array(xfs), model=np.array(cls_name), k=np.array(k), T=np.array(T), hover=np.array(hover),
+                            gpu_n_bwd_when_found=z["gpu_n_bwd"][take], gpu_accept_when_found=z["gpu_accept"][take])
+        same = (n_bwd == n_bwd[:, :1]).all(axis=1) & (acc == acc[:, :1]).all(axis=(1, 2))
+        print(f"g9 {fam}: {len(seeds)} items; the reference's own 33 members take ONE decision trace on {int(same.sum())} of them; "
+              f"max trajectory spread among members {dX.max():.2e}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         print("generating", w, flush=True)
         {"g1": g1_models, "g2": g2_costs, "g3": g3_passes, "g4": g4_solves,
-         "g5": g5_dispatch, "g6": g6_scenarios, "g7": g7_callers, "g8": g8_hetero}[w]()
+         "g5": g5_dispatch, "g6": g6_scenarios, "g7": g7_callers, "g8": g8_hetero, "g9": g9_chaos}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f"{f.name:40s} {f.stat().st_size/1024:8.1f} KiB")

@@ -643,6 +643,11 @@ def test_plain_bench_gpus_2_starts_two_ranks_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["launches"] > 0
     assert "cpu_baseline" not in d                       # N = 1 only
+    # the line validates itself: the rank count is the process group's, every rank names its device and its own throughput
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["n1_path"] is None
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and len({r["pid"] for r in d["ranks"]}) == 2
+    assert all(r["value"] > 0 and r["device_name"] and r["pci_bus"] for r in d["ranks"])
+    assert d["value"] <= sum(r["value"] for r in d["ranks"]) * 1.0001        # MAX over ranks bounds the job's time
     assert "batch-sharded x2" in d["config"]["parallelism"]
 
 

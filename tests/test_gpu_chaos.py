@@ -1,0 +1,57 @@
+"""The GPU against the REAL reference's perturbed ensemble (tests/golden/g9_chaos_*.npz, tests/chaos_util.py): on the
+items where the GPU's decisions differ from the CPU oracle's -- found on an MI355X by scripts/find_flips.py -- the
+reference was run on x0 and on 32 copies perturbed by 1e-14 .. 5e-13.  Every GPU decision must be one the reference
+ensemble takes or does not determine; the GPU's returned cost must lie where the reference's own 33 costs lie; and where the
+reference does determine its result the GPU reproduces it to the north star's 1e-5."""
+import numpy as np
+import pytest
+
+from tests import chaos_util as cu
+from tests.golden_util import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dp():
+    import dpilqr_amd
+    from dpilqr_amd import _lib
+    _lib.require_gpu()
+    return dpilqr_amd
+
+
+@pytest.mark.parametrize("fam", ["cfg2", "uni8", "quad10"])
+def test_gpu_decisions_against_the_reference_ensemble(dp, golden, fam):
+    z = golden(f"g9_chaos_{fam}")
+    model, n_dims, x0, xf, U0, Q, R, Qf, T = cu.problem_inputs(z)
+    pb = dp.ProblemBatch(model, n_dims, xf, Q, R, Qf, 0.5, 0.1, T)
+    g = {k: v.cpu().numpy() for k, v in pb.solve(x0, U0, trace=True).items()}
+    total = dict(witnessed=0, undetermined=0, violation=0, inconclusive=0, exhausted=0)
+    inside = strictly_inside = determined = 0
+    n = len(z["seeds"])
+    for a in range(n):
+        members = cu.member_traces(z, a)
+        mine = cu.trace_of(g["n_bwd"][a], np.nan_to_num(g["trace"][a, :, 1], nan=-9))
+        upto = cu.unanimous_prefix(members)
+        assert mine[:upto] == members[0][:upto], (fam, int(z["seeds"][a]), upto)      # while all 33 agree, so does the GPU
+        cat, where = cu.classify(mine, members)
+        for k_, v in cat.items():
+            total[k_] += v
+        lo, hi = z["J"][a].min(), z["J"][a].max()
+        strictly_inside += bool(lo - 1e-9 * abs(lo) <= g["J"][a] <= hi + 1e-9 * abs(hi))
+        inside += bool(lo - 1e-9 * abs(lo) - (hi - lo) <= g["J"][a] <= hi + 1e-9 * abs(hi) + (hi - lo))
+        # the final trajectory: no farther from the reference's than 10 x what its own perturbed members are
+        assert relerr(g["X"][a], z["X_base"][a]) <= 10 * max(1e-11, z["dX_vs_base"][a].max()), (fam, int(z["seeds"][a]))
+        if len(set(members)) == 1 and z["dX_vs_base"][a].max() < 1e-7:               # the reference determines this item
+            determined += 1
+            nb = int(z["n_bwd"][a, 0])
+            assert mine == members[0]
+            assert np.allclose(g["trace"][a, :nb, 3], z["Jstar_trace"][a, 0, :nb], rtol=1e-6)
+            assert relerr(g["X"][a], z["X_base"][a]) < 1e-5 and abs(g["J"][a] - z["J"][a, 0]) <= 1e-5 * abs(z["J"][a, 0])
+    n_dec = sum(total.values())
+    print(f"{fam}: {n} items, {n_dec} GPU decisions vs the reference's 33-member ensemble: {total}; returned J inside the members' "
+          f"range on {strictly_inside} / {n}; {determined} items determined by the reference")
+    assert total["violation"] <= max(1, n_dec // 100), total
+    assert total["witnessed"] >= 0.8 * n_dec, total
+    assert inside == n and strictly_inside >= 0.9 * n
+    assert determined >= 1

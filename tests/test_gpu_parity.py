@@ -584,13 +584,19 @@ def test_solve_large_clusters_vs_oracle(dp, model, k, T):
     rep = parity.envelope(r, proto, x0, xf, U0, natural=o)
     assert rep["summary"]["all_ok"], (rep["summary"], [w for w in rep["why"] if w])
     assert rep["summary"]["unchecked_frac"] <= 0.01
-    plain = ~rep["flipped"] & (rep["spreadX"] < 1e-6)
-    # (ten quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the oracle itself on most seeds:
-    # the envelope above still holds for every item, through every iteration)
-    assert plain.sum() >= (1 if (model, k) in ((4, 10), (3, 8), (3, 6)) else 2), rep["summary"]
+    # The north star's fixed 1e-5 for EVERY item the reference determines: an ensemble that stays within 1e-6 ("tight").  Ten
+    # quadcopters solved centrally from hover, and these eight unicycles, are chaotic in the reference itself on most seeds
+    # (tests/golden/g9_chaos_*.npz: the REAL reference's 33 perturbed runs take ~30 different decision traces there) -- the
+    # envelope above still holds for every item, through every iteration.
+    tight = rep["spreadX"] < 1e-6
+    assert (rep["errX"][tight] < TOL_SOLVE).all() and (rep["errU"][tight] < TOL_SOLVE).all(), rep["summary"]
+    plain = ~rep["flipped"] & tight
+    assert tight.sum() >= (1 if (model, k) in ((4, 10), (3, 8), (3, 6)) else 2), rep["summary"]
+    assert 2 * plain.sum() >= tight.sum(), (int(plain.sum()), int(tight.sum()))     # at least half of them: the oracle's own decisions throughout
     for i in np.where(plain)[0]:
         assert r["n_fwd"][i] == o["n_fwd"][i] and r["status"][i] == o["status"][i], i
         assert relerr(r["X"][i], o["X"][i]) < TOL_SOLVE and relerr(r["U"][i], o["U"][i]) < TOL_SOLVE, i
+    print(f"model {model} k {k}: {int(tight.sum())} of {B} items tight, {int(plain.sum())} of them with the oracle's own trace")
     assert np.isfinite(r["X"]).all()
 
 

@@ -321,3 +321,56 @@ def test_numpy_port_solve_misc(golden, tag):
     r = s.solve(g("x0"), g("U0"))
     np.testing.assert_array_equal(r["trace"][:, 1].astype(int), g("acc_trace"))
     assert relerr(r["X"], g("X")) < TOL_SOLVE and relerr(r["U"], g("U")) < TOL_SOLVE
+
+
+# ---------------------------------------------------------------- G9: does the reference determine its own result?
+@pytest.mark.parametrize("fam", ["cfg2", "uni8", "quad10"])
+def test_g9_the_reference_does_not_determine_its_own_result_where_the_gpu_flips(golden, fam):
+    """The fixture's own content, as a fact about the REFERENCE: on every item the GPU decided differently from the oracle,
+    the reference's 33 runs (x0 and 32 copies perturbed by at most 5e-13) do not agree on one decision trace -- typically
+    they take some thirty different ones -- while on the control items they take exactly one."""
+    from tests import chaos_util as cu
+    z = golden(f"g9_chaos_{fam}")
+    assert np.allclose(np.sort(np.abs(z["deltas"][1:])), np.sort(np.abs(np.array(__import__("oracle.parity", fromlist=["DELTAS"]).DELTAS))))
+    flipped = z["flipped_on_gpu"].astype(bool)
+    n_traces = np.array([len(set(cu.member_traces(z, a))) for a in range(len(flipped))])
+    assert (n_traces[flipped] >= 2).all(), n_traces
+    assert np.median(n_traces[flipped]) >= 10
+    assert (n_traces[~flipped] == 1).sum() >= 1
+    spread = z["dX_vs_base"].max(axis=1)
+    assert np.median(spread[flipped]) > 1e-3          # the members' final trajectories differ in the leading digits
+
+
+@pytest.mark.parametrize("fam", ["cfg2", "uni8", "quad10"])
+def test_g9_oracle_against_the_reference_ensemble(golden, fam):
+    """The C oracle on the same items (from the unperturbed x0): while all 33 reference members still agree on a decision
+    the oracle takes it too; afterwards each of its decisions is one an alive member takes, or one the alive members do not
+    agree on among themselves -- at most 1 % are taken against a unanimous group of >= 8 members (unanimity of n samples
+    bounds the odds of another outcome only by ~3/n).  On items where the reference takes ONE trace the oracle reproduces
+    it, the iteration costs and the final trajectory."""
+    from tests import chaos_util as cu
+    z = golden(f"g9_chaos_{fam}")
+    model, n_dims, x0, xf, U0, Q, R, Qf, T = cu.problem_inputs(z)
+    proto = orc.Problem(model, n_dims, xf[0], Q, R, Qf, 0.5, 0.1, T)
+    o = orc.solve_batch(proto, x0, xf, U0, trace=True)
+    total = dict(witnessed=0, undetermined=0, violation=0, inconclusive=0, exhausted=0)
+    inside = 0
+    for a in range(len(z["seeds"])):
+        members = cu.member_traces(z, a)
+        mine = cu.trace_of(o["n_bwd"][a], np.nan_to_num(o["trace"][a, :, 1], nan=-9))
+        upto = cu.unanimous_prefix(members)
+        assert mine[:upto] == members[0][:upto], (fam, int(z["seeds"][a]), upto)
+        cat, _ = cu.classify(mine, members)
+        for k_, v in cat.items():
+            total[k_] += v
+        lo, hi = z["J"][a].min(), z["J"][a].max()
+        inside += bool(lo - 1e-9 * abs(lo) - (hi - lo) <= o["J"][a] <= hi + 1e-9 * abs(hi) + (hi - lo))
+        if len(set(members)) == 1 and z["dX_vs_base"][a].max() < 1e-7:      # the reference determines this item
+            nb = int(z["n_bwd"][a, 0])
+            assert mine == members[0]
+            assert np.allclose(o["trace"][a, :nb, 3], z["Jstar_trace"][a, 0, :nb], rtol=1e-6)      # stored as float32
+            assert relerr(o["X"][a], z["X_base"][a]) < TOL_SOLVE
+    n_dec = sum(total.values())
+    assert total["violation"] <= max(1, n_dec // 100), total
+    assert total["witnessed"] >= 0.8 * n_dec, total
+    assert inside == len(z["seeds"]), inside            # the returned cost: within the reference ensemble's range, widened by its width
