@@ -200,12 +200,11 @@ template <> struct ModelDef<kQuadcopter12D> {
         o[11] = R(kTz) * u[2] - R(kCz) * wx * wy;
     }
     template <typename R> __device__ static void jac(const R* x, const R*, R* A, R* B) {
-        // (sin and cos by separate calls HERE -- the Jacobians are evaluated once per step, their cost is nothing -- because
-        // sincos pairs keep some eighteen more registers live, and in the large-cluster sweep (riccati_big.hpp: 128 registers
-        // per lane, 64 of them spilled already) the build with 82 spilled registers died with an HSA memory aperture
-        // violation on config 5's heterogeneous team -- deterministically, and not under rocgdb.  tests/test_kernel_resources.py
-        // holds that kernel to the spill count it is known to run with.)
-#ifdef DPILQR_JAC_SINCOS   // diagnostic builds only: the form that raises the large-cluster sweep's spills to 82 registers (see above)
+        // (sin and cos by separate calls here: the Jacobians are evaluated once per step, their cost is nothing, and the values are
+        // those of sincos.  Round 4 reverted sincos pairs because they raised the large-cluster sweep's spills from 64 to 82
+        // registers, a build that died with an HSA aperture violation; since round 5 that sweep does not spill in either form
+        // -- riccati_big.hpp -- and -DDPILQR_JAC_SINCOS only remains as the soak test's second build, scripts/cfg5_soak.sh.)
+#ifdef DPILQR_JAC_SINCOS   // diagnostic builds only (see above)
         R sps, cps, sth, cth, sph, cph;
         sincos_r(x[3], &sps, &cps); sincos_r(x[4], &sth, &cth); sincos_r(x[5], &sph, &cph);
         const R tth = tan(x[4]);

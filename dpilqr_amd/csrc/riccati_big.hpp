@@ -53,12 +53,22 @@ template <> struct Mfma<double> {
     typedef double acc_t __attribute__((ext_vector_type(4)));
     __device__ static __forceinline__ acc_t mac(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     __device__ static __forceinline__ int row(int v, int g) { return g + 4 * v; }    // scripts/ubench/mfma_f64.hip
+    __device__ static constexpr int reg_of(int row) { return row / 4; }              // ... and its inverse: which register,
+    __device__ static constexpr int group_of(int row) { return row % 4; }            // which 16-lane group holds a tile row
 };
 template <> struct Mfma<float> {
     typedef float acc_t __attribute__((ext_vector_type(4)));
     __device__ static __forceinline__ acc_t mac(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     __device__ static __forceinline__ int row(int v, int g) { return 4 * g + v; }
+    __device__ static constexpr int reg_of(int row) { return row % 4; }
+    __device__ static constexpr int group_of(int row) { return row / 4; }
 };
+
+// the value lane `src` holds (ds_bpermute: any lane to any lane)
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)));
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
 
 // Scratch of one workgroup in global memory, in elements of R.  Every matrix has the same leading dimension ldw (a
 // multiple of 16 >= n + 1, so that a 16-wide operand tile never leaves its row) and the control-indexed ones have mk
@@ -163,6 +173,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 
     // per-step plugin evaluation at (x, u) of step t: linearisation, x - x_f, pair derivatives, weights
     auto stage_step = [&](int t, bool terminal) {
+        // (its own thread id, opaque to the optimiser like the phases' lane terms below: hoisted out of the horizon loop the
+        // staging loops' per-lane addresses stayed live through every phase and were spilled)
+        int tid_s_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_s_));
+        const int tid = tid_s_;
         const R* xt = Xb + (int64_t)t * n;
         const R* ut = Ub + (int64_t)(terminal ? 0 : t) * m;
         // the Jacobians are written straight into LDS (a Quadcopter12D Jacobian held in registers costs 400 of them and
@@ -264,7 +279,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     // The lane terms of a phase (tile coordinates, operand addresses) are formed at the phase's start from a thread id the
     // optimiser cannot see through: hoisted out of the horizon loop they are some fifty 64-bit addresses per lane, and at the
     // 128 registers per lane that sixteen wavefronts per CU allow they were spilled in the prologue and reloaded inside the
-    // phases' inner loops (round 2: 82 spilled registers, 324 B of scratch per lane).
+    // phases' inner loops (round 2: 82 spilled registers, 324 B of scratch per lane).  What the IR-level trick cannot reach --
+    // constants and addresses the MACHINE-level LICM hoists -- is switched off for this translation unit
+    // (__graft_entry__.UNIT_FLAGS: -mllvm -disable-machine-licm); together with round 5's substitution: no spills.
 #define BIG_LANE_TERMS()                                                                                   \
     int tid_p_ = threadIdx.x;                                                                              \
     asm volatile("" : "+v"(tid_p_));                                                                       \
@@ -497,98 +514,98 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         BPHASE(2)
 
         { BIG_LANE_TERMS()
-        // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u]: one right-hand side per thread, substitution in blocks of 16 rows
-        // (solved blocks go through the scratch; a row of 16 threads' values is one coalesced access)
-        // The factors' rows are read sixteen entries at a time as pairs (every row starts on an even offset): element by element
-        // each multiply-add waited for its own LDS load -- a 6 400-step chain per right-hand side at one LDS round trip per step
-        typedef R pair_t __attribute__((ext_vector_type(2)));
-        auto ld8 = [](const R* __restrict__ src, R (&o)[8]) {
+        // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u] by blocked substitution on the matrix pipe (round 5).  A wavefront owns a
+        // tile of sixteen right-hand sides (columns 16 jt .. 16 jt + 15 of [Q_ux | Q_u]: sixteen tiles at n_x = 240, one per
+        // wavefront) and walks the block rows I of the factors: the block row's updates Y_I -= L_IJ Y_J (80 % of the
+        // substitution's flops) are 16x16x4 products -- the factors' entries straight from LDS through the row permutation, the
+        // solved blocks Y_J read back from the scratch in the operand order (for fp64 a lane reads exactly the four entries it
+        // stored itself: D's row g + 4 v is the B operand's row 4 q + g at q = v) -- and the 16 x 16 diagonal block is solved
+        // inside the tile: lane (g, c) holds rows row(v, g) of column c, the pivot row's entry goes to the column's other
+        // three lanes by a lane shuffle, every lane updates its four rows.  Round 4's form -- one right-hand side per THREAD,
+        // 241 of 1024 threads busy, sixteen-row blocks of y, of the solved block and of a factor row in registers (112 of a lane's
+        // 128 registers; with S5 the reason the kernel spilled) -- took 301 k of a step's 1.43 M clocks.
+        {
+            const int nb = mk / 16, ntile = ldw / 16;
+            for (int jt = wave; jt < ntile; jt += kBigThreads / 64) {
+                const int col = 16 * jt + c16;
+                for (int I = 0; I < nb; ++I) {                   // L y = P b
+                    int prow[4];
+                    acc_t y;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const pair_t v = *reinterpret_cast<const pair_t*>(src + 2 * q);
-                o[2 * q] = v.x; o[2 * q + 1] = v.y;
-            }
-        };
-        const int nb = mk / 16;
-        for (int j = tid; j < n1; j += kBigThreads) {
-            for (int I = 0; I < nb; ++I) {                       // L y = P b
-                R y[16];
-                int pr[16];
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = 16 * I + Mfma<R>::row(v, g16), pr = sPerm[r];
+                        prow[v] = pr * ldlu;
+                        y[v] = (r < m) ? gG[(int64_t)pr * ldw + col] : (R)0.0;
+                    }
+                    const int arow = sPerm[16 * I + c16] * ldlu;
+                    for (int J = 0; J < I; ++J) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = 16 * I + i;
-                    pr[i] = sPerm[r] * ldlu;   // (the same for every thread; moved to scalar registers by readfirstlane it gave wrong rows at n_x = 64 -- not understood, not used)
-                    y[i] = (r < m) ? gG[(int64_t)sPerm[r] * ldw + j] : (R)0.0;
-                }
-                for (int J = 0; J < I; ++J) {
-                    R yj[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) yj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            R l[8];
-                            ld8(sLU + pr[i] + 16 * J + 8 * h, l);
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) y[i] = fma(-l[c], yj[8 * h + c], y[i]);
+                        for (int q = 0; q < 4; ++q) {
+                            const R a = -sLU[arow + 16 * J + 4 * q + g16];
+                            const R b = gKd[(int64_t)(16 * J + 4 * q + g16) * ldw + col];
+                            y = Mfma<R>::mac(a, b, y);
                         }
-                }
-                // the diagonal block, row by row (each y[i] still takes its terms in ascending c: the same sums as column by column)
-#pragma unroll
-                for (int i = 1; i < 16; ++i) {
-                    R l[16];
-#pragma unroll
-                    for (int q = 0; q < (i + 1) / 2; ++q) {
-                        const pair_t v = *reinterpret_cast<const pair_t*>(sLU + pr[i] + 16 * I + 2 * q);
-                        l[2 * q] = v.x; l[2 * q + 1] = v.y;
                     }
+                    // the unit-lower diagonal block: pivot rows 0 .. 14 in turn
 #pragma unroll
-                    for (int c = 0; c < i; ++c) y[i] = fma(-l[c], y[c], y[i]);
-                }
+                    for (int ip = 0; ip < 15; ++ip) {
+                        const int vp = Mfma<R>::reg_of(ip), gp = Mfma<R>::group_of(ip);
+                        const R yp = lane_bcast(y[vp], gp * 16 + c16);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) gKd[(int64_t)(16 * I + i) * ldw + j] = y[i];
-            }
-            for (int I = nb - 1; I >= 0; --I) {                  // U x = y ; [K | d] = -x
-                R y[16];
-                int pr[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { y[i] = gKd[(int64_t)(16 * I + i) * ldw + j]; pr[i] = sPerm[16 * I + i] * ldlu; }
-                for (int J = nb - 1; J > I; --J) {
-                    R xj[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) xj[c] = gKd[(int64_t)(16 * J + c) * ldw + j];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            R u[8];
-                            ld8(sLU + pr[i] + 16 * J + 8 * h, u);
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) y[i] = fma(u[c], xj[8 * h + c], y[i]);   // xj holds -x
+                        for (int v = 0; v < 4; ++v) {
+                            const R l = sLU[prow[v] + 16 * I + ip];
+                            if (Mfma<R>::row(v, g16) > ip) y[v] = fma(-l, yp, y[v]);
                         }
-                }
-#pragma unroll
-                for (int i = 15; i >= 0; --i) {
-                    R u[16];
-#pragma unroll
-                    for (int q = i / 2; q < 8; ++q) {
-                        const pair_t v = *reinterpret_cast<const pair_t*>(sLU + pr[i] + 16 * I + 2 * q);
-                        u[2 * q] = v.x; u[2 * q + 1] = v.y;
+                        // (without the fence the scheduler hoists all sixty factor loads of the block to its top: 120 registers)
+                        if (ip % 2 == 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                    R s = y[i];
 #pragma unroll
-                    for (int c = i + 1; c < 16; ++c) s = fma(u[c], y[c], s);
-                    y[i] = -(s / u[i]);
+                    for (int v = 0; v < 4; ++v) gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col] = y[v];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block is read back (by this wavefront only) as an operand
                 }
+                for (int I = nb - 1; I >= 0; --I) {              // U x = y ; [K | d] = -x  (the scratch holds -x: the updates add U (-x))
+                    int prow[4];
+                    acc_t y;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int a = 16 * I + i;
-                    if (a < m) {
-                        gKd[(int64_t)a * ldw + j] = y[i];
-                        if (j < n) Kout[((gslot * T + t) * m + a) * (int64_t)n + j] = y[i];
-                        else dout[(gslot * T + t) * m + a] = y[i];
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = 16 * I + Mfma<R>::row(v, g16);
+                        prow[v] = sPerm[r] * ldlu;
+                        y[v] = gKd[(int64_t)r * ldw + col];
                     }
+                    const int arow = sPerm[16 * I + c16] * ldlu;
+                    for (int J = nb - 1; J > I; --J) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const R a = sLU[arow + 16 * J + 4 * q + g16];
+                            const R b = gKd[(int64_t)(16 * J + 4 * q + g16) * ldw + col];
+                            y = Mfma<R>::mac(a, b, y);
+                        }
+                    }
+#pragma unroll
+                    for (int ip = 15; ip >= 0; --ip) {
+                        const int vp = Mfma<R>::reg_of(ip), gp = Mfma<R>::group_of(ip);
+                        const R sp_ = lane_bcast(y[vp], gp * 16 + c16);
+                        const R ud = sLU[sPerm[16 * I + ip] * ldlu + 16 * I + ip];
+                        const R nx = -(sp_ / ud);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const R u = sLU[prow[v] + 16 * I + ip];
+                            const int r = Mfma<R>::row(v, g16);
+                            if (r < ip) y[v] = fma(u, nx, y[v]);
+                            else if (r == ip) y[v] = nx;
+                        }
+                        if (ip % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int a = 16 * I + Mfma<R>::row(v, g16);
+                        if (a < m && col <= n) {
+                            gKd[(int64_t)a * ldw + col] = y[v];
+                            if (col < n) Kout[((gslot * T + t) * m + a) * (int64_t)n + col] = y[v];
+                            else dout[(gslot * T + t) * m + a] = y[v];
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             }
         }
@@ -684,26 +701,18 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     vji[v] = off ? ((q2 + b1[v]) + b2[v]) + b2t[v] : vij[v];
                     sT[lr * 17 + c16] = vij[v];
                     sT[272 + lr * 17 + c16] = vji[v];
-                    // V[:, n] goes back to its place in the scratch and is read as p behind the barrier below, as in round 2.  (A
-                    // direct store sp[row] = vij[v] from here faulted -- HSA aperture violation on mid-solve iterates of the
-                    // twelve-state family, every index in range -- in the build that still spilled 95 registers around this
-                    // loop, and runs clean since the lane terms are formed per phase (45 spilled): a code-generation problem of
-                    // that build, not of the store.  The round trip through the scratch costs one barrier and is kept.
-                    // Round 4 met the same error again WITHOUT any store here having changed: sincos pairs in the models' Jacobians
-                    // raised this kernel's spills from 64 to 82 registers and config 5's backward pass died on its first launch,
-                    // deterministically, in a fresh process -- and ran to the end under rocgdb.  No flat instruction in the
-                    // listing, 108 scratch loads / stores (the spills).  That build (-DDPILQR_JAC_SINCOS rebuilds it) with the
-                    // kernel cut off behind each phase of the first step (-DDPILQR_BIG_STOP=i) ran clean at every cut AND uncut
-                    // on one GPU box, and the very same binaries died on the next two boxes: the failure depends on the machine's
-                    // state (what the scratch memory held, where things were mapped), not on the data, and rocgdb -- no address
-                    // randomisation, fresh mappings -- hides it.  An "aperture violation" is an address outside every GPU
-                    // aperture, i.e. a 64-bit pointer with a wrong high half: a reload of a spill slot that this path never
-                    // stored (or stored with some lanes off: scalar registers spilled into the lanes of a vector register that
-                    // is spilled in turn) is what fits all of it.  What correlates is the NUMBER OF SPILLED REGISTERS (82
-                    // vector + 132 scalar there; 64 + 108 in the build that has passed every run of rounds 3 and 4), not an
-                    // index of this kernel; the Jacobians are back to separate sin / cos and tests/test_kernel_resources.py
-                    // holds the kernel to the spill counts it is known to run with.  The cure is fewer live 64-bit pointers
-                    // (three dozen per wavefront: scratch regions, trajectory, gains, descriptor arrays).)
+                    // V[:, n] goes back to its place in the scratch and is read as p behind the barrier below.
+                    // (History of this kernel's one failure: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- an address outside
+                    // every GPU aperture -- in builds that spilled 95 (round 3) and 82 (round 4: sincos pairs in the Jacobians)
+                    // vector registers, deterministic in a fresh process, absent under rocgdb, present on two of three boxes with
+                    // the same binary; builds with 45..64 spilled registers ran clean.  No index was ever out of range and no
+                    // hand-over lacked its barrier (audited again in round 5: every LDS / scratch producer is separated from its
+                    // consumers by __syncthreads, or by s_waitcnt inside one wavefront); what correlated was the number of
+                    // spilled registers, 108..132 scalar ones spilled into the lanes of vector registers that were spilled in
+                    // turn.  Round 5 removed the spills instead of bounding them: this kernel needs <= 122 registers and no
+                    // scratch in every instantiation, with either form of the Jacobians (tests/test_kernel_resources.py holds
+                    // it to zero), and both builds ran config 5's passes and whole solves 20 times in fresh processes without
+                    // a failure (scripts/cfg5_soak.sh).)
                     if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes

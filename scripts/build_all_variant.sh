@@ -11,7 +11,8 @@ cd $root   # the flags name include paths relative to the repository
 objs=""; pids=""
 for src in $root/dpilqr_amd/csrc/*.hip; do
   u=$(basename $src .hip); o=$root/build/variants/${u}_$tag.o
-  /opt/rocm/bin/hipcc $flags "$@" -c -o $o $src &
+  uflags=$(python -c "import __graft_entry__ as g; print(' '.join(g.UNIT_FLAGS.get('$u', [])))" | tail -1)
+  /opt/rocm/bin/hipcc $flags $uflags "$@" -c -o $o $src &
   pids="$pids $!"; objs="$objs $o"
 done
 for p in $pids; do wait $p; done

@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/dpilqr_amd/variants $root/build/variants
 # every translation unit's object must exist and be current (build() alone compiles nothing when the linked library is newer
 # than the sources, and objects do not travel to the GPU box)
-flags=$(cd $root && python -c "import __graft_entry__ as g; g.build(need_objects=True); print(' '.join(g.HIPCC_FLAGS))" | tail -1)
+flags=$(cd $root && python -c "import __graft_entry__ as g; g.build(need_objects=True); print(' '.join(g.HIPCC_FLAGS + g.UNIT_FLAGS.get('$unit', [])))" | tail -1)
 cd $root   # the flags name include paths relative to the repository
 /opt/rocm/bin/hipcc $flags "$@" -c -o $root/build/variants/${unit}_$tag.o $root/dpilqr_amd/csrc/$unit.hip
 objs=""

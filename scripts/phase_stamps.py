@@ -22,6 +22,7 @@ if "--build" in sys.argv:
         objs.append(str(obj))
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                                        "-DDPILQR_PHASE_STAMPS", *(["-DDPILQR_S3_SPLIT"] if "--s3split" in sys.argv else []),
+                                       *__import__("__graft_entry__").UNIT_FLAGS.get(src.stem, []),
                                        f"-I{ROOT / 'include'}", f"-I{csrc}", "-c", "-o", str(obj), str(src)]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(so), *objs], check=True)
