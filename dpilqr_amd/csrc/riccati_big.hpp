@@ -526,16 +526,119 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // 128 registers; with S5 the reason the kernel spilled) -- took 301 k of a step's 1.43 M clocks.
         {
             const int nb = mk / 16, ntile = ldw / 16;
+            constexpr int NBR = 5;            // block rows that stay in registers (config 5: n_u = 80 = 5 x 16)
+            // the unit-lower / upper diagonal block solved inside a tile; the factors' entries of the NEXT pivot are requested
+            // before the current pivot's shuffle (the fences keep the scheduler from hoisting all sixty loads: 120 registers)
+            auto solve_lower = [&](int I, acc_t& y) {
+                int prow[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) prow[v] = sPerm[16 * I + Mfma<R>::row(v, g16)] * ldlu + 16 * I;
+#pragma unroll
+                for (int ip = 0; ip < 15; ++ip) {
+                    R lc[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) lc[v] = sLU[prow[v] + ip];
+                    const R yp = lane_bcast(y[Mfma<R>::reg_of(ip)], Mfma<R>::group_of(ip) * 16 + c16);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (Mfma<R>::row(v, g16) > ip) y[v] = fma(-lc[v], yp, y[v]);
+                    if (ip % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto solve_upper = [&](int I, acc_t& y) {        // leaves -x in y
+                int prow[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) prow[v] = sPerm[16 * I + Mfma<R>::row(v, g16)] * ldlu + 16 * I;
+#pragma unroll
+                for (int ip = 15; ip >= 0; --ip) {
+                    R uc[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) uc[v] = sLU[prow[v] + ip];
+                    const R dc = sLU[sPerm[16 * I + ip] * ldlu + 16 * I + ip];
+                    const R s_ = lane_bcast(y[Mfma<R>::reg_of(ip)], Mfma<R>::group_of(ip) * 16 + c16);
+                    const R nx = -(s_ / dc);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = Mfma<R>::row(v, g16);
+                        if (r < ip) y[v] = fma(uc[v], nx, y[v]);
+                        else if (r == ip) y[v] = nx;
+                    }
+                    if (ip % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // (row offsets inside the step's gain block and inside the scratch are 32-bit; g_row is the lane's group index made
+            // opaque per column tile: rows do not depend on the tile, and hoisted out of the tile loop twenty rows' 64-bit
+            // addresses of [K | d], K and the scratch were eighty registers, spilled)
+            R* const Kt = Kout + (gslot * T + t) * (int64_t)m * n;
+            R* const dt_out = dout + (gslot * T + t) * (int64_t)m;
+            auto store_gains = [&](int I, const acc_t& y, int col, int g_row) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int a = 16 * I + Mfma<R>::row(v, g_row);
+                    if (a < m && col <= n) {
+                        gKd[a * ldw + col] = y[v];
+                        if (col < n) Kt[a * n + col] = y[v];
+                        else dt_out[a] = y[v];
+                    }
+                }
+            };
+            if (sizeof(R) == 8 && nb <= NBR) {
+                // fp64, everything of a column tile in registers: the right-hand sides of all block rows are requested at once, a
+                // solved block is the later blocks' matrix-pipe operand as it stands (D's row g + 4 v IS the B operand's row
+                // 4 q + g at q = v), nothing goes through the scratch but the final [K | d].  (fp32's D rows are 4 g + v: the
+                // operand needs a 4 x 4 exchange between the lane groups; with it the float instantiations spilled, and the
+                // tolerance study's arm is not the one to optimise: it takes the read-back form below.)
+                for (int jt = wave; jt < ntile; jt += kBigThreads / 64) {
+                    const int col = 16 * jt + c16;
+                    int g_row = g16;
+                    asm volatile("" : "+v"(g_row));
+                    acc_t y[NBR];
+                    auto operand = [&](int J, int q) -> R { return y[J][q]; };
+#pragma unroll
+                    for (int I = 0; I < NBR; ++I) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int r = 16 * I + Mfma<R>::row(v, g16);
+                            y[I][v] = (I < nb && r < m) ? gG[(int64_t)sPerm[min(r, mk - 1)] * ldw + col] : (R)0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int I = 0; I < NBR; ++I) {              // L y = P b
+                        if (I < nb) {
+                            const int arow = sPerm[16 * I + c16] * ldlu;
+#pragma unroll
+                            for (int J = 0; J < I; ++J)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) y[I] = Mfma<R>::mac(-sLU[arow + 16 * J + 4 * q + g16], operand(J, q), y[I]);
+                            solve_lower(I, y[I]);
+                        }
+                    }
+#pragma unroll
+                    for (int I = NBR - 1; I >= 0; --I) {         // U x = y ; [K | d] = -x  (the solved blocks hold -x: the updates add U (-x))
+                        if (I < nb) {
+                            const int arow = sPerm[16 * I + c16] * ldlu;
+#pragma unroll
+                            for (int J = NBR - 1; J > I; --J)
+                                if (J < nb) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) y[I] = Mfma<R>::mac(sLU[arow + 16 * J + 4 * q + g16], operand(J, q), y[I]);
+                                }
+                            solve_upper(I, y[I]);
+                            store_gains(I, y[I], col, g_row);
+                        }
+                    }
+                }
+            } else {
+            // more than NBR block rows (n_u > 80): the solved blocks are read back from the scratch in the operand order (for fp64 a
+            // lane reads exactly the four entries it stored itself)
             for (int jt = wave; jt < ntile; jt += kBigThreads / 64) {
                 const int col = 16 * jt + c16;
                 for (int I = 0; I < nb; ++I) {                   // L y = P b
-                    int prow[4];
                     acc_t y;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int r = 16 * I + Mfma<R>::row(v, g16), pr = sPerm[r];
-                        prow[v] = pr * ldlu;
-                        y[v] = (r < m) ? gG[(int64_t)pr * ldw + col] : (R)0.0;
+                        const int r = 16 * I + Mfma<R>::row(v, g16);
+                        y[v] = (r < m) ? gG[(int64_t)sPerm[r] * ldw + col] : (R)0.0;
                     }
                     const int arow = sPerm[16 * I + c16] * ldlu;
                     for (int J = 0; J < I; ++J) {
@@ -546,32 +649,15 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                             y = Mfma<R>::mac(a, b, y);
                         }
                     }
-                    // the unit-lower diagonal block: pivot rows 0 .. 14 in turn
-#pragma unroll
-                    for (int ip = 0; ip < 15; ++ip) {
-                        const int vp = Mfma<R>::reg_of(ip), gp = Mfma<R>::group_of(ip);
-                        const R yp = lane_bcast(y[vp], gp * 16 + c16);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const R l = sLU[prow[v] + 16 * I + ip];
-                            if (Mfma<R>::row(v, g16) > ip) y[v] = fma(-l, yp, y[v]);
-                        }
-                        // (without the fence the scheduler hoists all sixty factor loads of the block to its top: 120 registers)
-                        if (ip % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-                    }
+                    solve_lower(I, y);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col] = y[v];
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block is read back (by this wavefront only) as an operand
                 }
                 for (int I = nb - 1; I >= 0; --I) {              // U x = y ; [K | d] = -x  (the scratch holds -x: the updates add U (-x))
-                    int prow[4];
                     acc_t y;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int r = 16 * I + Mfma<R>::row(v, g16);
-                        prow[v] = sPerm[r] * ldlu;
-                        y[v] = gKd[(int64_t)r * ldw + col];
-                    }
+                    for (int v = 0; v < 4; ++v) y[v] = gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col];
                     const int arow = sPerm[16 * I + c16] * ldlu;
                     for (int J = nb - 1; J > I; --J) {
 #pragma unroll
@@ -581,32 +667,14 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                             y = Mfma<R>::mac(a, b, y);
                         }
                     }
+                    solve_upper(I, y);
+                    // (columns beyond n are padding: their entries must still reach the scratch, the later blocks read them back)
 #pragma unroll
-                    for (int ip = 15; ip >= 0; --ip) {
-                        const int vp = Mfma<R>::reg_of(ip), gp = Mfma<R>::group_of(ip);
-                        const R sp_ = lane_bcast(y[vp], gp * 16 + c16);
-                        const R ud = sLU[sPerm[16 * I + ip] * ldlu + 16 * I + ip];
-                        const R nx = -(sp_ / ud);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const R u = sLU[prow[v] + 16 * I + ip];
-                            const int r = Mfma<R>::row(v, g16);
-                            if (r < ip) y[v] = fma(u, nx, y[v]);
-                            else if (r == ip) y[v] = nx;
-                        }
-                        if (ip % 2 == 0) __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int a = 16 * I + Mfma<R>::row(v, g16);
-                        if (a < m && col <= n) {
-                            gKd[(int64_t)a * ldw + col] = y[v];
-                            if (col < n) Kout[((gslot * T + t) * m + a) * (int64_t)n + col] = y[v];
-                            else dout[(gslot * T + t) * m + a] = y[v];
-                        }
-                    }
+                    for (int v = 0; v < 4; ++v) gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col] = y[v];
+                    store_gains(I, y, col, g16);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+            }
             }
         }
         }
