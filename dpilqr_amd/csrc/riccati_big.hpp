@@ -92,7 +92,7 @@ struct BigScratch {
 };
 
 struct BigLds {   // offsets in elements of R (all even)
-    int AB, QQ, RR, E, U, G3, H, p, LU, inv, perm, ldlu, total;
+    int AB, QQ, RR, E, U, G3, H, HS, GS, p, LU, inv, perm, ldlu, total;
     __host__ __device__ BigLds(int k, int ns, int nc) {
         const int n = k * ns, m = k * nc, np = k * (k - 1) / 2, mk = big_round_up(m, 16);
         auto ev = [](int x) { return (x + 1) & ~1; };
@@ -104,6 +104,8 @@ struct BigLds {   // offsets in elements of R (all even)
         U = o;   o += ev(m);
         G3 = o;  o += ev(np * 3);               // pair gradients
         H = o;   o += ev(np * 9);               // pair Hessians
+        HS = o;  o += ev(k * 9);                // ... summed per agent over its pairs (the diagonal blocks of L_xx), in the loop's order
+        GS = o;  o += ev(k * 3);                // pair gradients summed per agent, signs as in cost.py:160-163
         p = o;   o += ev(n);
         ldlu = mk + 2;
         {   // also the Jacobians' scratch between steps and the tile-transposition buffer of S5 (16 wavefronts x 2 x 16 x 17)
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R* lds = reinterpret_cast<R*>(lds_raw);
     R* sAB = lds + O.AB; R* sQQ = lds + O.QQ; R* sRR = lds + O.RR; R* sE = lds + O.E; R* sU = lds + O.U;
-    R* sG3 = lds + O.G3; R* sH = lds + O.H; R* sp = lds + O.p; R* sLU = lds + O.LU; R* sInv = lds + O.inv;
+    R* sG3 = lds + O.G3; R* sH = lds + O.H; R* sHS = lds + O.HS; R* sGS = lds + O.GS; R* sp = lds + O.p; R* sLU = lds + O.LU; R* sInv = lds + O.inv;
     int* sPerm = reinterpret_cast<int*>(lds + O.perm);
     int* sPiv = sPerm + mk;
     int* sFlag = sPiv + mk;      // [0]: singular, [1]: pivot row of the current column
@@ -208,8 +210,29 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #pragma unroll
             for (int c = 0; c < 9; ++c) sH[p * 9 + c] = HH[c];
         }
+        __syncthreads();
+        // per agent: the sum of its pairs' Hessians / signed gradients, in the order the per-element loops took them (o ascending
+        // from 0.0): what the diagonal blocks of L_xx and l_x add -- once per step instead of once per element
+        for (int e = tid; e < k * 12; e += kBigThreads) {
+            const int a = e / 12, c = e - a * 12;
+            R acc = 0.0;
+            if (c < 9) {
+                for (int o = 0; o < k; ++o) {
+                    if (o == a) continue;
+                    acc += sH[((o < a) ? pair_index(o, a, k) : pair_index(a, o, k)) * 9 + c];
+                }
+                sHS[a * 9 + c] = acc;
+            } else {
+                const int lj = c - 9;
+                for (int o = 0; o < k; ++o) {
+                    if (o == a) continue;
+                    if (o < a) acc += -sG3[pair_index(o, a, k) * 3 + lj];
+                    else       acc += sG3[pair_index(a, o, k) * 3 + lj];
+                }
+                sGS[a * 3 + lj] = acc;
+            }
+        }
         if (!terminal) {
-            __syncthreads();
             for (int e = tid; e < k * NS * NSC; e += kBigThreads) {
                 const int a = e / (NS * NSC), q = e - a * NS * NSC, l = q / NSC, i = q - l * NSC;
                 sAB[e] = (i < NS) ? sJ[a * NS * NSC + l * NS + i] : sJ[a * NS * NSC + NS * NS + l * NC + (i - NS)];
@@ -236,11 +259,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (k > 1 && li < 3 && lj < 3) {
             R acc = 0.0;
             if (ai == aj) {
-                for (int o = 0; o < k; ++o) {
-                    if (o == ai) continue;
-                    const int p = (o < ai) ? pair_index(o, ai, k) : pair_index(ai, o, k);
-                    acc += sH[p * 9 + li * 3 + lj];
-                }
+                acc = sHS[ai * 9 + li * 3 + lj];
             } else {
                 const int p = (ai < aj) ? pair_index(ai, aj, k) : pair_index(aj, ai, k);
                 acc += -sH[p * 9 + li * 3 + lj];
@@ -254,13 +273,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #pragma unroll
         for (int i = 0; i < NS; ++i) v += sE[a * NS + i] * sQQ[a * NS * NS + i * NS + lj];
         if (k > 1 && lj < 3) {
-            R acc = 0.0;
-            for (int o = 0; o < k; ++o) {
-                if (o == a) continue;
-                if (o < a) acc += -sG3[pair_index(o, a, k) * 3 + lj];
-                else       acc += sG3[pair_index(a, o, k) * 3 + lj];
-            }
-            v += wp * acc;
+            v += wp * sGS[a * 3 + lj];
         }
         return v;
     };
@@ -307,6 +320,87 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).  (An MFMA formulation -- two
         // 16x16x4 products per block pair with T transposed through LDS -- was built and measured SLOWER, 500 k against 250 k
         // cycles per step: fifty dependent load -> MFMA -> LDS -> MFMA -> store chains per wavefront hide no latency.)
+        if constexpr (sizeof(R) == 8 && NS == 12 && NC == 4) {
+            // Twelve-state agents in fp64 (config 5), round 5: [A_ai | B_ai] is 12 x 16 -- a block pair's two products are one
+            // 16 x 16 matrix-pipe tile each, three reduction steps of four.  First  T^T[j][i] = sum_l P[12 ai + l][12 aj + j]
+            // [A|B]_ai[l][i]: the A operand is P's block straight from the scratch -- lane (g, c) loads P[12 ai + 4 q + g][12 aj + c],
+            // THREE coalesced loads per lane and block pair where the vector form below has every lane walk the whole 12 x 12
+            // block (144 loads; the phase was bound by them: 358 k of a step's 1.19 M clocks) -- the B operand [A|B]_ai from LDS.
+            // The accumulator's layout (lane (g, c): rows g + 4 v of column c) IS the second product's A operand layout
+            // (reduction rows 4 q + g at q = v), so T never leaves the registers: out[i][c'] = sum_j T[i][j] [A|B]_aj[j][c'].
+            // Rows j >= 12 of T^T (accumulator register 3) come from columns 12 aj + 12 .. 15 of P -- the next block's, or the
+            // zero padding -- and are never read: the second product's reduction stops at 12.  The association is the
+            // reference's ((A^T P) A); the matrix pipe sums each group of four products in its own order, so the entries agree
+            // with the vector form to rounding, not bit for bit.  The next block pair's three loads are requested before the
+            // current pair's products.
+            const int njobs = k * k;
+            auto p_loads = [&](int job, R (&dst)[3]) {
+                const int ai = job / k, aj = job - ai * k;
+                const R* src = gP + (ai * NS + g16) * ldw + aj * NS + c16;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[q] = src[4 * q * ldw];
+            };
+            auto do_job = [&](int job, const R (&pc)[3]) {
+                const int ai = job / k, aj = job - ai * k;
+                const R* abi = sAB + (ai * NS + g16) * NSC + c16;
+                const R* abj = sAB + (aj * NS + g16) * NSC + c16;
+                acc_t t1 = acc_t{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) t1 = Mfma<R>::mac(pc[q], abi[4 * q * NSC], t1);
+                if (ai == aj && c16 >= NS) {   // B^T (P + mu I) = B^T P + mu B^T   (quirk Q6): rows i >= 12 of T, i.e. columns of T^T
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) t1[v] = fma(mu, sAB[(ai * NS + g16 + 4 * v) * NSC + c16], t1[v]);
+                }
+                acc_t o = acc_t{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) o = Mfma<R>::mac(t1[q], abj[4 * q * NSC], o);
+                // every lane stores its four entries with ONE global store each, whatever they are (an entry of Q_xx, of Q_ux, of
+                // Q_uu, or -- rows < 12 of the control columns: A^T P B, which the transposed pair supplies as Q_ux -- nothing: a
+                // padding column of V that nobody reads): a fixed number of memory operations per pair is what lets the
+                // compiler wait for the operand loads alone (vmcnt counts loads and stores in issue order)
+                R* const gS = gP - S.oP;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = g16 + 4 * v;          // row of the 16 x 16 block: 0..11 state rows of agent ai, 12..15 its controls
+                    R val;
+                    int off;
+                    if (i < NS) {                        // (compile-time per v but for v = 3, where i = 12 + g16)
+                        const bool in = c16 < NS;
+                        val = lxx(ai, i, aj, in ? c16 : 0) + o[v];
+                        off = (int)S.oV + (ai * NS + i) * ldw + (in ? aj * NS + c16 : ldw - 1);
+                    } else {
+                        const int a = ai * NC + (i - NS), cc = c16 - NS;
+                        const R qv = ((ai == aj && cc >= 0) ? sRR[ai * NC * NC + (i - NS) * NC + max(cc, 0)] : (R)0.0) + o[v];
+                        val = (cc < 0) ? o[v] : qv;       // Q_ux (l_ux = 0, cost.py:93,231) or Q_uu
+                        off = (cc < 0) ? (int)S.oG + a * ldw + aj * NS + c16 : (int)S.oQuu + a * mk + aj * NC + cc;
+                        if (cc >= 0) sLU[a * ldlu + aj * NC + cc] = qv;
+                    }
+                    gS[off] = val;
+                }
+            };
+            // two operand sets, used in turn: the next pair's loads are in flight while the current pair's products run (with one set
+            // and a copy at the loop's end the compiler waits for the loads it has just issued: vmcnt counts in order)
+            constexpr int WS = kBigThreads / 64;
+            R pa[3] = {(R)0.0, (R)0.0, (R)0.0}, pb[3] = {(R)0.0, (R)0.0, (R)0.0};
+            int job = wave;
+            if (job < njobs) {
+                p_loads(job, pa);
+                // four stores to V's padding column: the loop's first pass then meets the state every later pass meets -- the
+                // awaited loads, four stores, three loads -- and the compiler's wait for the loads (it takes the weaker of the two
+                // entry states) no longer includes the previous pair's stores
+                R* const gS = gP - S.oP;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gS[(int)S.oV + (g16 + 4 * v) * ldw + ldw - 1] = (R)0.0;
+            }
+            while (job < njobs) {
+                p_loads(min(job + WS, njobs - 1), pb);          // (unconditional -- past the end: the last pair's again -- so that the
+                do_job(job, pa);                                //  number of operations behind the awaited loads is known)
+                if (job + WS >= njobs) break;
+                p_loads(min(job + 2 * WS, njobs - 1), pa);
+                do_job(job + WS, pb);
+                job += 2 * WS;
+            }
+        } else {
         for (int w = tid; w < k * k * NSC; w += kBigThreads) {
             const int blk = w / NSC, r = w - blk * NSC, ai = blk / k, aj = blk - ai * k;
             R Tr[NS];
@@ -352,6 +446,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     sLU[a * ldlu + aj * NC + c] = q;
                 }
             }
+        }
         }
         // Q_x = l_x + A^T p -> column n of V ; Q_u = l_u + B^T p -> column n of [Q_ux | Q_u]
         for (int i = tid; i < n + m; i += kBigThreads) {
@@ -750,12 +845,29 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     a1 = Mfma<R>::mac(t3i, kdj, a1);
                     a2 = Mfma<R>::mac(kdi, gj, a2);
                     a2t = Mfma<R>::mac(gi, kdj, a2t);
-                    if (off) {          // tile (jt, it): the same products with i and j exchanged
-                        b1 = Mfma<R>::mac(t3j, kdi, b1);
-                        b2 = Mfma<R>::mac(kdj, gi, b2);
-                        b2t = Mfma<R>::mac(gj, kdi, b2t);
-                    }
+                    if (off) b1 = Mfma<R>::mac(t3j, kdi, b1);     // tile (jt, it): only T3_j^T [K|d]_i is a product of its own (below)
                     t3i = n_t3i; kdi = n_kdi; gi = n_gi; t3j = n_t3j; kdj = n_kdj; gj = n_gj;
+                }
+                // Tile (jt, it)'s other two products are the TRANSPOSES of this tile's: [K|d]_j^T G_i = (G_i^T [K|d]_j)^T = a2t^T and
+                // G_j^T [K|d]_i = ([K|d]_i^T G_j)^T = a2^T -- the same products summed over the same reduction index in the same
+                // order, so the same bits (round 5: they were computed a second time, six matrix-pipe instructions per pair and
+                // reduction step where four do; at 64 cycles each the phase is bound by exactly that pipe).  The two tiles go
+                // through the wavefront's LDS tiles once more, ahead of V's own transposition.
+                if (off) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int lr = Mfma<R>::row(v, g16);
+                        sT[lr * 17 + c16] = a2[v];
+                        sT[272 + lr * 17 + c16] = a2t[v];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int lr = Mfma<R>::row(v, g16);
+                        b2t[v] = sT[c16 * 17 + lr];            // a2^T
+                        b2[v] = sT[272 + c16 * 17 + lr];       // a2t^T
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // before the tiles are overwritten with V below
                 }
                 R vij[4], vji[4];
 #pragma unroll
