@@ -485,7 +485,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // permutation is double-buffered: a column's eliminations read perm_kk while perm_kk+1 is being written (both exchanges
         // that separate the two buffers are applied by the one lane that decides them).  (Measured and dropped: panels of eight
         // columns factorised by one wavefront, 40 instead of 160 barriers -- 290 k: the per-column chain through LDS, not
-        // the barriers, sets the pace.)
+        // the barriers, sets the pace.  Round 5: a BLOCKED right-looking LU -- sixteen-column panels factorised by one wavefront
+        // entirely in registers (lane = row, wave-wide arg-max, pivot row through v_readlane, the exchange two position
+        // numbers changing owners), U_12 one thread per column, the trailing block one thread per row and four columns, 15
+        // barriers instead of 80, factors / pivots / permutation bit for bit those of this form (fp64 and fp32) -- measured
+        // SLOWER, 217 k against 172 k: a panel column is ~370 instructions of one wavefront that has its SIMD to itself.  Dropped.)
         int* sPermB = sPiv;                               // the second permutation buffer (sPiv is otherwise unused)
         for (int r = tid; r < mk; r += kBigThreads) sPermB[r] = r;
         if (wave == 0) {                                  // column 0's pivot, before the loop
