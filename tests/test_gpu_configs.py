@@ -85,7 +85,7 @@ def test_cfg3_fifteen_unicycles_T100_solve_distributed(dp):
     n_items, n_flipped, n_tight, worst = _envelope_over_buckets(info["audit"], 3, 2, Q, R, Qf, T)
     print(f"cfg3 first call: {n_items} sub-problem solves, {n_flipped} with a decision that is not the oracle's own (explained), "
           f"{n_tight} with a reference ensemble tighter than 1e-6, worst err/bound {worst:.3f}")
-    assert n_items == info["n_unique"] and n_tight >= max(3, n_items // 8)      # the strict leg (1e-5 on every tight item, inside the helper) is not vacuous
+    assert n_items == info["n_unique"] and 2 * n_tight >= n_items      # the strict leg (1e-5 on every tight item, inside the helper) is not vacuous
     # the reference's entry point, one scenario at a time: the same stitched trajectories, bit for bit
     for j in range(S):
         pj, _ = build(dp, dp.UnicycleDynamics4D, k, x0[j], xf[j])
