@@ -11,7 +11,7 @@ decision against the reference members that share its prefix so far ("alive"); e
     inconclusive  fewer than MIN_UNANIMOUS alive members, unanimous: too few samples to call the decision determined
     exhausted     no member shares the prefix any more: the fixture has nothing to say (the oracle-replay envelope does)
 Unanimity of n samples bounds the probability of another decision only by about 3 / n, so a lone violation among hundreds
-of decisions is within what a faithful implementation shows (the C oracle: 1 of 641); the tests bound the RATE."""
+of decisions is within what a faithful implementation shows (the C oracle: 1 of 687); the tests bound the RATE."""
 import numpy as np
 
 MIN_UNANIMOUS = 8
