@@ -15,8 +15,9 @@ collective, an RCCL all-gather of the converged (X, U, J, status, n_bwd, n_fwd) 
 on a side stream while the rest of the job still solves (dpilqr_amd/sharding.py ResultBuffers; buffers pre-allocated
 and the collective warmed on them outside the clock).
 
-The timed K-step job is REPEATED --reps times (default 5) on disjoint seeds inside one invocation; `value` and
-`ms_per_step` are the MEDIAN repetition (max over ranks each), the spread is reported beside them (`repetitions`).
+The timed K-step job is REPEATED on disjoint seeds inside one invocation -- --reps times if given, otherwise five times and on
+until the repetitions add up to --min-seconds (2 s) of timed work, at most --max-reps (48) -- and `value` / `ms_per_step` are the
+MEDIAN repetition (max over ranks each); the spread is reported beside them (`repetitions`).
 
     python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -225,7 +226,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step job (disjoint seeds); the median is reported")
+    ap.add_argument("--reps", type=int, default=None, help="repetitions of the timed K-step job (disjoint seeds); the median is reported.  "
+                    "Given: exactly that many.  Not given: five, and more while --min-seconds is not reached")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="keep repeating the timed job (beyond --reps, on further disjoint seeds, at "
+                    "most --max-reps times) until the repetitions add up to this much timed work: a 20-step job is 25 ms, and five of "
+                    "them are neither a stable median nor visible to a once-per-second utilisation sampler")
+    ap.add_argument("--max-reps", type=int, default=48)
     ap.add_argument("--batch", type=int, default=1024, help="sub-problems per GPU per step (cfg2: 1024)")
     ap.add_argument("--window", type=int, default=6144, help="sub-problems in flight per GPU (a multiple of 3072 = three sweep wavefronts per SIMD)")
     ap.add_argument("--gather-chunk", type=int, default=2048, help="N > 1: items per chunk of the overlapped all-gather")
@@ -273,7 +279,8 @@ def main():
     from dpilqr_amd.sharding import ResultBuffers
     _lib.require_gpu()
 
-    B, reps = args.batch, max(1, args.reps)
+    B, reps = args.batch, max(1, args.reps if args.reps is not None else 5)
+    max_reps = max(reps, args.max_reps) if (args.reps is None and args.min_seconds > 0) else reps
     Q, R, Qf = np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4)
 
     def make_job(n_steps, seed0, host=False):
@@ -286,10 +293,13 @@ def main():
         U0 = torch.zeros((n_steps * B, T, N_U), dtype=torch.float64, device="cuda")
         return dict(pb=pb, x0=x0, U0=U0, x0_h=x0.cpu().numpy() if host else None, xf_h=xf.cpu().numpy() if host else None)
 
-    seeds_per_rank = (reps * args.steps + args.warmup) * B
+    seeds_per_rank = (max_reps * args.steps + args.warmup) * B
     seed_base = rank * seeds_per_rank                                    # weak scaling: every rank its own seeds
-    jobs = [make_job(args.steps, seed_base + r * args.steps * B, host=(r == 0 and rank == 0)) for r in range(reps)]
-    warm = make_job(args.warmup, seed_base + reps * args.steps * B) if args.warmup > 0 else None
+    # repetition r's job is generated just before it runs, outside the clock (only repetition 0's stays: the parity and roofline
+    # legs look at it)
+    job_of = lambda r: make_job(args.steps, seed_base + r * args.steps * B, host=(r == 0 and rank == 0))
+    jobs = [job_of(0)]
+    warm = make_job(args.warmup, seed_base + max_reps * args.steps * B) if args.warmup > 0 else None
     # N > 1: the results' home and the gathered results of all ranks, allocated once for the job's shape
     rb = (ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank))
           if (world > 1 or args.gather_path) else None)
@@ -318,10 +328,12 @@ def main():
     times = []
     own_times = []                      # this rank's own clock around the same region (per-rank values of the JSON line)
     r0 = None
-    for rep in range(reps):
+    rep = 0
+    while True:
+        job = jobs[0] if rep == 0 else job_of(rep)
         fence()
         t0 = time.perf_counter()
-        r = run(jobs[rep], rb)
+        r = run(job, rb)
         fence()
         own_times.append(time.perf_counter() - t0)
         dt = torch.tensor([own_times[-1]], dtype=torch.float64, device="cuda")
@@ -335,6 +347,13 @@ def main():
                 assert torch.equal(g["X"][rank], r["X"]) and torch.equal(g["J"][rank], r["J"]), "all-gather returned another block"
                 assert bool(((g["status"] >= 1) & (g["status"] <= 3)).all()), "a rank's gathered results are not finished solves"
         del r
+        if rep > 0:
+            del job
+        rep += 1
+        # `times` holds the MAX over ranks: every rank takes the same decision
+        if rep >= max_reps or (rep >= reps and sum(times) >= args.min_seconds):
+            break
+    reps = rep
     prof = _lib.profile_read(reset=True)
     sweep_variants = {w: _lib.profile_read_sweep(w, reset=True) for w in (12, 8, 4)}
     _lib.profile_enable(False)
