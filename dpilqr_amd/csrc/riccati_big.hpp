@@ -153,7 +153,14 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     int* sFlag = sPiv + mk;      // [0]: singular, [1]: pivot row of the current column
 
     R* gP = scratch_all + (int64_t)slot * S.total + S.oP;
-    R* gV = scratch_all + (int64_t)slot * S.total + S.oV;
+    // Twelve-state fp64 clusters: V shares P's array.  Their S1 rewrites a block pair's 12 x 12 block in the wavefront that read it
+    // (all of it, into registers, before its first store) and S5 a tile pair likewise, so V = Q_xx .. never needs a place of its
+    // own -- and a third less scratch is touched per item (0.94 instead of 1.43 MB: 256 items then fit the 256 MB Infinity Cache).
+    // Column n of the shared array is Q_x after S1 and the new p after S5; P itself never uses it.  The other forms of S1
+    // (work items of several wavefronts read one block) keep V apart.
+    constexpr bool kAliasPV = (sizeof(R) == 8 && NS == 12 && NC == 4);
+    const int64_t oVa = kAliasPV ? S.oP : S.oV;
+    R* gV = scratch_all + (int64_t)slot * S.total + oVa;
     R* gG = scratch_all + (int64_t)slot * S.total + S.oG;
     R* gKd = scratch_all + (int64_t)slot * S.total + S.oKd;
     R* gT3 = scratch_all + (int64_t)slot * S.total + S.oT3;
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     if (i < NS) {                        // (compile-time per v but for v = 3, where i = 12 + g16)
                         const bool in = c16 < NS;
                         val = lxx(ai, i, aj, in ? c16 : 0) + o[v];
-                        off = (int)S.oV + (ai * NS + i) * ldw + (in ? aj * NS + c16 : ldw - 1);
+                        off = (int)oVa + (ai * NS + i) * ldw + (in ? aj * NS + c16 : ldw - 1);
                     } else {
                         const int a = ai * NC + (i - NS), cc = c16 - NS;
                         const R qv = ((ai == aj && cc >= 0) ? sRR[ai * NC * NC + (i - NS) * NC + max(cc, 0)] : (R)0.0) + o[v];
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 // entry states) no longer includes the previous pair's stores
                 R* const gS = gP - S.oP;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) gS[(int)S.oV + (g16 + 4 * v) * ldw + ldw - 1] = (R)0.0;
+                for (int v = 0; v < 4; ++v) gS[(int)oVa + (g16 + 4 * v) * ldw + ldw - 1] = (R)0.0;
             }
             while (job < njobs) {
                 p_loads(min(job + WS, njobs - 1), pb);          // (unconditional -- past the end: the last pair's again -- so that the
@@ -676,8 +683,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     const int a = 16 * I + Mfma<R>::row(v, g_row);
                     if (a < m && col <= n) {
                         gKd[a * ldw + col] = y[v];
-                        if (col < n) Kt[a * n + col] = y[v];
-                        else dt_out[a] = y[v];
+                        // (the gains stream out -- 23 MB per item and pass at n_x = 240 -- and must not push the scratch out of the caches)
+                        if (col < n) __builtin_nontemporal_store(y[v], Kt + a * n + col);
+                        else __builtin_nontemporal_store(y[v], dt_out + a);
                     }
                 }
             };
