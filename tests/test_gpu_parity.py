@@ -753,6 +753,40 @@ def test_fused_workgroup_sweep_is_bit_identical_to_the_record_fed_sweep(dp, fami
     assert torch.equal(K0, K1) and torch.equal(d0, d1), (float((K0 - K1).abs().max()), float((d0 - d1).abs().max()))
 
 
+def test_fused_workgroup_sweep_with_non_finite_iterates(dp):
+    """The four-state family's structured S1 / S2 in the fused workgroup sweep drops the 0 * x terms of the general chain, so a
+    non-finite P spreads differently there (0 * Inf = NaN in the general form only).  What must hold: a poisoned item (an
+    overflowing or NaN state somewhere in its trajectory) has non-finite gains on BOTH routes -- neither hands back
+    finite-looking gains -- and the items beside it are untouched, bit for bit."""
+    import torch
+    from dpilqr_amd.device import to_dev
+    k, B, T = 9, 96, 12
+    rng = np.random.default_rng(77)
+    n, m = 4 * k, 2 * k
+    models = [(0 if a % 3 == 0 else 3) for a in range(k)]
+    x0 = rng.normal(size=(B, n)) * 0.5; xf = rng.normal(size=(B, n)); U0 = rng.normal(size=(B, T, m)) * 0.3
+    Q, R, Qf = np.diag([1.0, 1, 0.1, 0.1]), np.eye(2), 30.0 * np.eye(4)
+    pb = dp.ProblemBatch(models, [2] * k, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, _ = pb.rollout(x0, U0)
+    X = X.clone()
+    bad = [3, 40, 95]              # (item 41's 1e200 overflows nothing: it stays among the items that must agree bit for bit)
+    X[3, 5, 0] = float("inf"); X[40, T, 7] = float("nan"); X[41, 6, 2] = 1e200; X[95, 8, 17] = -float("inf")
+    mu = to_dev(np.full(B, 0.125))
+    K0, d0 = pb.backward_pass(X, U0, mu)
+    K1, d1 = pb.backward_pass_fused(X, U0, mu)
+    good = torch.tensor([i for i in range(B) if i not in bad], device=K0.device)
+    assert torch.equal(K0[good], K1[good]) and torch.equal(d0[good], d1[good]) and bool(torch.isfinite(K0[good]).all())
+    for i in bad:      # (an infinite POSITION leaves K finite -- it enters l_x only -- and shows in d)
+        fin0 = bool(torch.isfinite(K0[i]).all()) and bool(torch.isfinite(d0[i]).all())
+        fin1 = bool(torch.isfinite(K1[i]).all()) and bool(torch.isfinite(d1[i]).all())
+        assert not fin0 and not fin1, (i, fin0, fin1)
+    # ... and a whole solve from such a start ends, with the same status as its neighbours' kind of failure would: no hang, no crash
+    x0b = x0.copy(); x0b[0, 0] = 1e200
+    r = pb.solve(x0b, U0, n_lqr_iter=5)
+    st = r["status"].cpu().numpy()
+    assert st[0] in (2, 3, 4) and (st[1:] != 0).all()
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
 def test_sweep_three_state_family(dp, k):
     """CarDynamics3D (3 states / 2 controls): even agent counts take the workgroup-per-item sweep, odd ones the size-generic
