@@ -163,3 +163,33 @@ def test_descriptor_hints_of_a_batch():
     Q6 = np.broadcast_to(np.eye(6), (2, 6, 6)); R3 = np.broadcast_to(np.eye(3), (2, 3, 3))
     w = ProblemBatch.hint_word([4, 1], [3, 2], Q6, R3, Q6)                # six-state agents, mixed n_dims
     assert w & 0xff == 0 and (w >> 8) & 0xff == 0 and (w >> 17) & 1 == 0
+
+
+def test_solve_kwargs_names_what_it_drops():
+    """Keyword arguments of the batched solve: n_lqr_iter, tol, t_kill pass (and `verbose` is the reference's print switch);
+    anything else is named in a warning instead of being dropped silently (round-4 review: solve_rhc_scenarios filtered its
+    kwargs to two names without a word, t_kill among the casualties)."""
+    import warnings
+    from dpilqr_amd.dispatch import solve_kwargs
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert solve_kwargs(dict(n_lqr_iter=3, tol=1e-4, t_kill=0.1, verbose=False)) == dict(n_lqr_iter=3, tol=1e-4, t_kill=0.1)
+    with pytest.warns(UserWarning, match="n_iter"):
+        assert solve_kwargs(dict(n_iter=3, tol=1e-4), "here") == dict(tol=1e-4)
+
+
+def test_monte_carlo_trial_inputs_follow_the_references_stream():
+    """dpilqr_amd/analysis.py: a trial consumes NumPy's global stream in the order scripts/analysis.py:45-54 and
+    distributed.py:152 do -- random_setup, then the centralized branch's warm start, then the distributed branch's -- seeded per
+    (model, team size, trial), distinct seeds for distinct cells."""
+    from dpilqr_amd import analysis
+    x0, xf, Uc, Ud = analysis.trial_inputs(4, 4, 8, 10, 10.0, 2, seed=12345)
+    np.random.seed(12345)
+    a, b = dp.random_setup(4, 4, is_rotation=False, rel_dist=4, var=2.0, n_d=2, random=True, energy=10.0)
+    c = np.random.rand(10, 8) * 0.01; d = np.random.rand(10, 8) * 0.01
+    assert np.array_equal(x0, a) and np.array_equal(xf, b) and np.array_equal(Uc, c) and np.array_equal(Ud, d)
+    seeds = {analysis.seed_of(m, k, i) for m in analysis.MODELS for k in (3, 4, 5, 6, 7) for i in range(64)}
+    assert len(seeds) == 3 * 5 * 64
+    Q, R, Qf = analysis.weights_of(analysis.MODELS[2], 6)
+    assert Q[0, 0] == 50.0 and R.shape == (3, 3) and Qf[5, 5] == 1000.0          # analysis.py:62-69
+    assert analysis.HEADER.split(",")[:4] == ["dynamics", "n_agents", "trial", "centralized"]
