@@ -80,6 +80,9 @@ x0, xf = scenarios(0, B)
 pb = dp.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), 0.5, 0.1, T)
 r = pb.solve(x0, np.zeros((B, T, N_U)), n_lqr_iter=2)       # an operating point where agents interact
 X, U = r["X"], r["U"]
+import os
+if os.environ.get("RADIUS"):   # the same iterates, another proximity radius for the timed pass (1e-9: no pair is ever near)
+    pb = dp.ProblemBatch([0] * K_AGENTS, [2] * K_AGENTS, xf, np.diag([1.0, 1, 0, 0]), np.eye(2), 1000.0 * np.eye(4), float(os.environ["RADIUS"]), 0.1, T)
 mu = to_dev(np.full(B, 0.125)); K = empty((B, T, N_U, N_X)); d = empty((B, T, N_U)); tl = pb.make_tiles(X, U)
 lib = _lib.load()
 buf = torch.zeros((B * 12,), dtype=torch.int64, device="cuda")
