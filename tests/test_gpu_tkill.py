@@ -181,3 +181,33 @@ def test_rhc_scenarios_pass_t_kill_and_warn_on_unknown_kwargs(dp, golden):
     assert any(not np.array_equal(b[s][0], c[s][0]) for s in range(S))       # ...and it did reach the solves
     with pytest.warns(UserWarning, match="n_iter_lqr"):
         dp.solve_rhc_scenarios(prob, x0[:1], N, 0.5, n_iter_lqr=3, **dict(kw, U0=U0[:1]))
+
+
+@pytest.mark.parametrize("case", ["fp32", "big", "wg"])
+def test_every_solve_path_reads_the_clock(dp, case):
+    """The decision lives in two places -- linesearch_decide (the wavefront / team line searches) and k_forward's own copy (the
+    generic kernel: the fp32 arm, clusters beyond n_x = 60) -- and every sweep family feeds them: a limit below one tick is one
+    iteration per item on each."""
+    import torch
+    from dpilqr_amd.util import random_setup
+    model, k, T, dtype = {"fp32": (0, 3, 20, torch.float32), "big": (3, 16, 12, torch.float64), "wg": (4, 6, 20, torch.float64)}[case]
+    ns, nc = (6, 3) if model == 4 else (4, 2)
+    nd = 3 if ns == 6 else 2
+    B = 24
+    x0 = np.zeros((B, k * ns)); xf = np.zeros((B, k * ns))
+    for s in range(B):
+        np.random.seed(700 + s)
+        a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0)
+        x0[s], xf[s] = a.ravel(), b.ravel()
+    Q, R = (50.0 * np.eye(6), np.eye(3)) if ns == 6 else (np.diag([1.0, 1, 0, 0]), np.eye(2))
+    U0 = np.zeros((B, T, k * nc))
+    if model == 4:
+        U0[:, :, 0::3] = 9.80665
+    pb = dp.ProblemBatch([model] * k, [nd] * k, xf, Q, R, 1000.0 * np.eye(ns), 0.5, 0.1, T)
+    r = host(pb.solve(x0, U0, t_kill=1e-12, dtype=dtype))
+    one = host(pb.solve(x0, U0, n_lqr_iter=1, dtype=dtype))
+    assert (r["n_bwd"] == 1).all() and set(np.unique(r["status"])) <= {KILLED, CONVERGED, LS_FAILED}
+    assert (r["status"] == KILLED).sum() >= B // 2
+    assert np.array_equal(r["X"], one["X"]) and np.array_equal(r["J"], one["J"])
+    free = host(pb.solve(x0, U0, dtype=dtype))
+    assert (free["n_bwd"] >= r["n_bwd"]).all() and (free["n_bwd"] > 1).any()
