@@ -235,16 +235,27 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
             t[s] += step_size * dt
         still = keep_going(ia) & ~diverged
         active = active[still]
-    out = []
+    # the executed trajectories, and J_full = the cost of rolling the executed controls out from x0 (distributed.py:208): one
+    # batched rollout per executed length instead of one launch per scenario
+    XU = []
     for s in range(S):
         if X_parts[s]:
-            Xf = torch.cat(X_parts[s]).cpu().numpy(); Uf = torch.cat(U_parts[s]).cpu().numpy()
+            XU.append((torch.cat(X_parts[s]).cpu().numpy(), torch.cat(U_parts[s]).cpu().numpy()))
         else:
-            Xf = x0[s].copy(); Uf = np.zeros((1, n_u))
-        pbs = ProblemBatch(d["model"], d["n_dims"], xf_h[s:s + 1], d["Q"], d["R"], d["Qf"], d["radius"], dt, Uf.shape[0],
-                           w_ref=d["w_ref"], w_prox=d["w_prox"], B=1)
-        _, Jf = pbs.rollout(x0[s:s + 1], Uf[None])
-        out.append((Xf, Uf, float(Jf.cpu().numpy()[0]), bool(converged[s])))
+            XU.append((x0[s].copy(), np.zeros((1, n_u))))
+    J_full = np.zeros(S)
+    by_len = {}
+    for s in range(S):
+        by_len.setdefault(XU[s][1].shape[0], []).append(s)
+    for L_exec, idx in by_len.items():
+        pbl = ProblemBatch(d["model"], d["n_dims"], xf_h[idx], d["Q"], d["R"], d["Qf"], d["radius"], dt, L_exec,
+                           w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(idx))
+        _, Jl = pbl.rollout(x0[idx], np.stack([XU[s][1] for s in idx]))
+        J_full[idx] = Jl.cpu().numpy()
+    out = []
+    for s in range(S):
+        Xf, Uf = XU[s]
+        out.append((Xf, Uf, float(J_full[s]), bool(converged[s])))
         if want_rows:
             row_log[s].append(rhc_log_row(model_name, k, trial_of[s], centralized, True, Uf.shape[0] * dt, out[-1][2], N, dt,
                                           bool(converged[s]), ids, *last_fields[s]))
