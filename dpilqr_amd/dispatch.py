@@ -81,6 +81,19 @@ def solve_problem_list(problems, x0s, U0s, keys=None, window=None, **kwargs):
     return out
 
 
+def device_constants(d, kc=None):
+    """The per-agent constants of a described problem (lowering.describe) as device tensors, for its first kc agents (all of
+    them by default), and their descriptor hints -- made once per description and kept in it: the receding-horizon loop builds a
+    batch per round and per cluster size, and six small uploads per batch were a tenth of the Monte-Carlo study's time."""
+    kc = d["k"] if kc is None else int(kc)
+    cache = d.setdefault("_dev", {})
+    if kc not in cache:
+        cache[kc] = dict(model=to_dev(d["model"][:kc], torch.int32), n_dims=to_dev(d["n_dims"][:kc], torch.int32),
+                         Q=to_dev(d["Q"][:kc]), R=to_dev(d["R"][:kc]), Qf=to_dev(d["Qf"][:kc]),
+                         word=ProblemBatch.hint_word(d["model"][:kc], d["n_dims"][:kc], d["Q"][:kc], d["R"][:kc], d["Qf"][:kc]))
+    return cache[kc]
+
+
 def pairwise_graph(X, radius, k, n_s):
     """define_inter_graph_threshold (distributed.py:224-247) for S scenarios on the device.
     X: (S, N, k*n_s) sampled trajectories (N may be 1); returns adjacency (S, k, k) int32 incl. self loops."""
@@ -144,10 +157,9 @@ class ScenarioFrontEnd:
                                                    ptr(self.bits), ptr(self.X), ptr(self.U), ptr(self.xf), k * ns, ptr(x0),
                                                    ptr(xfb), ptr(U0), ptr(members), stream_handle()))
         if self.uniform_agents:
-            word = ProblemBatch.hint_word(d["model"][:kc], d["n_dims"][:kc], d["Q"][:kc], d["R"][:kc], d["Qf"][:kc])
-            pb = ProblemBatch(to_dev(d["model"][:kc], torch.int32), to_dev(d["n_dims"][:kc], torch.int32), xfb, to_dev(d["Q"][:kc]),
-                              to_dev(d["R"][:kc]), to_dev(d["Qf"][:kc]), d["radius"], d["dt"], T, w_ref=d["w_ref"],
-                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, word))
+            c = device_constants(d, kc)
+            pb = ProblemBatch(c["model"], c["n_dims"], xfb, c["Q"], c["R"], c["Qf"], d["radius"], d["dt"], T, w_ref=d["w_ref"],
+                              w_prox=d["w_prox"], B=cnt, hints=(kc, ns, nc, c["word"]))
         else:
             g = {}
             for key, width, eb, dt_ in (("model", 1, 4, torch.int32), ("n_dims", 1, 4, torch.int32), ("Q", ns * ns, 8, torch.float64),
@@ -211,7 +223,7 @@ class ScenarioFrontEnd:
 
 
 def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, concurrent=True, ignore_ids=None, device_out=False,
-                                shard=None, audit=False, **kwargs):
+                                shard=None, audit=False, desc=None, **kwargs):
     """solve_distributed (distributed.py:25-103) for S scenarios of ONE k-agent problem at once -- the Monte-Carlo
     front end (scripts/analysis.py:126-174 runs it seed by seed).  Everything between the trajectories and the stitched
     result stays on the device: graph, de-duplication, size buckets, gathered sub-problem inputs (ScenarioFrontEnd), one
@@ -228,7 +240,7 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
     device tensors with device_out=True; with `shard` the unstitched (front end, solved slices) pair instead.
     """
     from .sharding import shard_bounds
-    d = describe(problem)
+    d = desc if desc is not None else describe(problem)      # desc: the caller's description (its device constants are reused)
     k = d["k"]
     ignore = None
     if ignore_ids:
@@ -294,7 +306,8 @@ def solve_scenarios_distributed(problem, X, U, radius, xf=None, window=None, con
 
 def full_rollout_cost(d, fe, U_dec):
     """J_full of every scenario: _rollout(X[0], U_dec) on the full k-agent problem (distributed.py:100-101)."""
-    full = ProblemBatch(d["model"], d["n_dims"], fe.xf, d["Q"], d["R"], d["Qf"], d["radius"], d["dt"], fe.T,
-                        w_ref=d["w_ref"], w_prox=d["w_prox"], B=fe.S)
+    c = device_constants(d)
+    full = ProblemBatch(c["model"], c["n_dims"], fe.xf, c["Q"], c["R"], c["Qf"], d["radius"], d["dt"], fe.T,
+                        w_ref=d["w_ref"], w_prox=d["w_prox"], B=fe.S, hints=(d["k"], fe.n_s, fe.n_c, c["word"]))
     _, J = full.rollout(fe.X[:, 0].contiguous(), U_dec)
     return J

@@ -150,7 +150,7 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
     import torch
     from .batch import ProblemBatch
     from .device import to_dev
-    from .dispatch import solve_scenarios_distributed
+    from .dispatch import device_constants, solve_scenarios_distributed
     from .lowering import describe
     if (J_converge is None) == (dist_converge is None):
         raise ValueError("Must either specify a convergence cost or distance")
@@ -194,14 +194,15 @@ def solve_rhc_scenarios(problem, x0, N, radius, xf=None, U0=None, centralized=Fa
         t_round = pc()
         bits = None
         if centralized:
-            pb = ProblemBatch(d["model"], d["n_dims"], xf_d[ia], d["Q"], d["R"], d["Qf"], d["radius"], dt, N,
-                              w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(active))
+            c = device_constants(d)
+            pb = ProblemBatch(c["model"], c["n_dims"], xf_d[ia], c["Q"], c["R"], c["Qf"], d["radius"], dt, N,
+                              w_ref=d["w_ref"], w_prox=d["w_prox"], B=len(active), hints=(k, n_s, n_u // k, c["word"]))
             r = pb.solve(xi[ia], U[ia], window=window, **solve_kw)
             Xa, Ua, Ja = r["X"], r["U"], r["J"]
         else:
             Xin = xi[ia][:, None, :] if X is None else X[ia]
             Xa, Ua, Ja, info = solve_scenarios_distributed(problem, Xin, U[ia], radius, xf=xf_d[ia], window=window, device_out=True,
-                                                           **solve_kw)
+                                                           desc=d, **solve_kw)
             bits = info["cluster_bits"]
         if X is None:
             X = torch.zeros((S, N + 1, n_x), dtype=torch.float64, device=xi.device)
