@@ -613,7 +613,11 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
 #pragma unroll
             for (int c = 0; c < 9; ++c) sFh[p * 9 + c] = H[c];
         }
-        wg_barrier();
+    };
+    // ... and the per-agent sums of what the pair lanes left in LDS (behind a barrier after fused_derive).  Round 5: in the horizon
+    // loop they are formed at the top of the S1 phase -- S1's products need neither, and the one consumer inside S1, l_x in the
+    // p column's Q_x, moved into the S2 phase -- so the barrier that used to separate them from S1 is gone
+    auto fused_sums = [&]() {
         if (KA > 1) {
             // per agent: the sums over its pairs, in combinations order (a serial chain of adds, as in the producer; the
             // loads are all issued first).  The lane's pair addresses and signs are formed HERE from a thread id the
@@ -666,6 +670,8 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         fused_put_xu(true);
         wg_barrier();
         fused_derive(true);
+        wg_barrier();
+        fused_sums();
         wg_barrier();
         for (int e = tid; e < N * N; e += kWgThreads) {
             const int i = e / N, j = e - i * N;
@@ -786,6 +792,7 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
         WPHASE(0)
 
         __builtin_amdgcn_s_setprio(1);   // vector-pipe phases win arbitration over another workgroup's MFMA phases
+        if constexpr (FUSED) fused_sums();
         // ---- S1: [A|B]^T [P|p], block diagonal.  T1 replaces P in place (this work item is the only reader and the only
         // writer of its agent's rows of its two columns); T2 goes where S2 will turn it into Q_ux
 #pragma unroll
@@ -852,28 +859,17 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
 #pragma unroll
                     for (int i = 0; i < NC; ++i) st_row<2, true>(sG + (NC * ag + i) * LG + MO + j0, acc + 2 * (NS + i));
                 } else {   // p column: Q_x = l_x + A^T p ; Q_u = l_u + B^T p
-                    if constexpr (FUSED) {   // l_x = w_ref e^T (Q + Q^T) + w_prox sum_pairs(+-g) ; l_u = w_ref u^T (R + R^T)
+                    if constexpr (FUSED) {   // A^T p, B^T p now; l_x, l_u are added in the S2 phase (the sums they need are being formed)
 #pragma unroll
-                        for (int lj = 0; lj < NS; ++lj) {
-                            double v = 0.0;
+                        for (int i = 0; i < NS; ++i) sP[(NS * ag + i) * LP + N] = acc[2 * i];
 #pragma unroll
-                            for (int i = 0; i < NS; ++i) v += sFe[ag * NS + i] * sQQ[(ag * NS + i) * NS + lj];
-                            v = wr * v;
-                            if (KA > 1 && lj < 3) v += wp * sFs[ag * 3 + lj];
-                            nX[r][lj] = v;
-                        }
-#pragma unroll
-                        for (int lj = 0; lj < NC; ++lj) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int i = 0; i < NC; ++i) v += sFu[ag * NC + i] * sRR[(ag * NC + i) * NC + lj];
-                            nX[r][NS + lj] = wr * v;
-                        }
-                    }
+                        for (int i = 0; i < NC; ++i) sG[(NC * ag + i) * LG + MO + N] = acc[2 * (NS + i)];
+                    } else {
 #pragma unroll
                     for (int i = 0; i < NS; ++i) sP[(NS * ag + i) * LP + N] = nX[r][i] + acc[2 * i];
 #pragma unroll
                     for (int i = 0; i < NC; ++i) sG[(NC * ag + i) * LG + MO + N] = nX[r][NS + i] + acc[2 * (NS + i)];
+                    }
                 }
             }
         }
@@ -998,6 +994,27 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                 }
             }
         }
+        }
+        if constexpr (FUSED) {
+            // Q_x = l_x + A^T p, Q_u = l_u + B^T p: the l-part, one entry per lane (S2's work items never touch column n).
+            // l_x = w_ref e^T (Q + Q^T) + w_prox sum_pairs(+-g) ; l_u = w_ref u^T (R + R^T) -- the expressions and orders S1 had
+            int tid_q = tid;
+            asm volatile("" : "+v"(tid_q));
+            if (tid_q < N) {
+                const int ag = tid_q / NS, lj = tid_q - ag * NS;
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) v += sFe[ag * NS + i] * sQQ[(ag * NS + i) * NS + lj];
+                v = wr * v;
+                if (KA > 1 && lj < 3) v += wp * sFs[ag * 3 + lj];
+                sP[tid_q * LP + N] = v + sP[tid_q * LP + N];
+            } else if (tid_q < N + M) {
+                const int a = tid_q - N, ag = a / NC, lj = a - ag * NC;
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) v += sFu[ag * NC + i] * sRR[(ag * NC + i) * NC + lj];
+                sG[a * LG + MO + N] = wr * v + sG[a * LG + MO + N];
+            }
         }
         // [K | d]'s reduction-padding rows must read as zero (the previous step's a2 may have reached them)
         for (int e = tid; e < (C::KROWS - M) * LK; e += kWgThreads) sK[M * LK + e] = 0.0;
