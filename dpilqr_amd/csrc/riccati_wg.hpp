@@ -752,6 +752,36 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
     constexpr int RW = 64 - M;
     constexpr int K_PAIRS = M * N / 2, K_ROUNDS = (K_PAIRS + kWgThreads - 1) / kWgThreads;
 
+    // FUSED: where this lane's S2 work items find their l-values, once.  Row ip of agent ag's column block takes w_ref (Q + Q^T) or
+    // w_ref (R + R^T) if the row is the agent's own, and -+ w_prox H of a pair (or + the agent's sum of them) on the position
+    // entries.  Bits 0-9: the weights' row (doubles from sQQ), 10-21: the Hessian row (doubles from [K|d]), 24: own state row,
+    // 25: own control row, 26: position row of a team, 27: own.  (Formed per step from the thread id -- two divisions, a pair
+    // index and a dozen exec-mask regions per row -- this was more than half of the fused S2 phase's 1 375 instructions.)
+    unsigned lvd[FUSED ? C::R2R : 1][C::RPL];
+    if constexpr (FUSED) {
+        static_assert(!FUSED || (C::szW < 1024 && M * C::LK < 4096), "the packed l-value descriptor's fields");
+#pragma unroll
+        for (int r = 0; r < C::R2R; ++r) {
+            const int w = min(tid + kWgThreads * r, C::NI2 - 1);
+            const int ag = w / C::RG, rg = w - ag * C::RG;
+#pragma unroll
+            for (int q = 0; q < C::RPL; ++q) {
+                const int ip = min(C::RPL * rg + q, NM - 1);
+                const bool xrow = ip < N;
+                const int ai = xrow ? ip / NS : (ip - N) / NC, li = xrow ? ip - ai * NS : (ip - N) - ai * NC;
+                const bool own = ai == ag;
+                const int woff = xrow ? (ag * NS + li) * NS : KA * NS * NS + (ag * NC + li) * NC;
+                const int pidx = own ? 0 : ((ai < ag) ? pair_index(ai, ag, KA) : pair_index(ag, ai, KA));
+                const bool prox = KA > 1 && xrow && li < 3;
+                const int hoff = prox ? (own ? C::oFd + ag * 9 : C::oFh + pidx * 9) + li * 3 : 0;
+                unsigned dsc = (unsigned)woff | ((unsigned)hoff << 10) | ((xrow && own) ? 1u << 24 : 0u) | ((!xrow && own) ? 1u << 25 : 0u) |
+                               (prox ? 1u << 26 : 0u) | (own ? 1u << 27 : 0u);
+                asm volatile("" : "+v"(dsc));
+                lvd[r][q] = dsc;
+            }
+        }
+    }
+
     if constexpr (!FUSED) prefetch_ab(T - 1);
     wg_barrier();
 
@@ -916,36 +946,28 @@ __global__ __launch_bounds__(kWgThreads, (WgCfg<N, M, NS, NC, FUSED>::OCC)) void
                 // L_uu = w_ref blockdiag(R + R^T) -- its rows, its agent's column block
 #pragma unroll
                 for (int q = 0; q < C::RPL; ++q) {
-                    const int ip = ip2[r][q];
-                    const bool xrow = ip < N;
-                    const int ai = xrow ? ip / NS : (ip - N) / NC, li = xrow ? ip - ai * NS : (ip - N) - ai * NC;
-                    const bool own = ai == ag;
-                    // the weights' row (Q + Q^T for a state row, R + R^T for a control row) and the Hessian row that goes with it
-                    const double* wrow = xrow ? sQQ + (ag * NS + li) * NS : sRR + (ag * NC + li) * NC;
-                    const int pidx = own ? 0 : ((ai < ag) ? pair_index(ai, ag, KA) : pair_index(ag, ai, KA));
-                    const double* hrow = (own ? sFd + ag * 9 : sFh + pidx * 9) + min(li, 2) * 3;
-                    const bool prox = KA > 1 && xrow && li < 3;
+                    const unsigned dsc = lvd[r][q];
+                    const double* wrow = sQQ + (dsc & 1023u);
+                    const double* hrow = sK + ((dsc >> 10) & 4095u);
+                    const bool own_x = (dsc & (1u << 24)) != 0, own_u = (dsc & (1u << 25)) != 0, prox = (dsc & (1u << 26)) != 0,
+                               own = (dsc & (1u << 27)) != 0;
                     double w[NS], h[3];
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) w[c] = wrow[min(c, xrow ? NS - 1 : NC - 1)];
+                    for (int c = 0; c < NS; ++c) w[c] = wrow[c];     // (a control row's NC entries and what follows them: inside LDS)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) h[c] = hrow[c];
 #pragma unroll
-                    for (int c = 0; c < NSC; ++c) nL[r][q][c] = 0.0;
-#pragma unroll
                     for (int lj = 0; lj < NS; ++lj) {
-                        double v = 0.0;
-                        if (xrow && own) v = wr * w[lj];
-                        if (lj < 3 && prox) {
-                            double pa = 0.0;
-                            if (own) pa = h[lj]; else pa += -h[lj];
-                            v += wp * pa;
+                        double v = own_x ? wr * w[lj] : 0.0;
+                        if (lj < 3) {
+                            const double pa = own ? h[lj] : -h[lj];
+                            const double vp = v + wp * pa;
+                            v = prox ? vp : v;
                         }
-                        if (xrow) nL[r][q][lj] = v;
+                        nL[r][q][lj] = v;
                     }
 #pragma unroll
-                    for (int lj = 0; lj < NC; ++lj)
-                        if (!xrow && own) nL[r][q][NS + lj] = wr * w[lj];
+                    for (int lj = 0; lj < NC; ++lj) nL[r][q][NS + lj] = own_u ? wr * w[lj] : 0.0;
                 }
             }
             if constexpr (STRUCT4) {   // see S1: columns 0, 1 of T A are T's, 2 and 3 two free terms plus T's own, T B = T_2 b20, T_3 b31
