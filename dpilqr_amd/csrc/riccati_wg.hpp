@@ -244,6 +244,9 @@ __device__ __attribute__((noinline)) int lu_fallback_wg(const double* __restrict
 // profiles/r03_gj_threshold_tails.txt), so 8 stays.  With the swaps, on 2048 real iterates (profiles/r04_gj_row_swaps.txt): the
 // record-fed sweep 8.39 -> 7.51 ms (ten quadcopters, T = 75) and 11.27 -> 9.73 ms (fifteen unicycles, T = 100), the fused one
 // 9.04 -> 8.73 and 12.27 -> 11.53.  (DPILQR_GJ_THRESHOLD, DPILQR_GJ_NO_SWAP: A/B builds.)
+// Round 5, the same audit with the swaps in place per threshold 1 (dgetf2's rule) .. 64 (profiles/r05_gj_threshold_tails.txt): the tails at
+// the sizes this elimination serves do not depend on the threshold any more (the largest, 3.52 spreads, under true partial pivoting): they
+// are the solves' chaos, not element growth.  Threshold 1 costs 7 % of a sweep, 2 3 %, 4 1 %; 64 gains 0.5 %.
 // Q_uu = R + B^T (P + mu I) B is symmetric with a heavy diagonal; it is NOT always positive definite away from a minimum (half
 // of the steps of a fresh 15-unicycle iterate have a negative pivot), which is why the rule looks at magnitudes.  Only a pivot
 // that is zero or not finite after the search (a singular or poisoned Q_uu) makes the caller run the register LU with
