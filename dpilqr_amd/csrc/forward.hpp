@@ -19,15 +19,30 @@
 
 namespace dpilqr {
 
+constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step (per chunk, kdirect): ceil(n_u*n_x / threads) must not exceed this
+
 struct ForwardLds {   // offsets in elements of the arithmetic type
     int Kt, dt, dx, xs, cref, cpair, J, ctl, total;
-    // kdirect: K[t] is read from global memory row by row instead of being staged (large clusters: K[t] alone is
-    // 154 KB at n_x = 240, n_u = 80)
+    int cw, rs;   // kdirect: columns of K[t] per chunk, elements per chunk column (>= m)
+    // kdirect: K[t] goes through LDS in CHUNKS of cw columns (large clusters: K[t] alone is 154 KB at n_x = 240, n_u = 80), two
+    // chunk buffers used in turn, a chunk stored column by column with row a NC + c of a column at c k + a (the lanes of a candidate --
+    // its agents -- read consecutive words, the candidates the same ones: with an agent's NC rows contiguous the reads were 5-way
+    // bank conflicts).  Round 5; before, every thread walked its rows in global memory, two columns in flight: 160 k of a step's
+    // 265 k clocks at cfg5's size (now 68 k, bound by the LDS return path: every entry of K[t] is read once per candidate).
     __host__ __device__ ForwardLds(int n, int m, int k, int ngrp, bool kdirect = false) {
         const int npairs = k * (k - 1) / 2;
         int o = 0;
+        cw = 0; rs = 0;
+        if (kdirect) {
+            const int nth = ((k * ngrp + 63) / 64) * 64;                  // the launch's threads (tu_bigfwd.hip)
+            int c = 2048 / m;                                             // two buffers of <= 2048 elements
+            if (c > kMaxStage * nth / m) c = kMaxStage * nth / m;         // ... which the threads stage kMaxStage elements each
+            if (c > n) c = n;
+            cw = c < 1 ? 1 : c;
+            rs = ((m + 14) / 16) * 16 + 1;   // >= m and = 1 mod 16: the staging lanes' consecutive columns fall into consecutive banks
+        }
         // everything staged per time step is double-buffered by the parity of t: one barrier per step
-        Kt = o;    o += kdirect ? 0 : 2 * m * n;
+        Kt = o;    o += kdirect ? 2 * (cw * rs + 2) : 2 * m * n;   // (kdirect: + the store target of idle elements)
         dt = o;    o += 2 * m;
         dx = o;    o += 2 * ngrp * n;
         xs = o;    o += 2 * ngrp * n;
@@ -50,7 +65,22 @@ __device__ __forceinline__ void lds_handoff(bool single_wave) {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step: ceil(n_u*n_x / threads) must not exceed this
+// p[0] + p[1] + ... + p[count - 1] added in that order (the reference's stage-cost sums), the loads eight at a time: one thread
+// per candidate walks 190 pair costs at cfg5's size, and a load -> add -> load chain is an LDS round trip per term
+template <typename R>
+__device__ __forceinline__ R sum_in_order(const R* p, int count) {
+    R s = 0.0;
+    int i = 0;
+    for (; i + 8 <= count; i += 8) {
+        R v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; i < count; ++i) s += p[i];
+    return s;
+}
 
 // One pass over the horizon for the calling thread's (candidate g, agent a).
 //   GAINS : u = U + (K dx + alpha d) (control.py:104-107) ; else u = U (control.py:89)
@@ -72,13 +102,36 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
     const int mn = m * n;
     const R dtr = (R)D.dt, radius = (R)P.radius, w_prox = (R)D.w_prox, w_ref = (R)D.w_ref;
 
-    R x[NS], xold[NS], u[NC], stK[KDIRECT ? 1 : kMaxStage], std_ = 0.0;
+    R x[NS], xold[NS], u[NC], stK[kMaxStage], std_ = 0.0;
     const int model = active ? P.model[a] : 0;
     const double* xf = P.xf + a * NS;
     const double* Qa = P.Q + a * NS * NS;
     const double* Ra = P.R + a * NC * NC;
     const double* Qfa = P.Qf + a * NS * NS;
 
+    // KDIRECT: K[t] in chunks of O.cw columns.  Element e = tid + q nth of a chunk is (row e / cw, column e % cw): consecutive threads
+    // read consecutive columns of a row (coalesced) and store column by column (ForwardLds)
+    const int n_chunks = KDIRECT ? (n + O.cw - 1) / O.cw : 0;
+    int ck_src[KDIRECT ? kMaxStage : 1], ck_dst[KDIRECT ? kMaxStage : 1];
+    if constexpr (KDIRECT && GAINS) {
+#pragma unroll
+        for (int q = 0; q < kMaxStage; ++q) {
+            const int e = tid + q * nth;
+            const int row = e / O.cw, jj = e - row * O.cw;
+            ck_src[q] = (e < m * O.cw) ? row * n + jj : -1;
+            ck_dst[q] = jj * O.rs + (row % NC) * k + row / NC;
+        }
+    }
+    auto fetch_chunk = [&](int t, int ch) {  // registers <- HBM for chunk ch of K[t]
+        if constexpr (KDIRECT && GAINS) {
+            const R* Kt = Kb + (int64_t)t * mn + ch * O.cw;
+            const int left = n - ch * O.cw;   // columns of the matrix from this chunk's first on
+            // (no load behind a test: an element outside the chunk -- e >= m cw, or column jj = dst / rs >= left in the last chunk --
+            // reads the chunk's first entry instead; behind per-lane tests the compiler drained the load queue before every load)
+#pragma unroll
+            for (int q = 0; q < kMaxStage; ++q) stK[q] = Kt[(ck_src[q] >= 0 && ck_dst[q] < left * O.rs) ? ck_src[q] : 0];
+        }
+    };
     auto fetch = [&](int t) {  // registers <- HBM for step t
         if (GAINS) {
             if constexpr (!KDIRECT) {
@@ -110,6 +163,8 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
         }
     }
     fetch(0);
+    fetch_chunk(0, 0);
+    int ck_buf = 0;   // KDIRECT: the chunk buffer the next chunk goes into
     R J = 0.0;
 
     for (int t = 0; t < T; ++t) {
@@ -140,22 +195,65 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
         }
         if (t + 1 < T) fetch(t + 1);
         lds_handoff(single_wave);
+        R ksum[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ksum[c] = 0.0;
+        if constexpr (KDIRECT && GAINS) {
+            // K[t] dx, chunk by chunk: this chunk from the registers into its buffer, the next one requested (the first of step t + 1
+            // behind the last of step t), one barrier, the chunk's columns added in ascending order.  The buffer written in one
+            // round was last read two rounds earlier, and every thread has passed the barrier in between.
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                R* sKc = lds + O.Kt + ck_buf * (O.cw * O.rs + 2);
+                const int left = n - ch * O.cw, cwa = left < O.cw ? left : O.cw;
+#pragma unroll
+                for (int q = 0; q < kMaxStage; ++q)
+                    sKc[(ck_src[q] >= 0 && ck_dst[q] < left * O.rs) ? ck_dst[q] : O.cw * O.rs + (tid & 1)] = stK[q];   // (else: the pad behind the buffer)
+                if (ch + 1 < n_chunks) fetch_chunk(t, ch + 1);
+                else if (t + 1 < T) fetch_chunk(t + 1, 0);
+                lds_handoff(single_wave);
+                if (active) {
+                    const R* colp = sKc + a;
+                    const R* dxp = sdx + ch * O.cw;
+                    // eight columns' operands requested before the first is used (one wavefront per SIMD: nothing else hides an
+                    // LDS round trip), then added in ascending order
+                    int jj = 0;
+                    for (; jj + 8 <= cwa; jj += 8) {
+                        R kv[8][NC], dxv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            dxv[q] = dxp[jj + q];
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) kv[q][c] = colp[(jj + q) * O.rs + c * k];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) ksum[c] += kv[q][c] * dxv[q];
+                    }
+                    for (; jj < cwa; ++jj) {
+                        const R dxj = dxp[jj];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) ksum[c] += colp[jj * O.rs + c * k] * dxj;
+                    }
+                }
+                ck_buf ^= 1;
+            }
+        }
         if (active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), summed in the reference's order
             const R* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
             const R* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
-            R prox = 0.0, ref = 0.0;
-            for (int p = 0; p < npairs; ++p) prox += cp[p];
-            for (int i = 0; i < k; ++i) ref += cr[i];
+            const R prox = sum_in_order(cp, npairs), ref = sum_in_order(cr, k);
             J += w_prox * prox + w_ref * ref;
         }
         if (active) {
             if (GAINS) {  // du = K[t] dx + alpha d[t] (control.py:106), this agent's NC rows, j ascending
                 R sum[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) sum[c] = 0.0;
-                // the agent's NC rows of K[t]: staged in LDS, or (large clusters) straight from global memory
-                const R* rows = KDIRECT ? Kb + (int64_t)t * mn + (int64_t)(a * NC) * n : sKt + (a * NC) * n;
-                if ((n & 1) == 0) {
+                for (int c = 0; c < NC; ++c) sum[c] = KDIRECT ? ksum[c] : (R)0.0;   // (KDIRECT: summed chunk by chunk above, j ascending)
+                // the agent's NC rows of K[t], staged in LDS
+                const R* rows = sKt + (a * NC) * n;
+                if constexpr (KDIRECT) {
+                } else if ((n & 1) == 0) {
                     typedef R v2r __attribute__((ext_vector_type(2)));
 #pragma unroll 2
                     for (int j = 0; j < n; j += 2) {
@@ -181,10 +279,15 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 }
             }
             lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, ut, xf, Qa, Ra, false);
-            for (int o = a + 1; o < k; ++o) {
-                const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
-                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
-                    pair_cost(sxs + a * NS, sxs + o * NS, nd, radius);
+            // the candidate's pairs dealt evenly: agent a takes (a, a + 1), ..., (a, a + k / 2) mod k -- at most k / 2 each instead of
+            // k - 1 for agent 0 -- each computed as (lower, higher) and put where the sum in combinations order finds it
+            for (int dd = 1; 2 * dd <= k; ++dd) {
+                if (2 * dd == k && a >= dd) break;
+                const int o = a + dd < k ? a + dd : a + dd - k;
+                const int lo = a < o ? a : o, hi = a < o ? o : a;
+                const int nd = homog ? 2 : min(P.n_dims[lo], P.n_dims[hi]);
+                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(lo, hi, k)] =
+                    pair_cost(sxs + lo * NS, sxs + hi * NS, nd, radius);
             }
             if (Uw) {
 #pragma unroll
@@ -213,28 +316,29 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
             if (a == 0 && T > 0) {
                 const R* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
                 const R* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
-                R prox = 0.0, ref = 0.0;
-                for (int p = 0; p < npairs; ++p) prox += cp[p];
-                for (int i = 0; i < k; ++i) ref += cr[i];
+                const R prox = sum_in_order(cp, npairs), ref = sum_in_order(cr, k);
                 J += w_prox * prox + w_ref * ref;
             }
             R uz[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) uz[c] = 0.0;
             lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, uz, xf, Qfa, Ra, true);
-            for (int o = a + 1; o < k; ++o) {
-                const int nd = homog ? 2 : min(P.n_dims[a], P.n_dims[o]);
-                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(a, o, k)] =
-                    pair_cost(sxs + a * NS, sxs + o * NS, nd, radius);
+            // the candidate's pairs dealt evenly: agent a takes (a, a + 1), ..., (a, a + k / 2) mod k -- at most k / 2 each instead of
+            // k - 1 for agent 0 -- each computed as (lower, higher) and put where the sum in combinations order finds it
+            for (int dd = 1; 2 * dd <= k; ++dd) {
+                if (2 * dd == k && a >= dd) break;
+                const int o = a + dd < k ? a + dd : a + dd - k;
+                const int lo = a < o ? a : o, hi = a < o ? o : a;
+                const int nd = homog ? 2 : min(P.n_dims[lo], P.n_dims[hi]);
+                lds[O.cpair + (par * ngrp + g) * np1 + pair_index(lo, hi, k)] =
+                    pair_cost(sxs + lo * NS, sxs + hi * NS, nd, radius);
             }
         }
         lds_handoff(single_wave);
         if (active && a == 0) {
             const R* cr = lds + O.cref + (par * ngrp + g) * k;
             const R* cp = lds + O.cpair + (par * ngrp + g) * np1;
-            R prox = 0.0, ref = 0.0;
-            for (int p = 0; p < npairs; ++p) prox += cp[p];
-            for (int i = 0; i < k; ++i) ref += cr[i];
+            const R prox = sum_in_order(cp, npairs), ref = sum_in_order(cr, k);
             J += w_prox * prox + w_ref * ref;
         }
     }
