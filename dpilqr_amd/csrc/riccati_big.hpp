@@ -75,7 +75,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_
 // rows (m rounded up to the 16-row blocks of the substitution); padding is zeroed once by the host and never written.
 struct BigScratch {
     int n, m, n1, ldw, mk;
-    int64_t oP, oV, oG, oKd, oT3, oQuu, total;
+    int64_t oP, oV, oG, oKd, oT3, oQuu, oSync, total;
     __host__ __device__ BigScratch(int n_, int m_) : n(n_), m(m_) {
         n1 = n + 1;
         ldw = big_round_up(n1, 16);
@@ -87,6 +87,7 @@ struct BigScratch {
         oKd = o;  o += (int64_t)mk * ldw;
         oT3 = o;  o += (int64_t)mk * ldw;
         oQuu = o; o += (int64_t)mk * mk;
+        oSync = (o + 3) & ~(int64_t)3; o = oSync + 32;   // the team's four words (k_riccati_big, nparts > 1), 16-byte aligned in either type
         total = (o + 31) & ~(int64_t)31;
     }
 };
@@ -118,6 +119,43 @@ struct BigLds {   // offsets in elements of R (all even)
     }
 };
 
+// ---- a TEAM of workgroups per item (few items: BASELINE config 5 is ONE problem) -------------------------------------------
+// With fewer items than CUs the item's workgroup has the chip to itself and S5 + S6 -- 42 % of a step, bound by ONE CU's matrix
+// pipes -- is the first thing more CUs can take: `nparts - 1` helper workgroups per item run their share of the tile pairs, whose
+// operands and results all live in the item's global scratch.  Per step two hand-overs through words in that scratch: the main
+// workgroup publishes "K, T3^T, Q ready" (a release store of the step's sequence number), every part adds itself to a counter
+// when its tiles of P are stored (release), the main workgroup goes on when the counter says all have (acquire).  Agent scope:
+// the parts may sit on different XCDs, whose L2s are not coherent without it.
+// No hang by construction: helpers REPORT (a counter) when they start; the main workgroup decides at its first S5 whether all of
+// them have (mode 1: team) or not (mode 2: alone, exactly the single-workgroup pass -- helpers that arrive later leave at once), so
+// a chip busy with other work costs the speed-up, not the result; and every wait is bounded (a fault aborts the launch).
+struct BigTeam { int flag_k, done, joined, mode; };     // one per item, zeroed by the launcher
+constexpr int kBigSpinMax = 1 << 22;
+
+__device__ __forceinline__ int big_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire.  false: gave up
+__device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok) {
+    if (threadIdx.x == 0) {
+        int it = 0, ok = 1;
+        while (big_ld(p) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++it > kBigSpinMax) { ok = 0; break; }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    (void)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    return *s_ok != 0;
+}
+
+template <typename R>
+__global__ void k_big_team_reset(R* scratch_all, int64_t stride, int64_t o_sync, int n_slots) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)s * stride + o_sync);
+    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0;
+}
+
 template <typename R, int NS, int NC>
 __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D, const R* __restrict__ X,
                                                              const R* __restrict__ U, const double* __restrict__ mu_arr,
@@ -125,10 +163,16 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                                                              int32_t* __restrict__ singular,
                                                              const int32_t* __restrict__ items,
                                                              const int32_t* __restrict__ n_items, int gains_by_item,
-                                                             R* scratch_all) {
+                                                             R* scratch_all, int n_slots, int nparts) {
     typedef typename Mfma<R>::acc_t acc_t;
     constexpr int NSC = NS + NC;
-    const int slot = blockIdx.x;
+    // nparts > 1: workgroup x + 8 y is part y % nparts of slot x + 8 (y / nparts) -- workgroups are dealt to the eight XCDs in turn,
+    // so an item's parts share an L2 (a placement the hand-overs do not rely on)
+    const int wg = blockIdx.x;
+    // (readfirstlane: the division runs on the vector pipe, and every pointer derived from a per-lane slot would be per lane)
+    const int slot = __builtin_amdgcn_readfirstlane(nparts > 1 ? (wg & 7) + 8 * ((wg >> 3) / nparts) : wg);
+    const int part = __builtin_amdgcn_readfirstlane(nparts > 1 ? (wg >> 3) % nparts : 0);
+    if (slot >= n_slots) return;
     if (n_items && slot >= *n_items) return;
     // (the item index is the same in every lane: say so, or every pointer derived from it -- scratch regions, trajectory, gains,
     // descriptor arrays: three dozen 64-bit values -- is held per lane and, at 128 registers per lane, spilled)
@@ -287,6 +331,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 
     // ---- terminal condition: p = l_x(T), P = l_xx(T)   (control.py:125-129)
     __syncthreads();
+    if (part == 0) {     // (the main workgroup; a helper goes straight to its loop below)
     stage_step(T, true);
     __syncthreads();
     for (int e = tid; e < n * n; e += kBigThreads) {
@@ -294,6 +339,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         gP[(int64_t)i * ldw + j] = lxx(i / NS, i % NS, j / NS, j % NS);
     }
     for (int i = tid; i < n; i += kBigThreads) sp[i] = lx(i / NS, i % NS);
+    }
     __syncthreads();
 
     // The lane terms of a phase (tile coordinates, operand addresses) are formed at the phase's start from a thread id the
@@ -307,6 +353,29 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     asm volatile("" : "+v"(tid_p_));                                                                       \
     const int tid = tid_p_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g16 = lane >> 4, c16 = lane & 15; \
     (void)wave; (void)g16; (void)c16; (void)lane;
+    BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)slot * S.total + S.oSync);
+    int coop = 0;      // 1: this pass is run by the team
+    if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!big_wait_ge(&team->mode, 1, &sFlag[2])) {
+            __builtin_trap();     // (the main workgroup never decided: the launch is aborted, loudly)
+        }
+        if (big_ld(&team->mode) != 1) return;     // the main workgroup went ahead alone
+        for (int t = T - 1; t >= 0; --t) {
+            if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2])) {
+                __builtin_trap();
+            }
+            {
+                const int part_ = part, nparts_ = nparts;
+#include "riccati_big_pairs.inc"
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
 #ifdef DPILQR_PHASE_STAMPS
     unsigned long long bph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bph_t = __builtin_amdgcn_s_memtime();
 #define BPHASE(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bph[i] += now_ - bph_t; bph_t = now_; }
@@ -825,102 +894,32 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         BPHASE(4)
 
 #ifndef DPILQR_BIG_S5_SEPARATE
-        { BIG_LANE_TERMS()
-        // ---- S5 + S6 on tile PAIRS: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T, then
-        // P <- (V + V^T)/2, p <- V[:, n].  A wavefront computes the tiles (it, jt) AND (jt, it) of V together: they share all six
-        // operand streams (T3^T, [K|d], [Q_ux|Q_u] at column blocks it and jt: 6 loads per 6 matrix-pipe products instead of
-        // 10 per 6 for two separate tiles -- the phase is bound by those loads, section 9), and having both it forms P's two tiles
-        // at once: the transposed tile goes through 2 KB of LDS per wavefront (the LU buffer is dead here), V is never written
-        // back and the separate pass over V with its transposed reads (round 2's S6, 9 % of a step) is gone.  Same values, same
-        // operations as the separate phases: 0.5 (V[i][j] + V[j][i]) with V's entries rounded exactly as before
-        // (-DDPILQR_BIG_S5_SEPARATE builds round 2's phases for A/B).
         {
-            const int tn = (n1 + 15) / 16, npair = tn * (tn + 1) / 2;
-            R* sT = sLU + wave * 544;        // two 16 x 17 tiles per wavefront
-            const int jt_p = n / 16, c_p = n - 16 * jt_p;   // where column n (the vector part) lives
-            for (int job = wave; job < npair; job += kBigThreads / 64) {
-                int it = 0, rem = job;
-                while (rem >= tn - it) { rem -= tn - it; ++it; }
-                const int jt = it + rem;
-                const bool off = it != jt;
-                acc_t a1 = acc_t{0, 0, 0, 0}, a2 = acc_t{0, 0, 0, 0}, a2t = acc_t{0, 0, 0, 0};
-                acc_t b1 = acc_t{0, 0, 0, 0}, b2 = acc_t{0, 0, 0, 0}, b2t = acc_t{0, 0, 0, 0};
-                const int64_t xo = (int64_t)g16 * ldw + 16 * it + c16, yo = (int64_t)g16 * ldw + 16 * jt + c16;
-                // operands of reduction rows ks + 4 .. ks + 7 are requested before the products of rows ks .. ks + 3 are issued: the
-                // loop is bound by the latency / bandwidth of these loads (scratch in L2 / Infinity Cache), not by the matrix pipe
-                // (two blocks ahead measured no better: 90.5 against 89.2 ms per 256 passes)
-                R t3i = gT3[xo], kdi = gKd[xo], gi = gG[xo], t3j = gT3[yo], kdj = gKd[yo], gj = gG[yo];
-                for (int ks = 0; ks < mk; ks += 4) {
-                    const int64_t ro = (int64_t)min(ks + 4, mk - 4) * ldw;     // the last round re-reads its own rows
-                    const R n_t3i = gT3[ro + xo], n_kdi = gKd[ro + xo], n_gi = gG[ro + xo];
-                    const R n_t3j = gT3[ro + yo], n_kdj = gKd[ro + yo], n_gj = gG[ro + yo];
-                    a1 = Mfma<R>::mac(t3i, kdj, a1);
-                    a2 = Mfma<R>::mac(kdi, gj, a2);
-                    a2t = Mfma<R>::mac(gi, kdj, a2t);
-                    if (off) b1 = Mfma<R>::mac(t3j, kdi, b1);     // tile (jt, it): only T3_j^T [K|d]_i is a product of its own (below)
-                    t3i = n_t3i; kdi = n_kdi; gi = n_gi; t3j = n_t3j; kdj = n_kdj; gj = n_gj;
-                }
-                // Tile (jt, it)'s other two products are the TRANSPOSES of this tile's: [K|d]_j^T G_i = (G_i^T [K|d]_j)^T = a2t^T and
-                // G_j^T [K|d]_i = ([K|d]_i^T G_j)^T = a2^T -- the same products summed over the same reduction index in the same
-                // order, so the same bits (round 5: they were computed a second time, six matrix-pipe instructions per pair and
-                // reduction step where four do; at 64 cycles each the phase is bound by exactly that pipe).  The two tiles go
-                // through the wavefront's LDS tiles once more, ahead of V's own transposition.
-                if (off) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int lr = Mfma<R>::row(v, g16);
-                        sT[lr * 17 + c16] = a2[v];
-                        sT[272 + lr * 17 + c16] = a2t[v];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int lr = Mfma<R>::row(v, g16);
-                        b2t[v] = sT[c16 * 17 + lr];            // a2^T
-                        b2[v] = sT[272 + c16 * 17 + lr];       // a2t^T
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // before the tiles are overwritten with V below
-                }
-                R vij[4], vji[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int lr = Mfma<R>::row(v, g16);
-                    const int row = 16 * it + lr, col = 16 * jt + c16;           // tile (it, jt)
-                    const R q = (row < n && col <= n) ? gV[(int64_t)row * ldw + col] : (R)0.0;
-                    vij[v] = ((q + a1[v]) + a2[v]) + a2t[v];
-                    const int row2 = 16 * jt + lr, col2 = 16 * it + c16;         // tile (jt, it)
-                    const R q2 = (off && row2 < n && col2 <= n) ? gV[(int64_t)row2 * ldw + col2] : (R)0.0;
-                    vji[v] = off ? ((q2 + b1[v]) + b2[v]) + b2t[v] : vij[v];
-                    sT[lr * 17 + c16] = vij[v];
-                    sT[272 + lr * 17 + c16] = vji[v];
-                    // V[:, n] goes back to its place in the scratch and is read as p behind the barrier below.
-                    // (History of this kernel's one failure: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- an address outside
-                    // every GPU aperture -- in builds that spilled 95 (round 3) and 82 (round 4: sincos pairs in the Jacobians)
-                    // vector registers, deterministic in a fresh process, absent under rocgdb, present on two of three boxes with
-                    // the same binary; builds with 45..64 spilled registers ran clean.  No index was ever out of range and no
-                    // hand-over lacked its barrier (audited again in round 5: every LDS / scratch producer is separated from its
-                    // consumers by __syncthreads, or by s_waitcnt inside one wavefront); what correlated was the number of
-                    // spilled registers, 108..132 scalar ones spilled into the lanes of vector registers that were spilled in
-                    // turn.  Round 5 removed the spills instead of bounding them: this kernel needs <= 122 registers and no
-                    // scratch in every instantiation, with either form of the Jacobians (tests/test_kernel_resources.py holds
-                    // it to zero), and both builds ran config 5's passes and whole solves 20 times in fresh processes without
-                    // a failure (scripts/cfg5_soak.sh).)
-                    if (jt == jt_p && c16 == c_p && row < n) gV[(int64_t)row * ldw + n] = vij[v];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wavefront's own LDS writes, before it reads them across lanes
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int lr = Mfma<R>::row(v, g16);
-                    const int row = 16 * it + lr, col = 16 * jt + c16;
-                    const R vt = sT[272 + c16 * 17 + lr];                          // V[col][row]
-                    if (row < n && col < n) gP[(int64_t)row * ldw + col] = (R)0.5 * (vij[v] + vt);
-                    if (off) {
-                        const int row2 = 16 * jt + lr, col2 = 16 * it + c16;
-                        const R vt2 = sT[c16 * 17 + lr];                           // V[col2][row2]
-                        if (row2 < n && col2 < n) gP[(int64_t)row2 * ldw + col2] = (R)0.5 * (vji[v] + vt2);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and the reads, before the next job overwrites the tiles
+        if (nparts > 1 && t == T - 1) {     // the team or alone: decided once, when the first step's operands are in place
+            if (threadIdx.x == 0) {
+                const int joined = __hip_atomic_load(&team->joined, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const int mode = (joined == nparts - 1) ? 1 : 2;
+                __hip_atomic_store(&team->mode, mode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                sFlag[3] = (mode == 1);
+            }
+            __syncthreads();
+            coop = sFlag[3];
+        }
+        if (coop) {      // K, T3^T, [Q_ux|Q_u], Q_xx of this step are in the scratch: every thread's stores done, then the word
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(&team->flag_k, T - t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        {
+            const int part_ = 0, nparts_ = coop ? nparts : 1;
+#include "riccati_big_pairs.inc"
+        }
+        if (coop) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2])) {
+                __builtin_trap();
             }
         }
         __syncthreads();

@@ -18,11 +18,37 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
                                     int gains_by_item, void* scratch, hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
     const size_t lds = sizeof(R) * (size_t)BigLds(D.k, D.n_s, D.n_c).total;
+    // Few items (config 5 is one problem): a team of workgroups per item, the helpers taking their share of S5 + S6's tile pairs
+    // (riccati_big.hpp, BigTeam) -- as many parts as give every wavefront at most one pair, as long as all of them fit the chip at
+    // one workgroup per CU.  DPILQR_BIG_TEAM=0 switches it off (A/B), =N sets the parts.
+    const int n = D.k * D.n_s, m = D.k * D.n_c;
+    const BigScratch S(n, m);
+    int nparts = 1;
+#ifndef DPILQR_BIG_S5_SEPARATE
+    {
+        static const int cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+            return v;
+        }();
+        const int tn = (n + 1 + 15) / 16, npair = tn * (tn + 1) / 2, waves = kBigThreads / 64;
+        const int slots8 = ((grid_items + 7) / 8) * 8;
+        nparts = (npair + waves - 1) / waves;
+        if (nparts > cus / slots8) nparts = cus / slots8;
+        const char* e = std::getenv("DPILQR_BIG_TEAM");
+        if (e && *e) { const int v = std::atoi(e); nparts = v <= 0 ? 1 : (v < nparts ? v : nparts); }
+        if (nparts < 2) nparts = 1;
+    }
+#endif
+    const int grid = nparts > 1 ? ((grid_items + 7) / 8) * 8 * nparts : grid_items;
+    if (nparts > 1)
+        hipLaunchKernelGGL((k_big_team_reset<R>), dim3((grid_items + 255) / 256), dim3(256), 0, st, static_cast<R*>(scratch),
+                           (int64_t)S.total, (int64_t)S.oSync, grid_items);
     DISPATCH_FAMILY(D.n_s, {
         int32_t rc = allow_lds(k_riccati_big<R, NS, NC>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_riccati_big<R, NS, NC>), dim3(grid_items), dim3(kBigThreads), lds, st, D, X, U, mu, K, d,
-                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch));
+        hipLaunchKernelGGL((k_riccati_big<R, NS, NC>), dim3(grid), dim3(kBigThreads), lds, st, D, X, U, mu, K, d,
+                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch), grid_items, nparts);
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;

@@ -434,3 +434,31 @@ def test_enqueue_only_solve_can_be_captured_in_a_hip_graph(dp):
     torch.cuda.synchronize()
     for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
         assert torch.equal(r[key], ref[key]), key
+
+
+@pytest.mark.parametrize("B,dtype_name", [(1, "float64"), (3, "float64"), (2, "float32")])
+def test_team_of_workgroups_gives_the_single_workgroups_gains(dp, monkeypatch, B, dtype_name):
+    """Few items: helper workgroups take their share of S5 + S6's tile pairs (csrc/riccati_big.hpp, BigTeam).  The same tiles,
+    computed by the same instructions wherever they run: the gains of the team (the default; of two parts only; of as many as fit)
+    are those of the single workgroup (DPILQR_BIG_TEAM=0) bit for bit -- and so are two consecutive team passes on one scratch."""
+    import torch
+    dtype = getattr(torch, dtype_name)
+    models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(True, tuple(range(6100, 6100 + B)))
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, J = pb.rollout(x0, U0, dtype=dtype)
+    Ud = torch.as_tensor(U0, dtype=dtype, device="cuda")
+    mu = torch.ones(B, dtype=torch.float64, device="cuda")
+
+    def run(team):
+        if team is None:
+            monkeypatch.delenv("DPILQR_BIG_TEAM", raising=False)
+        else:
+            monkeypatch.setenv("DPILQR_BIG_TEAM", team)
+        K, d = pb.backward_pass(X, Ud, mu, dtype=dtype)
+        return K.cpu().numpy(), d.cpu().numpy()
+
+    K0, d0 = run("0")
+    assert np.isfinite(K0).all() and np.isfinite(d0).all()
+    for team in (None, "2", None):
+        K1, d1 = run(team)
+        assert np.array_equal(K0, K1) and np.array_equal(d0, d1), team
