@@ -566,6 +566,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // numbers changing owners), U_12 one thread per column, the trailing block one thread per row and four columns, 15
         // barriers instead of 80, factors / pivots / permutation bit for bit those of this form (fp64 and fp32) -- measured
         // SLOWER, 217 k against 172 k: a panel column is ~370 instructions of one wavefront that has its SIMD to itself.  Dropped.)
+        // (Also round 5, measured and dropped, both bit-identical: the look-ahead wavefront keeping the arg-max of the entries it
+        // has just formed -- no read-back of the column, the pivot's value and row arriving with a 64-lane arg-max -- and the
+        // other wavefronts' updates in groups of 3 x 3 entries with every kind of operand requested before any is used: 32.0 and
+        // 32.4 ms per pass of one item against 32.5.  A column costs ~2.1 k clocks because it is a chain of ~twelve dependent
+        // LDS round trips, a division and a barrier whichever way they are arranged.)
         int* sPermB = sPiv;                               // the second permutation buffer (sPiv is otherwise unused)
         for (int r = tid; r < mk; r += kBigThreads) sPermB[r] = r;
         if (wave == 0) {                                  // column 0's pivot, before the loop
