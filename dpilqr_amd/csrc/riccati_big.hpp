@@ -129,7 +129,7 @@ struct BigLds {   // offsets in elements of R (all even)
 // No hang by construction: helpers REPORT (a counter) when they start; the main workgroup decides at its first S5 whether all of
 // them have (mode 1: team) or not (mode 2: alone, exactly the single-workgroup pass -- helpers that arrive later leave at once), so
 // a chip busy with other work costs the speed-up, not the result; and every wait is bounded (a fault aborts the launch).
-struct BigTeam { int flag_k, done, joined, mode; };     // one per item, zeroed by the launcher
+struct BigTeam { int flag_k, done, joined, mode, done1; };     // one per item, zeroed by the launcher
 constexpr int kBigSpinMax = 1 << 22;
 
 __device__ __forceinline__ int big_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -153,7 +153,7 @@ __global__ void k_big_team_reset(R* scratch_all, int64_t stride, int64_t o_sync,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)s * stride + o_sync);
-    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0;
+    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0;
 }
 
 template <typename R, int NS, int NC>
@@ -354,6 +354,13 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     const int tid = tid_p_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g16 = lane >> 4, c16 = lane & 15; \
     (void)wave; (void)g16; (void)c16; (void)lane;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)slot * S.total + S.oSync);
+    // (the team also shares S1 where S1 is the matrix-pipe form -- twelve-state fp64, config 5; the vector forms of the other
+    // instantiations keep it on the main workgroup: with the helper's copy of them the fp32 twelve-state kernel spilled 40 registers)
+#ifdef DPILQR_BIG_TEAM_S1_ALL
+    constexpr bool kTeamS1 = true;
+#else
+    constexpr bool kTeamS1 = (sizeof(R) == 8 && NS == 12 && NC == 4);
+#endif
     int coop = 0;      // 1: this pass is run by the team
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -361,7 +368,28 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             __builtin_trap();     // (the main workgroup never decided: the launch is aborted, loudly)
         }
         if (big_ld(&team->mode) != 1) return;     // the main workgroup went ahead alone
+        if constexpr (kTeamS1) {     // w_ref (Q + Q^T): the helper's first stage is step T - 2's, the weights' own step has passed
+            for (int e = threadIdx.x; e < k * NS * NS; e += kBigThreads) {
+                const int a = e / (NS * NS), r = e - a * NS * NS, li = r / NS, lj = r - li * NS;
+                const double* M = P.Q + a * NS * NS;
+                sQQ[e] = wr * ((R)M[li * NS + lj] + (R)M[lj * NS + li]);
+            }
+        }
         for (int t = T - 1; t >= 0; --t) {
+            if (kTeamS1 && t < T - 1) {
+                // S1 of this step with the team (the first step's ran before the team was decided): P of the previous step is
+                // complete when EVERY part has added itself to `done`; then the step's plugin data, as on the main workgroup
+                if (!big_wait_ge(&team->done, (T - 1 - t) * nparts, &sFlag[2])) __builtin_trap();
+                stage_step(t, false);
+                __syncthreads();
+                {
+                    const int part_ = part, nparts_ = nparts;
+#include "riccati_big_s1.inc"
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2])) {
                 __builtin_trap();
             }
@@ -391,139 +419,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         __syncthreads();
         BPHASE(0)
 
+        {
+            const int part_ = 0, nparts_ = (kTeamS1 && coop) ? nparts : 1;
+#include "riccati_big_s1.inc"
+        }
         { BIG_LANE_TERMS()
-        // ---- S1: the block products.  Work item (ai, aj, r): row r of [A_ai | B_ai]^T P_(ai,aj) (NS terms), then times
-        // [A_aj | B_aj] (NS terms): a row of Q_xx (r < NS) or of [Q_uu | Q_ux] (r >= NS).  (An MFMA formulation -- two
-        // 16x16x4 products per block pair with T transposed through LDS -- was built and measured SLOWER, 500 k against 250 k
-        // cycles per step: fifty dependent load -> MFMA -> LDS -> MFMA -> store chains per wavefront hide no latency.)
-        if constexpr (sizeof(R) == 8 && NS == 12 && NC == 4) {
-            // Twelve-state agents in fp64 (config 5), round 5: [A_ai | B_ai] is 12 x 16 -- a block pair's two products are one
-            // 16 x 16 matrix-pipe tile each, three reduction steps of four.  First  T^T[j][i] = sum_l P[12 ai + l][12 aj + j]
-            // [A|B]_ai[l][i]: the A operand is P's block straight from the scratch -- lane (g, c) loads P[12 ai + 4 q + g][12 aj + c],
-            // THREE coalesced loads per lane and block pair where the vector form below has every lane walk the whole 12 x 12
-            // block (144 loads; the phase was bound by them: 358 k of a step's 1.19 M clocks) -- the B operand [A|B]_ai from LDS.
-            // The accumulator's layout (lane (g, c): rows g + 4 v of column c) IS the second product's A operand layout
-            // (reduction rows 4 q + g at q = v), so T never leaves the registers: out[i][c'] = sum_j T[i][j] [A|B]_aj[j][c'].
-            // Rows j >= 12 of T^T (accumulator register 3) come from columns 12 aj + 12 .. 15 of P -- the next block's, or the
-            // zero padding -- and are never read: the second product's reduction stops at 12.  The association is the
-            // reference's ((A^T P) A); the matrix pipe sums each group of four products in its own order, so the entries agree
-            // with the vector form to rounding, not bit for bit.  The next block pair's three loads are requested before the
-            // current pair's products.
-            const int njobs = k * k;
-            auto p_loads = [&](int job, R (&dst)[3]) {
-                const int ai = job / k, aj = job - ai * k;
-                const R* src = gP + (ai * NS + g16) * ldw + aj * NS + c16;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dst[q] = src[4 * q * ldw];
-            };
-            auto do_job = [&](int job, const R (&pc)[3]) {
-                const int ai = job / k, aj = job - ai * k;
-                const R* abi = sAB + (ai * NS + g16) * NSC + c16;
-                const R* abj = sAB + (aj * NS + g16) * NSC + c16;
-                acc_t t1 = acc_t{0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 3; ++q) t1 = Mfma<R>::mac(pc[q], abi[4 * q * NSC], t1);
-                if (ai == aj && c16 >= NS) {   // B^T (P + mu I) = B^T P + mu B^T   (quirk Q6): rows i >= 12 of T, i.e. columns of T^T
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) t1[v] = fma(mu, sAB[(ai * NS + g16 + 4 * v) * NSC + c16], t1[v]);
-                }
-                acc_t o = acc_t{0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 3; ++q) o = Mfma<R>::mac(t1[q], abj[4 * q * NSC], o);
-                // every lane stores its four entries with ONE global store each, whatever they are (an entry of Q_xx, of Q_ux, of
-                // Q_uu, or -- rows < 12 of the control columns: A^T P B, which the transposed pair supplies as Q_ux -- nothing: a
-                // padding column of V that nobody reads): a fixed number of memory operations per pair is what lets the
-                // compiler wait for the operand loads alone (vmcnt counts loads and stores in issue order)
-                R* const gS = gP - S.oP;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int i = g16 + 4 * v;          // row of the 16 x 16 block: 0..11 state rows of agent ai, 12..15 its controls
-                    R val;
-                    int off;
-                    if (i < NS) {                        // (compile-time per v but for v = 3, where i = 12 + g16)
-                        const bool in = c16 < NS;
-                        val = lxx(ai, i, aj, in ? c16 : 0) + o[v];
-                        off = (int)oVa + (ai * NS + i) * ldw + (in ? aj * NS + c16 : ldw - 1);
-                    } else {
-                        const int a = ai * NC + (i - NS), cc = c16 - NS;
-                        const R qv = ((ai == aj && cc >= 0) ? sRR[ai * NC * NC + (i - NS) * NC + max(cc, 0)] : (R)0.0) + o[v];
-                        val = (cc < 0) ? o[v] : qv;       // Q_ux (l_ux = 0, cost.py:93,231) or Q_uu
-                        off = (cc < 0) ? (int)S.oG + a * ldw + aj * NS + c16 : (int)S.oQuu + a * mk + aj * NC + cc;
-                        if (cc >= 0) sLU[a * ldlu + aj * NC + cc] = qv;
-                    }
-                    gS[off] = val;
-                }
-            };
-            // two operand sets, used in turn: the next pair's loads are in flight while the current pair's products run (with one set
-            // and a copy at the loop's end the compiler waits for the loads it has just issued: vmcnt counts in order)
-            constexpr int WS = kBigThreads / 64;
-            R pa[3] = {(R)0.0, (R)0.0, (R)0.0}, pb[3] = {(R)0.0, (R)0.0, (R)0.0};
-            int job = wave;
-            if (job < njobs) {
-                p_loads(job, pa);
-                // four stores to V's padding column: the loop's first pass then meets the state every later pass meets -- the
-                // awaited loads, four stores, three loads -- and the compiler's wait for the loads (it takes the weaker of the two
-                // entry states) no longer includes the previous pair's stores
-                R* const gS = gP - S.oP;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) gS[(int)oVa + (g16 + 4 * v) * ldw + ldw - 1] = (R)0.0;
-            }
-            while (job < njobs) {
-                p_loads(min(job + WS, njobs - 1), pb);          // (unconditional -- past the end: the last pair's again -- so that the
-                do_job(job, pa);                                //  number of operations behind the awaited loads is known)
-                if (job + WS >= njobs) break;
-                p_loads(min(job + 2 * WS, njobs - 1), pa);
-                do_job(job + WS, pb);
-                job += 2 * WS;
-            }
-        } else {
-        for (int w = tid; w < k * k * NSC; w += kBigThreads) {
-            const int blk = w / NSC, r = w - blk * NSC, ai = blk / k, aj = blk - ai * k;
-            R Tr[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) Tr[j] = 0.0;
-#pragma unroll
-            for (int l = 0; l < NS; ++l) {
-                const R ab = sAB[(ai * NS + l) * NSC + r];
-                const R* Prow = gP + (int64_t)(ai * NS + l) * ldw + aj * NS;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) Tr[j] = fma(ab, Prow[j], Tr[j]);
-            }
-            if (r >= NS && ai == aj) {   // B^T (P + mu I) = B^T P + mu B^T   (quirk Q6)
-#pragma unroll
-                for (int j = 0; j < NS; ++j) Tr[j] = fma(mu, sAB[(ai * NS + j) * NSC + r], Tr[j]);
-            }
-            if (r < NS) {
-                R* out = gV + (int64_t)(ai * NS + r) * ldw + aj * NS;
-#pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    R s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + c], s);
-                    out[c] = lxx(ai, r, aj, c) + s;
-                }
-            } else {
-                const int a = ai * NC + (r - NS);
-                R* out = gG + (int64_t)a * ldw + aj * NS;
-#pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    R s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + c], s);
-                    out[c] = s;                                   // l_ux = 0 (cost.py:93,231)
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    R s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) s = fma(Tr[j], sAB[(aj * NS + j) * NSC + NS + c], s);
-                    const R q = ((ai == aj) ? sRR[ai * NC * NC + (r - NS) * NC + c] : (R)0.0) + s;
-                    gQuu[(int64_t)a * mk + aj * NC + c] = q;
-                    sLU[a * ldlu + aj * NC + c] = q;
-                }
-            }
-        }
-        }
         // Q_x = l_x + A^T p -> column n of V ; Q_u = l_u + B^T p -> column n of [Q_ux | Q_u]
         for (int i = tid; i < n + m; i += kBigThreads) {
             R s = 0.0;
@@ -542,6 +442,16 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 gG[(int64_t)ia * ldw + n] = lu + s;
             }
         }
+        }
+        if (kTeamS1 && coop) {      // the team's S1: every part's block products stored, then Q_uu -- the other parts' entries of it -- into the LU buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!big_wait_ge(&team->done1, (T - 1 - t) * nparts, &sFlag[2])) __builtin_trap();
+            for (int e = threadIdx.x; e < m * m; e += kBigThreads) {
+                const int a = e / m, c = e - a * m;
+                sLU[a * ldlu + c] = gQuu[(int64_t)a * mk + c];
+            }
         }
         __syncthreads();
         BPHASE(1)
