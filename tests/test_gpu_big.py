@@ -438,7 +438,8 @@ def test_enqueue_only_solve_can_be_captured_in_a_hip_graph(dp):
 
 @pytest.mark.parametrize("B,dtype_name", [(1, "float64"), (3, "float64"), (2, "float32")])
 def test_team_of_workgroups_gives_the_single_workgroups_gains(dp, monkeypatch, B, dtype_name):
-    """Few items: helper workgroups take their share of S5 + S6's tile pairs (csrc/riccati_big.hpp, BigTeam).  The same tiles,
+    """Few items: helper workgroups take their share of S5 + S6's tile pairs and (twelve-state fp64) of S1's block pairs
+    (csrc/riccati_big.hpp, BigTeam).  The same tiles,
     computed by the same instructions wherever they run: the gains of the team (the default; of two parts only; of as many as fit)
     are those of the single workgroup (DPILQR_BIG_TEAM=0) bit for bit -- and so are two consecutive team passes on one scratch."""
     import torch
