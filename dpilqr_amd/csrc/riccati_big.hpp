@@ -133,18 +133,18 @@ struct BigTeam { int flag_k, done, joined, mode, done1; };     // one per item, 
 constexpr int kBigSpinMax = 1 << 22;
 
 __device__ __forceinline__ int big_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire.  false: gave up
+// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire fence.  false: gave up
 __device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok) {
     if (threadIdx.x == 0) {
         int it = 0, ok = 1;
-        while (big_ld(p) < target) {
+        while (big_ld(p) < target) {      // (relaxed: an acquire here invalidates the caches at every poll -- measured, 2 .. 5 x slower passes)
             __builtin_amdgcn_s_sleep(4);
             if (++it > kBigSpinMax) { ok = 0; break; }
         }
         *s_ok = ok;
     }
     __syncthreads();
-    (void)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (every wavefront drops what its caches hold of the other parts' data)
     return *s_ok != 0;
 }
 
