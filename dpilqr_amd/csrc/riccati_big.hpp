@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                                                              int32_t* __restrict__ singular,
                                                              const int32_t* __restrict__ items,
                                                              const int32_t* __restrict__ n_items, int gains_by_item,
-                                                             R* scratch_all, int n_slots, int nparts) {
+                                                             R* scratch_all, int n_slots, int nparts, int team_late) {
     typedef typename Mfma<R>::acc_t acc_t;
     constexpr int NSC = NS + NC;
     // nparts > 1: workgroup x + 8 y is part y % nparts of slot x + 8 (y / nparts) -- workgroups are dealt to the eight XCDs in turn,
@@ -363,6 +363,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #endif
     int coop = 0;      // 1: this pass is run by the team
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
+        // (tests: DPILQR_BIG_TEAM_LATE makes the helpers report a few milliseconds late -- after the main workgroup's decision --
+        // which is what a chip busy with other work does to them: the pass must then be the single workgroup's)
+        if (team_late) for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(127);
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (!big_wait_ge(&team->mode, 1, &sFlag[2])) {
             __builtin_trap();     // (the main workgroup never decided: the launch is aborted, loudly)

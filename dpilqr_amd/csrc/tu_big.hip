@@ -40,6 +40,7 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
         if (nparts < 2) nparts = 1;
     }
 #endif
+    const int team_late = std::getenv("DPILQR_BIG_TEAM_LATE") != nullptr;     // tests: see the kernel
     const int grid = nparts > 1 ? ((grid_items + 7) / 8) * 8 * nparts : grid_items;
     if (nparts > 1)
         hipLaunchKernelGGL((k_big_team_reset<R>), dim3((grid_items + 255) / 256), dim3(256), 0, st, static_cast<R*>(scratch),
@@ -48,7 +49,7 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
         int32_t rc = allow_lds(k_riccati_big<R, NS, NC>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((k_riccati_big<R, NS, NC>), dim3(grid), dim3(kBigThreads), lds, st, D, X, U, mu, K, d,
-                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch), grid_items, nparts);
+                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch), grid_items, nparts, team_late);
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;

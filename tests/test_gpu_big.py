@@ -463,3 +463,36 @@ def test_team_of_workgroups_gives_the_single_workgroups_gains(dp, monkeypatch, B
     for team in (None, "2", None):
         K1, d1 = run(team)
         assert np.array_equal(K0, K1) and np.array_equal(d0, d1), team
+
+
+def test_team_helpers_that_start_late_leave_the_pass_to_the_main_workgroup(dp, monkeypatch):
+    """What a chip busy with other work does to the team: the helpers report after the main workgroup has looked for them
+    (DPILQR_BIG_TEAM_LATE delays them by a few milliseconds).  The main workgroup then runs the whole pass alone -- the
+    single-workgroup gains, bit for bit, no hang -- and the late helpers leave at once; the next pass, with the helpers on
+    time again, is a team's."""
+    import time
+    import torch
+    models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(True, (6200,))
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, J = pb.rollout(x0, U0)
+    Ud = torch.as_tensor(U0, dtype=torch.float64, device="cuda")
+    mu = torch.ones(1, dtype=torch.float64, device="cuda")
+
+    def run(**env):
+        for key in ("DPILQR_BIG_TEAM", "DPILQR_BIG_TEAM_LATE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K, d = pb.backward_pass(X, Ud, mu)
+        torch.cuda.synchronize()
+        return K.cpu().numpy(), d.cpu().numpy(), time.perf_counter() - t0
+
+    run()                                         # (warm)
+    K0, d0, t_alone = run(DPILQR_BIG_TEAM="0")
+    K1, d1, t_late = run(DPILQR_BIG_TEAM_LATE="1")
+    K2, d2, t_team = run()
+    assert np.array_equal(K0, K1) and np.array_equal(d0, d1)
+    assert np.array_equal(K0, K2) and np.array_equal(d0, d2)
+    assert t_late > 0.9 * t_alone and t_team < 0.85 * t_alone, (t_alone, t_late, t_team)    # alone again / a team again
