@@ -496,3 +496,29 @@ def test_team_helpers_that_start_late_leave_the_pass_to_the_main_workgroup(dp, m
     assert np.array_equal(K0, K1) and np.array_equal(d0, d1)
     assert np.array_equal(K0, K2) and np.array_equal(d0, d2)
     assert t_late > 0.9 * t_alone and t_team < 0.85 * t_alone, (t_alone, t_late, t_team)    # alone again / a team again
+
+
+@pytest.mark.parametrize("model,k,ns,nc,nd,T", [(3, 30, 4, 2, 2, 30), (4, 20, 6, 3, 3, 25), (7, 10, 12, 4, 3, 20), (0, 24, 4, 2, 2, 20)])
+def test_team_at_other_sizes_and_families(dp, monkeypatch, model, k, ns, nc, nd, T):
+    """The team with two or three parts (n_x = 96, 120) and with the vector forms of S1 (four- and six-state agents, fp32): the
+    single workgroup's gains bit for bit."""
+    import torch
+    from dpilqr_amd.util import random_setup
+    np.random.seed(5)
+    a, b = random_setup(k, ns, is_rotation=False, rel_dist=k, var=k / 2, n_d=nd, random=True, energy=10.0 * k)
+    x0, xf = a.ravel()[None], b.ravel()[None]
+    U0 = np.zeros((1, T, k * nc))
+    if model == 4:
+        U0[:, :, 0::3] = 9.80665
+    if model == 7:
+        U0[:, :, 3::4] = 9.80665 * 63.0 / 2000.0
+    pb = dp.ProblemBatch([model] * k, [nd] * k, xf, np.eye(ns), np.eye(nc), 100.0 * np.eye(ns), 0.5, 0.1, T)
+    for dtype in (torch.float64, torch.float32):
+        X, J = pb.rollout(x0, U0, dtype=dtype)
+        Ud = torch.as_tensor(U0, dtype=dtype, device="cuda")
+        mu = torch.ones(1, dtype=torch.float64, device="cuda")
+        monkeypatch.setenv("DPILQR_BIG_TEAM", "0")
+        K0, d0 = pb.backward_pass(X, Ud, mu, dtype=dtype)
+        monkeypatch.delenv("DPILQR_BIG_TEAM")
+        K1, d1 = pb.backward_pass(X, Ud, mu, dtype=dtype)
+        assert torch.isfinite(K0).all() and torch.equal(K0, K1) and torch.equal(d0, d1), dtype
