@@ -479,11 +479,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // numbers changing owners), U_12 one thread per column, the trailing block one thread per row and four columns, 15
         // barriers instead of 80, factors / pivots / permutation bit for bit those of this form (fp64 and fp32) -- measured
         // SLOWER, 217 k against 172 k: a panel column is ~370 instructions of one wavefront that has its SIMD to itself.  Dropped.)
-        // (Also round 5, measured and dropped, both bit-identical: the look-ahead wavefront keeping the arg-max of the entries it
-        // has just formed -- no read-back of the column, the pivot's value and row arriving with a 64-lane arg-max -- and the
-        // other wavefronts' updates in groups of 3 x 3 entries with every kind of operand requested before any is used: 32.0 and
-        // 32.4 ms per pass of one item against 32.5.  A column costs ~2.1 k clocks because it is a chain of ~twelve dependent
-        // LDS round trips, a division and a barrier whichever way they are arranged.)
+        // (Also round 5: the look-ahead wavefront keeps the arg-max of the entries it has just formed AND every lane divides for its own
+        // candidate while the arg-max runs -- below; without the early division the same arrangement bought nothing, 32.0 against
+        // 32.5 ms per pass of one item, with it 29.6 -> 28.9.  Measured and dropped, bit-identical: the other wavefronts' updates in
+        // groups of 3 x 3 entries with every kind of operand requested before any is used, 32.4 against 32.5.  A column is a chain of
+        // about a dozen dependent LDS round trips, a division and a barrier.)
         int* sPermB = sPiv;                               // the second permutation buffer (sPiv is otherwise unused)
         for (int r = tid; r < mk; r += kBigThreads) sPermB[r] = r;
         if (wave == 0) {                                  // column 0's pivot, before the loop
@@ -516,30 +516,58 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             const R* prow = sLU + pk[kk] * ldlu;
             if (wave == 0) {
                 if (kk + 1 < m) {
-                    // column kk + 1 first, all rows below the pivot ...
+                    // Column kk + 1, all rows below the pivot, its pivot AND the pivot's reciprocal in one pass (round 5): a lane keeps
+                    // the largest of the entries it has just formed -- magnitude, position, row -- and divides for ITS candidate
+                    // while the arg-max runs (the division, ~40 dependent instructions, used to follow the search on one lane);
+                    // the winner's reciprocal and row arrive with the arg-max, nothing is read back, and what the deciding lane
+                    // needs of the permutation is requested before the pass.  pn holds perm_kk-1; replaying the exchange (kk, b0)
+                    // that made perm_kk gives it pk's entries there, so they are read from pk -- early -- and the lane only
+                    // writes.  Same pivots (first position of the largest magnitude), same entries, the same reciprocal 1 / pivot.
+                    const int b0 = sFlag[1];
+                    const int pk_a0 = pk[kk], pk_b0 = pk[b0], rk = pk[kk + 1];
+                    R best = -1.0, bval = 0.0;
+                    int piv = kk + 1, brow = rk;
                     for (int ps = kk + 1 + lane; ps < m; ps += 64) {
-                        R* row = sLU + pk[ps] * ldlu;
+                        const int r = pk[ps];
+                        R* row = sLU + r * ldlu;
                         const R l = row[kk] * inv;
-                        row[kk + 1] = fma(-l, prow[kk + 1], row[kk + 1]);
+                        const R v = fma(-l, prow[kk + 1], row[kk + 1]);
+                        row[kk + 1] = v;
+                        const R av = fabs(v);
+                        if (av > best) { best = av; piv = ps; bval = v; brow = r; }
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // ... then its pivot: sixteen lanes scan the column, ties go to the lower position
-                    R best = -1.0;
-                    int piv = kk + 1;
-                    for (int ps = kk + 1 + (lane & 15); ps < m; ps += 16) {
-                        const R v = fabs(sLU[pk[ps] * ldlu + kk + 1]);
-                        if (v > best) { best = v; piv = ps; }
+                    R binv = (bval == (R)0.0) ? (R)0.0 : (R)1.0 / bval;      // this lane's candidate's (lanes without one: 0)
+#define DPILQR_ARGMAX4(OB, OP, OV, OR_)                                                                  \
+                    if ((OB) > best || ((OB) == best && (OP) < piv)) { best = (OB); piv = (OP); binv = (OV); brow = (OR_); }
+#define DPILQR_ARGMAX4_DPP(CTRL)                                                                        \
+                    {                                                                                   \
+                        const R ob = dpp_val<CTRL>(best), ov = dpp_val<CTRL>(binv);                     \
+                        const int op = dpp_i32<CTRL>(piv), orw = dpp_i32<CTRL>(brow);                   \
+                        DPILQR_ARGMAX4(ob, op, ov, orw)                                                 \
                     }
-                    DPILQR_ARGMAX_STEP(0xB1) DPILQR_ARGMAX_STEP(0x4E) DPILQR_ARGMAX_STEP(0x141) DPILQR_ARGMAX_STEP(0x140)
+#define DPILQR_ARGMAX4_XROW(MASK)                                                                       \
+                    {                                                                                   \
+                        const int src = lane ^ (MASK);                                                  \
+                        const R ob = lane_bcast(best, src), ov = lane_bcast(binv, src);                 \
+                        const int op = __builtin_amdgcn_ds_bpermute(src << 2, piv), orw = __builtin_amdgcn_ds_bpermute(src << 2, brow); \
+                        DPILQR_ARGMAX4(ob, op, ov, orw)                                                 \
+                    }
+                    DPILQR_ARGMAX4_DPP(0xB1) DPILQR_ARGMAX4_DPP(0x4E) DPILQR_ARGMAX4_DPP(0x141) DPILQR_ARGMAX4_DPP(0x140)
+                    if (m - kk - 1 > 16) { DPILQR_ARGMAX4_XROW(16) }     // (the rows of lanes that had entries at all)
+                    if (m - kk - 1 > 32) { DPILQR_ARGMAX4_XROW(32) }
+#undef DPILQR_ARGMAX4_XROW
+#undef DPILQR_ARGMAX4_DPP
+#undef DPILQR_ARGMAX4
                     if (lane == 0) {
-                        // pn holds perm_kk-1: replay the exchange that made perm_kk, then make this column's
-                        const int a0 = kk, b0 = sFlag[1];
-                        const int t0 = pn[a0]; pn[a0] = pn[b0]; pn[b0] = t0;
-                        const int rk = pn[kk + 1], rp = pn[piv];
-                        pn[kk + 1] = rp; pn[piv] = rk;
-                        const R pv = sLU[rp * ldlu + kk + 1];
-                        if (!(best > (R)0.0)) sFlag[0] = 1;
-                        sInv[kk + 1] = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                        pn[kk] = pk_a0; pn[b0] = pk_b0;          // perm_kk-1 -> perm_kk (the replayed exchange)
+                        pn[kk + 1] = brow; pn[piv] = rk;         // ... -> perm_kk+1
+                        if (!(best > (R)0.0)) {
+                            // a column without a positive finite maximum -- singular, or poisoned -- is flagged; its "pivot" is read back
+                            sFlag[0] = 1;
+                            const R pv = sLU[brow * ldlu + kk + 1];
+                            binv = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                        }
+                        sInv[kk + 1] = binv;
                         sFlag[1] = piv;
                     }
                 }
