@@ -392,7 +392,7 @@ def main():
         # roofline = the dominant kernel: the sweep variant (wavefronts per workgroup) that ran the full-window launches,
         # exactly the launches a rocprofv3 kernel trace lists under that instantiation's name; the job's other sweep
         # launches (the draining tail's smaller variants) are reported beside it under "all_sweep_launches"
-        fused = os.environ.get("DPILQR_NO_FUSED") is None
+        fused = not _lib.route_flag("DPILQR_NO_FUSED")
         all_ric = prof["riccati"]
         waves = next((w for w in (12, 8, 4) if sweep_variants[w]["launches"]), None)
         ric = sweep_variants[waves] if waves else all_ric

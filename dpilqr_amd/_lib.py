@@ -8,14 +8,26 @@ import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = Path(os.environ["DPILQR_LIB"]) if os.environ.get("DPILQR_LIB") else HERE / "libdpilqr_hip.so"   # override: diagnostics only
+
+
+def route_env(name):
+    """The library's A/B route switches (csrc/launch.hpp: route_env) and this binding's DPILQR_LIB override are for experiments
+    and tests: they count only in a process that sets DPILQR_DEBUG_ROUTES=1.  A production process ignores them all."""
+    return os.environ.get(name) if os.environ.get("DPILQR_DEBUG_ROUTES") == "1" else None
+
+
+def route_flag(name):
+    return route_env(name) is not None
+
+
+LIB_PATH = Path(route_env("DPILQR_LIB")) if route_env("DPILQR_LIB") else HERE / "libdpilqr_hip.so"   # override: A/B builds only
 
 i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOGPU, EWORKSPACE = 0, -1, -2, -3, -4, -5
 N_ALPHA = 10
-ABI_VERSION = 3          # DPILQR_ABI_VERSION of include/dpilqr_hip.h
-STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STATUS_SINGULAR, STATUS_KILLED = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 4          # DPILQR_ABI_VERSION of include/dpilqr_hip.h
+STATUS_ACTIVE, STATUS_CONVERGED, STATUS_LINESEARCH_FAILED, STATUS_MAX_ITER, STATUS_SINGULAR, STATUS_KILLED, STATUS_FAULT = 0, 1, 2, 3, 4, 5, 6
 
 
 class BatchDesc(C.Structure):

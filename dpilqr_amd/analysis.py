@@ -14,6 +14,12 @@ per-trial run of solve_rhc on the same seed sees the same inputs (tests/test_gpu
 
 limit_solve_time (analysis 2, the reference's default, analysis.py:179): t_kill = dt reaches every solve -- inside the
 batched device solve (include/dpilqr_hip.h: every item's own clock from its admission) -- and t_diverge = N dt.
+What that clock measures differs in kind from the reference's: there a solve has a CPU core to itself and perf_counter() runs
+over its own work; here an item shares every launch with the rest of the window, so its elapsed time includes the work the GPU
+does for up to `window` other items.  Which solves are killed therefore depends on the batch size, the window and whatever else
+the GPU runs, and varies from run to run: analysis-2 rows answer "what does a real-time budget of dt buy on THIS device at THIS
+load", not the reference's question, and cannot be compared row by row with its CSV.  For a reproducible budget pass
+n_lqr_iter (a cap on iterations per solve, deterministic) instead of, or beside, limit_solve_time.
 """
 import logging
 from os import getpid
@@ -102,17 +108,29 @@ def multi_agent_run(model, x_dims, dt, N, radius, energy=10.0, n_d=2, trials=(0,
     return {i: tuple(v) for i, v in out.items()}
 
 
+LOGGER_NAME = "dpilqr.analysis"
+
+
 def setup_logger(limit_solve_time, log_file=None):
     """setup_logger (analysis.py:110-123): logs/dec-mc-{1|2}_<date>_<pid>.csv beside the repository's scripts unless a
-    file is named; the header row first.  Returns the path."""
+    file is named; the header row first.  Returns the path.  The reference configures the ROOT logger of its own script; a
+    library must not (the embedding application's handlers are its own): the rows go through the logger `dpilqr.analysis`, which
+    gets the file handler and does not propagate."""
     analysis = "1" if not limit_solve_time else "2"
     if log_file is None:
         log_path = Path(__file__).resolve().parent.parent / "logs"
         log_path.mkdir(exist_ok=True)
         log_file = log_path / strftime(f"dec-mc-{analysis}_%m-%d-%y_%H.%M.%S_{getpid()}.csv")
     print(f"Logging results to {log_file}")
-    logging.basicConfig(filename=log_file, format="%(message)s", level=logging.INFO, force=True)
-    logging.info(HEADER)
+    logger = logging.getLogger(LOGGER_NAME)
+    for h in list(logger.handlers):            # a previous study's file
+        logger.removeHandler(h); h.close()
+    handler = logging.FileHandler(log_file)
+    handler.setFormatter(logging.Formatter("%(message)s"))
+    logger.addHandler(handler)
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+    logger.info(HEADER)
     return Path(log_file)
 
 
@@ -122,7 +140,7 @@ def monte_carlo_analysis(limit_solve_time=False, n_trials=2, n_agents_iter=(3, 4
     trials) is the batch.  n_trials may be thousands -- that is what the batched path is for."""
     if emit is None:
         setup_logger(limit_solve_time, log_file)
-        emit = logging.info
+        emit = logging.getLogger(LOGGER_NAME).info
     if limit_solve_time:
         t_kill, t_diverge = dt, N * dt
     else:

@@ -241,7 +241,7 @@ class ProblemBatch:
 
     def backward_pass(self, X, U, mu, tiles=None, dtype=torch.float64):
         """control.py:116-148: K (B,T,n_u,n_x), d (B,T,n_u)."""
-        if dtype == torch.float64 and not self.fused_sweep and "DPILQR_FORCE_BIG" not in os.environ:
+        if dtype == torch.float64 and not self.fused_sweep and not _lib.route_flag("DPILQR_FORCE_BIG"):
             tiles = self.make_tiles(X, U, tiles)
             return backward_pass_tiles(tiles, self.B, self.T, self.n_x, self.n_u, mu, blocks=(self.n_s, self.n_c))
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
@@ -343,6 +343,11 @@ class ProblemBatch:
         d = empty((B, T, m), dtype) if gains else None
         ws = _workspace_pool.acquire(self.workspace_bytes(window, not gains, dtype))
         fn = self._lib.dpilqr_solve_batch if dtype == torch.float64 else self._lib.dpilqr_solve_batch_f32
+        out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
+        if trace:
+            out["trace"] = tr
+        if gains:
+            out["K"], out["d"] = K, d
         ok = False
         try:
             with _lib.progress_callback(progress):
@@ -350,21 +355,24 @@ class ProblemBatch:
                               ptr(ws), ws.numel(),
                               ptr(X), ptr(J), ptr(status), ptr(n_bwd), ptr(n_fwd), ptr(tr), ptr(K), ptr(d), stream_handle()))
             ok = True
+        except _lib.DpilqrError as e:
+            # DPILQR_EHIP because the device gave items up (STATUS_FAULT): the solve ran to its end, the other items' results
+            # are valid -- they travel with the exception
+            e.results = out
+            raise
         finally:
             if ok:
                 _workspace_pool.release(ws)   # solve_batch has synchronised its stream: the buffer is idle
             # a failed solve's buffer is dropped, not pooled: the allocator frees it in stream order
-        out = dict(X=X, U=U, J=J, status=status, n_bwd=n_bwd, n_fwd=n_fwd)
-        if trace:
-            out["trace"] = tr
-        if gains:
-            out["K"], out["d"] = K, d
         return out
 
-    def solve_enqueue(self, x0, U0, n_global_iter, n_lqr_iter=50, tol=1e-3, window=None, state=None, t_kill=None):
+    def solve_enqueue(self, x0, U0, n_global_iter, n_lqr_iter=None, tol=None, window=None, state=None, t_kill=None):
         """The same solve as pure enqueue on torch's current stream (dpilqr_solve_enqueue): nothing is waited for.
         Returns (results dict, state); pass `state` back to continue with another n_global_iter iterations.  An item is
-        finished when its status is no longer 0 (STATUS_ACTIVE)."""
+        finished when its status is no longer 0 (STATUS_ACTIVE).
+        n_lqr_iter (default 50), tol (1e-3) and t_kill (none) are fixed by the FIRST call and kept in `state`: a continuing call
+        need not repeat them and may not change them (the per-item admission clocks t_kill reads are stamped only by a solve that
+        started with a limit)."""
         B, T, n, m = self.B, self.T, self.n_x, self.n_u
         if state is None:
             window = self.default_window() if window is None else int(window)
@@ -372,10 +380,15 @@ class ProblemBatch:
             r = dict(X=empty((B, T + 1, n)), U=U, J=empty((B,)), status=empty((B,), torch.int32),
                      n_bwd=empty((B,), torch.int32), n_fwd=empty((B,), torch.int32))
             ws = torch.empty(self.workspace_bytes(window, True), dtype=torch.uint8, device=device())
-            state = dict(r=r, ws=ws, x0=x0, window=window, resume=0)
+            state = dict(r=r, ws=ws, x0=x0, window=window, resume=0, n_lqr_iter=int(50 if n_lqr_iter is None else n_lqr_iter),
+                         tol=float(1e-3 if tol is None else tol), t_kill=float(t_kill or 0.0))
+        else:
+            for name, given in (("n_lqr_iter", n_lqr_iter), ("tol", tol), ("t_kill", t_kill)):
+                if given is not None and float(given) != float(state[name]):
+                    raise ValueError(f"solve_enqueue: {name}={given} on a continuing call, the solve was started with {state[name]}")
         r, ws = state["r"], state["ws"]
-        _lib.check(self._lib.dpilqr_solve_enqueue(self._d, ptr(state["x0"]), ptr(r["U"]), int(n_lqr_iter), float(tol),
-                                                  float(t_kill or 0.0), state["window"], ptr(ws), ws.numel(), ptr(r["X"]), ptr(r["J"]),
+        _lib.check(self._lib.dpilqr_solve_enqueue(self._d, ptr(state["x0"]), ptr(r["U"]), state["n_lqr_iter"], state["tol"],
+                                                  state["t_kill"], state["window"], ptr(ws), ws.numel(), ptr(r["X"]), ptr(r["J"]),
                                                   ptr(r["status"]), ptr(r["n_bwd"]), ptr(r["n_fwd"]), None, None, None,
                                                   int(n_global_iter), state["resume"], stream_handle()))
         state["resume"] = 1

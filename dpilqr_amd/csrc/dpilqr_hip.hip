@@ -31,6 +31,12 @@ int32_t fail(int32_t code, const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+// The one gate in front of every A/B route switch (launch.hpp): closed unless DPILQR_DEBUG_ROUTES=1, read once.
+const char* route_env(const char* name) {
+    static const bool open = [] { const char* g = std::getenv("DPILQR_DEBUG_ROUTES"); return g && g[0] == '1' && g[1] == 0; }();
+    return open ? std::getenv(name) : nullptr;
+}
+
 // compute units of the current device (256 on MI355X), remembered per device
 int device_cus() {
     static int cus_of[64] = {0};
@@ -100,8 +106,9 @@ __global__ void k_init_state(int B, double* mu, double* delta, int32_t* status, 
 // want_prefix = 0: nobody listens for progress, the scan of the list for its lowest index is skipped (mail[2] = 0).
 // t_admit (null without t_kill): the admitted items' own t0 of control.py:167 -- the device's constant-rate clock now,
 // just before their first backward pass.
+// mail[3] = items retired with DPILQR_STATUS_FAULT so far (solve_state.hpp: retire_without_gains).
 __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int32_t* admitted, int B, int window,
-                        int32_t* mail, int want_prefix, int64_t* t_admit) {
+                        int32_t* mail, int want_prefix, int64_t* t_admit, const int32_t* fault) {
     const int base = *count, first = *admitted;
     const int n_new = min(B - first, window - base);
     __shared__ int lowest;
@@ -121,7 +128,7 @@ __global__ void k_admit(int32_t* list, int32_t* count, int32_t* next_count, int3
     }
     if (threadIdx.x == 0) {
         *count = base + n_new; *admitted = first + n_new; *next_count = 0;
-        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; mail[2] = want_prefix ? lowest : 0; }   // pinned host memory: the host reads it after the event
+        if (mail) { mail[0] = base + n_new; mail[1] = first + n_new; mail[2] = want_prefix ? lowest : 0; mail[3] = *fault; }   // pinned host memory: the host reads it after the event
     }
 }
 
@@ -167,7 +174,7 @@ struct SolveWorkspace {
         alphas = o;   o = al(o + sizeof(double) * DPILQR_N_ALPHA);
         singular = o; o = al(o + sizeof(int32_t) * B);
         lists = o;    o = al(o + sizeof(int32_t) * 2 * Wn);
-        counts = o;   o = al(o + sizeof(int32_t) * (kCountRing + 1));   // ring + the `admitted` counter
+        counts = o;   o = al(o + sizeof(int32_t) * (kCountRing + 2));   // ring + the `admitted` counter + the fault counter
         t_admit = o;  o = al(o + sizeof(int64_t) * B);                  // t_kill: every item's admission stamp
         total = o;
     }
@@ -180,7 +187,7 @@ int window_of(const dpilqr_batch_desc& D, int window) { return (window <= 0 || w
 // The host reads the device-side counters kHostLag iterations late: that many iterations of launches are always
 // queued behind the one the GPU is running, so a host thread that loses its core for a millisecond (a loaded box)
 // does not leave the GPU idle.  The price is kHostLag empty iterations (a dozen tiny launches) at the end of a solve.
-constexpr int kHostLag = 3, kMailRing = kHostLag + 1, kMailWords = 4;   // {active, admitted, finished prefix, -}
+constexpr int kHostLag = 3, kMailRing = kHostLag + 1, kMailWords = 4;   // {active, admitted, finished prefix, faulted items}
 
 // opt-in per-kernel timing (dpilqr_profile_*): event pairs recorded on the solve's own stream
 struct Profiler {
@@ -413,7 +420,8 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     };
 
     int32_t* admitted_dev = counts + kCountRing;
-    static const bool no_static = getenv("DPILQR_TILES_NO_STATIC") != nullptr;   // A/B switch
+    S.fault = counts + kCountRing + 1;
+    static const bool no_static = route_flag("DPILQR_TILES_NO_STATIC");   // A/B switch
     const int um = hint_model(D);
     // One linear model and one R for the whole batch: A, B and L_uu are the same in every record of every item
     // the fused sweep evaluates the plugins itself: no tile producer, no records
@@ -423,9 +431,9 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     if (!resume) {
         double a[DPILQR_N_ALPHA];
         alpha_table(a);
-        const int init_n = D.B > kCountRing + 1 ? D.B : kCountRing + 1;
+        const int init_n = D.B > kCountRing + 2 ? D.B : kCountRing + 2;
         hipLaunchKernelGGL(k_init_state, dim3((init_n + 255) / 256), dim3(256), 0, st, D.B, S.mu, S.delta, status, n_bwd, n_fwd,
-                           singular, counts, kCountRing + 1, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+                           singular, counts, kCountRing + 2, alphas, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
         HIP_TRY(hipGetLastError());
         // X, J* <- rollout(x0, U) for every item up front (control.py:164)
         prof.begin(3, -1, st);
@@ -460,7 +468,7 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
         int32_t* nxt_n = counts + ((it + 1) % kCountRing);
         int32_t* mail = solver ? solver->dev + kMailWords * (it % kMailRing) : nullptr;
         hipLaunchKernelGGL(k_admit, dim3(1), dim3(256), 0, st, cur, cur_n, nxt_n, admitted_dev, D.B, Wn, mail,
-                           (solver && solver->progress) ? 1 : 0, t_admit);
+                           (solver && solver->progress) ? 1 : 0, t_admit, S.fault);
         if (solver) HIP_TRY(hipEventRecord(solver->ev[it % kMailRing], st));
         S.next_items = lists + (size_t)((it + 1) & 1) * Wn;
         S.next_count = nxt_n;
@@ -538,6 +546,15 @@ int32_t solve_impl(dpilqr_solver* solver, const dpilqr_batch_desc* desc, const R
     }
     prof.collect(solver->hist, D.B);
     if (solver->progress) solver->progress(solver->progress_user, D.B, D.B);   // the stream has been waited for: everything is final
+    if (n_lqr_iter > 0) {
+        // items the device gave up (DPILQR_STATUS_FAULT): the count only grows, and the iterations since the list emptied were
+        // no-ops, so the freshest mailbox holds the final figure
+        int32_t faulted = 0;
+        for (int j = 0; j < kMailRing; ++j) faulted = std::max(faulted, solver->host[kMailWords * j + 3]);
+        if (faulted > 0)
+            return fail(DPILQR_EHIP, "solve_batch: the device gave up %d of %d items (status DPILQR_STATUS_FAULT: a hand-over inside a "
+                                     "team of workgroups expired); every other item's result is valid", faulted, D.B);
+    }
     return DPILQR_OK;
 }
 

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(
     }
 
     if (mode == kModeLineSearch && S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
-        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] += 1; }
+        if (tid == 0) retire_without_gains(S, b);
         return;
     }
     const int64_t gslot = (mode == kModeLineSearch && !S.gains_by_item) ? slot : b;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(128, 2) void k_linesearch_team(
     double* Xb = X + (int64_t)b * (T + 1) * n;
     double* Ub = U + (int64_t)b * T * m;
     if (S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
-        if (threadIdx.x == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] += 1; }
+        if (threadIdx.x == 0) retire_without_gains(S, b);
         return;
     }
     const bool active = tid < KA * NG;

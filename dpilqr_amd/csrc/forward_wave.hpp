@@ -192,7 +192,7 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
     double* Xb = X + (int64_t)b * (T + 1) * n;
     double* Ub = U + (int64_t)b * T * m;
     if (S.singular && S.singular[b]) {  // np.linalg.solve would have raised LinAlgError
-        if (tid == 0) { S.status[b] = DPILQR_STATUS_SINGULAR; S.n_bwd[b] += 1; }
+        if (tid == 0) retire_without_gains(S, b);
         return;
     }
     const int64_t gslot = S.gains_by_item ? b : slot;
@@ -341,15 +341,10 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         // the trajectory stores of the previous step go out here, BEFORE the next prefetch is issued: memory
         // operations retire in order, so the wait for that prefetch at the top of the next step then never
         // includes a younger store's round trip (the stores are invisible to the compiler's wait counts)
-#ifdef DPILQR_LS_EXP   // timing experiments only (wrong results): which of the candidate stores the launch time depends on
-        if (active && (DPILQR_LS_EXP < 3) && (g == 0 || DPILQR_LS_EXP < 1)) store_vec(Xw + (int64_t)t * n, x, NS);
-        if (active && (DPILQR_LS_EXP < 3) && (g == 0 || DPILQR_LS_EXP < 2) && t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
-#else
         if (active) {
             store_vec(Xw + (int64_t)t * n, x, NS);
             if (t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
         }
-#endif
 #pragma unroll
         for (int i = 0; i < NC; ++i) ut[i] = u[i];
         if (active) {
@@ -368,11 +363,6 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
             double sum[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) sum[c] = 0.0;
-#ifdef DPILQR_LS_SPLIT
-            double sum2[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) sum2[c] = 0.0;
-#endif
             const double* rows = sK + a * (W::KBLK + W::KGAP);
             if (n % 2 == 0) {
 #pragma unroll 5
@@ -381,16 +371,8 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         const v2d kr = *reinterpret_cast<const v2d*>(rows + c * n + j);
-#if defined(DPILQR_LS_SPLIT)   // timing experiment: two partial sums per control (another summation order)
-                        sum[c] += kr.x * dx2.x;
-                        sum2[c] += kr.y * dx2.y;
-#elif defined(DPILQR_LS_FMA)
-                        sum[c] = fma(kr.x, dx2.x, sum[c]);
-                        sum[c] = fma(kr.y, dx2.y, sum[c]);
-#else
                         sum[c] += kr.x * dx2.x;
                         sum[c] += kr.y * dx2.y;
-#endif
                     }
                 }
             } else {
@@ -401,10 +383,6 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
                     for (int c = 0; c < NC; ++c) sum[c] += rows[c * n + j] * dxj;
                 }
             }
-#ifdef DPILQR_LS_SPLIT
-#pragma unroll
-            for (int c = 0; c < NC; ++c) sum[c] += sum2[c];
-#endif
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double du = sum[c] + alpha * sd[a * NC + c];

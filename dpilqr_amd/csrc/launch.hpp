@@ -49,6 +49,14 @@ inline int32_t allow_lds(Kern kern, size_t bytes) {
 // compute units of the current device (256 on MI355X): the sweep deals its items over rounds of this many workgroups
 int device_cus();
 
+// A/B route switches and tuning knobs (DPILQR_NO_FUSED, DPILQR_MFMA_WAVES, DPILQR_BIG_TEAM, ...) exist for experiments and
+// tests.  They are honoured only in a process that sets DPILQR_DEBUG_ROUTES=1: without that gate route_env answers null for
+// every name, so a stray variable in a production process's environment cannot change which kernel serves a batch.  The gate and
+// the library's only getenv live in dpilqr_hip.hip.
+const char* route_env(const char* name);
+inline bool route_flag(const char* name) { return route_env(name) != nullptr; }
+inline int route_int(const char* name, int dflt) { const char* e = route_env(name); return (e && *e) ? atoi(e) : dflt; }
+
 // hints packed into dpilqr_batch_desc::uniform_model (include/dpilqr_hip.h): -1 = unknown / mixed
 inline int hint_model(const dpilqr_batch_desc& D) { return (D.uniform_model & 0xff) - 1; }
 inline int hint_n_dims(const dpilqr_batch_desc& D) { return ((D.uniform_model >> 8) & 0xff) - 1; }
@@ -58,7 +66,7 @@ inline bool hint_planar4(const dpilqr_batch_desc& D) { return ((D.uniform_model 
 // Wavefront sweep (n_x <= 20, riccati_mfma.hpp): DoubleIntDynamics4D agents only, planar proximity cost, one Q / R / Q_f for
 // every agent of every item (the descriptor's hints), at most five agents.
 inline bool fused_wavefront_sweep_applies(const dpilqr_batch_desc& D) {
-    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr;   // A/B switch: the record-fed sweep
+    static const bool off = route_flag("DPILQR_NO_FUSED");   // A/B switch: the record-fed sweep
     return !off && hint_model(D) == 0 && hint_n_dims(D) == 2 && hint_shared_weights(D) && D.Q_bstride == 0 && D.R_bstride == 0 &&
            D.Qf_bstride == 0 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
 }
@@ -66,21 +74,21 @@ inline bool fused_wavefront_sweep_applies(const dpilqr_batch_desc& D) {
 // DoubleIntDynamics4D and UnicycleDynamics4D, mixed or not (the descriptor's hints) -- with any per-agent, per-item Q / R / Q_f,
 // planar proximity cost.  Two wavefronts per SIMD at most (the per-agent weights take the LDS the third one needs).
 inline bool fused_wavefront_general_applies(const dpilqr_batch_desc& D) {
-    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_GENERAL") != nullptr;
+    static const bool off = route_flag("DPILQR_NO_FUSED") || route_flag("DPILQR_NO_FUSED_GENERAL");
     return !off && hint_planar4(D) && hint_n_dims(D) == 2 && D.n_s == 4 && D.n_c == 2 && D.k <= 5;
 }
 // Workgroup sweep (riccati_wg.hpp): 6..15 agents of the four-state family or 2..10 of the six-state family -- any models of
 // the family, any per-agent weights, any n_dims.
 inline bool fused_workgroup_sweep_applies(const dpilqr_batch_desc& D) {
-    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_FUSED_WG") != nullptr;
+    static const bool off = route_flag("DPILQR_NO_FUSED") || route_flag("DPILQR_NO_FUSED_WG");
     return !off && ((D.n_s == 4 && D.n_c == 2 && D.k >= 6 && D.k <= 15) || (D.n_s == 6 && D.n_c == 3 && D.k >= 2 && D.k <= 10));
 }
 // Wavefront sweep with in-sweep production (riccati_mfma.hpp, PNS; tu_inprod.hip): at most four agents of the six-state family
 // (n_x <= 24) or at most six CarDynamics3D agents (n_x <= 18) -- any models of the family, any per-agent weights, any n_dims --
 // padded into the next instantiated size.
 inline bool fused_wavefront_inprod_applies(const dpilqr_batch_desc& D) {
-    static const bool off = getenv("DPILQR_NO_FUSED") != nullptr || getenv("DPILQR_NO_INPROD") != nullptr;
-    static const bool no4 = getenv("DPILQR_NO_INPROD4") != nullptr;   // A/B switch: the four-state clusters' previous routes
+    static const bool off = route_flag("DPILQR_NO_FUSED") || route_flag("DPILQR_NO_INPROD");
+    static const bool no4 = route_flag("DPILQR_NO_INPROD4");   // A/B switch: the four-state clusters' previous routes
     if (off) return false;
     // ... and what is left of the four-state family at n_x <= 20: at most five agents WITHOUT the hints the forms above need (a
     // proximity cost over three dimensions, mixed models unannounced).  (Six agents, n_x = 24, keep the producer + the
@@ -102,11 +110,11 @@ inline bool fused_sweep_applies(const dpilqr_batch_desc& D) {
 // (four quadcopters) 2.67 against 1.01 + 0.88.  Whole solves of 2048 items: two quadcopters 24.3 -> 13.4 ms, four 26.7 -> 20.6,
 // six unicycles 86.2 -> 80.6, six double integrators 23.8 -> 21.3.  DPILQR_NO_WAVE_PREF: A/B switch.
 inline bool solve_prefers_records(const dpilqr_batch_desc& D) {
-    static const bool off = getenv("DPILQR_NO_WAVE_PREF") != nullptr;
+    static const bool off = route_flag("DPILQR_NO_WAVE_PREF");
     // round 4: three six-state agents (n_x = 18: 16 % of cfg4's sub-problems) through the (20, 10) wavefront sweep, padded
     // while loading (riccati_mfma.hpp, PAD; DPILQR_RICCATI_NO_PAD switches it off in the launcher)
     // (two .. four six-state agents: records unless the in-sweep producer serves them)
-    if (fused_wavefront_inprod_applies(D)) { static const bool rec = getenv("DPILQR_INPROD_RECORDS") != nullptr; return rec; }
+    if (fused_wavefront_inprod_applies(D)) { static const bool rec = route_flag("DPILQR_INPROD_RECORDS"); return rec; }
     return !off && ((D.n_s == 6 && D.n_c == 3 && (D.k == 2 || D.k == 3 || D.k == 4)) || (D.n_s == 4 && D.n_c == 2 && D.k == 6));
 }
 
@@ -172,7 +180,7 @@ int32_t launch_forward_big_f32(const dpilqr_batch_desc& D, int mode, const float
                                hipStream_t st);
 // the sweep's choice: clusters beyond the wavefront / workgroup sweeps (n_x > 60) take the fused big kernel
 inline bool uses_big_path(int n_x) {
-    static const bool force = getenv("DPILQR_FORCE_BIG") != nullptr;   // test / A-B switch: every size through tu_big.hip
+    static const bool force = route_flag("DPILQR_FORCE_BIG");   // test / A-B switch: every size through tu_big.hip
     return force || n_x > 60;
 }
 

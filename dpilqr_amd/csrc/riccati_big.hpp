@@ -128,24 +128,40 @@ struct BigLds {   // offsets in elements of R (all even)
 // the parts may sit on different XCDs, whose L2s are not coherent without it.
 // No hang by construction: helpers REPORT (a counter) when they start; the main workgroup decides at its first S5 whether all of
 // them have (mode 1: team) or not (mode 2: alone, exactly the single-workgroup pass -- helpers that arrive later leave at once), so
-// a chip busy with other work costs the speed-up, not the result; and every wait is bounded (a fault aborts the launch).
-struct BigTeam { int flag_k, done, joined, mode, done1; };     // one per item, zeroed by the launcher
-constexpr int kBigSpinMax = 1 << 22;
+// a chip busy with other work costs the speed-up, not the result; and every wait is bounded.
+// No abort either: a part whose wait expires GIVES UP -- it raises every counter of the team past any target (so every other
+// part's wait ends, as failed) and leaves; the main workgroup then marks the item (singular[b] = 2, which the line search turns
+// into DPILQR_STATUS_FAULT and dpilqr_solve_batch into DPILQR_EHIP; the gain offsets d of the item are NaN for callers of the bare
+// pass) and leaves too.  The launch ends normally and the HIP context stays usable (include/dpilqr_hip.h: "never aborts").
+struct BigTeam { int flag_k, done, joined, mode, done1; };     // five words per item, zeroed by the launcher
+constexpr int kBigSpinLog2 = 22;       // polls per wait before giving up (tests lower it: tu_big.hip, DPILQR_BIG_SPIN_LOG2)
+constexpr int kBigGaveUp = 1 << 30;    // a counter at or above this: some part of the team gave up
 
 __device__ __forceinline__ int big_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire fence.  false: gave up
-__device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok) {
+// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire fence.  false: the wait expired, or another
+// part gave up
+__device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok, int spin_log2) {
     if (threadIdx.x == 0) {
-        int it = 0, ok = 1;
-        while (big_ld(p) < target) {      // (relaxed: an acquire here invalidates the caches at every poll -- measured, 2 .. 5 x slower passes)
+        int it = 0, ok = 1, v;
+        while ((v = big_ld(p)) < target) {      // (relaxed: an acquire here invalidates the caches at every poll -- measured, 2 .. 5 x slower passes)
             __builtin_amdgcn_s_sleep(4);
-            if (++it > kBigSpinMax) { ok = 0; break; }
+            if ((++it >> spin_log2) != 0) { ok = 0; break; }
         }
+        if (v >= kBigGaveUp) ok = 0;
         *s_ok = ok;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (every wavefront drops what its caches hold of the other parts' data)
     return *s_ok != 0;
+}
+// a part gives up: every wait of the team, current or future, ends as failed; helpers that have not looked yet see mode 3 and leave
+__device__ __forceinline__ void big_give_up(BigTeam* team) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&team->flag_k, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->done, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->done1, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->mode, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <typename R>
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                                                              int32_t* __restrict__ singular,
                                                              const int32_t* __restrict__ items,
                                                              const int32_t* __restrict__ n_items, int gains_by_item,
-                                                             R* scratch_all, int n_slots, int nparts, int team_late) {
+                                                             R* scratch_all, int n_slots, int nparts, int team_dbg) {
     typedef typename Mfma<R>::acc_t acc_t;
     constexpr int NSC = NS + NC;
     // nparts > 1: workgroup x + 8 y is part y % nparts of slot x + 8 (y / nparts) -- workgroups are dealt to the eight XCDs in turn,
@@ -354,6 +370,16 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     const int tid = tid_p_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g16 = lane >> 4, c16 = lane & 15; \
     (void)wave; (void)g16; (void)c16; (void)lane;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)slot * S.total + S.oSync);
+    const int spin_log2 = (team_dbg >> 8) ? (team_dbg >> 8) : kBigSpinLog2;
+    // the main workgroup's way out when the team has failed: the item is marked (for callers of the bare pass, who hand over no
+    // `singular`: the first gain offset of the item is NaN), the launch goes on
+    auto gave_up = [&]() {
+        big_give_up(team);
+        if (threadIdx.x == 0) {
+            if (singular) singular[b] = 2;
+            dout[gslot * (int64_t)T * m] = (R)__builtin_nan("");
+        }
+    };
     // (the team also shares S1 where S1 is the matrix-pipe form -- twelve-state fp64, config 5; the vector forms of the other
     // instantiations keep it on the main workgroup: with the helper's copy of them the fp32 twelve-state kernel spilled 40 registers)
 #ifdef DPILQR_BIG_TEAM_S1_ALL
@@ -363,14 +389,14 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #endif
     int coop = 0;      // 1: this pass is run by the team
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
-        // (tests: DPILQR_BIG_TEAM_LATE makes the helpers report a few milliseconds late -- after the main workgroup's decision --
-        // which is what a chip busy with other work does to them: the pass must then be the single workgroup's)
-        if (team_late) for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(127);
+        // (tests: DPILQR_BIG_TEAM_LATE=1 makes the helpers report a few milliseconds late -- after the main workgroup's decision --
+        // which is what a chip busy with other work does to them: the pass must then be the single workgroup's; =2 makes them join
+        // and then never work -- fault injection: the main workgroup's first wait for them must expire into a status)
+        if ((team_dbg & 3) == 1) for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(127);
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (!big_wait_ge(&team->mode, 1, &sFlag[2])) {
-            __builtin_trap();     // (the main workgroup never decided: the launch is aborted, loudly)
-        }
-        if (big_ld(&team->mode) != 1) return;     // the main workgroup went ahead alone
+        if (!big_wait_ge(&team->mode, 1, &sFlag[2], spin_log2)) { big_give_up(team); return; }   // (the main workgroup never decided)
+        if (big_ld(&team->mode) != 1) return;     // the main workgroup went ahead alone (2), or the team gave up (3)
+        if ((team_dbg & 3) == 2) { big_wait_ge(&team->mode, 3, &sFlag[2], spin_log2 + 2); return; }   // (until the main workgroup has given up)
         if constexpr (kTeamS1) {     // w_ref (Q + Q^T): the helper's first stage is step T - 2's, the weights' own step has passed
             for (int e = threadIdx.x; e < k * NS * NS; e += kBigThreads) {
                 const int a = e / (NS * NS), r = e - a * NS * NS, li = r / NS, lj = r - li * NS;
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             if (kTeamS1 && t < T - 1) {
                 // S1 of this step with the team (the first step's ran before the team was decided): P of the previous step is
                 // complete when EVERY part has added itself to `done`; then the step's plugin data, as on the main workgroup
-                if (!big_wait_ge(&team->done, (T - 1 - t) * nparts, &sFlag[2])) __builtin_trap();
+                if (!big_wait_ge(&team->done, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
                 stage_step(t, false);
                 __syncthreads();
                 {
@@ -393,9 +419,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2])) {
-                __builtin_trap();
-            }
+            if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
             {
                 const int part_ = part, nparts_ = nparts;
 #include "riccati_big_pairs.inc"
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (!big_wait_ge(&team->done1, (T - 1 - t) * nparts, &sFlag[2])) __builtin_trap();
+            if (!big_wait_ge(&team->done1, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
             for (int e = threadIdx.x; e < m * m; e += kBigThreads) {
                 const int a = e / m, c = e - a * m;
                 sLU[a * ldlu + c] = gQuu[(int64_t)a * mk + c];
@@ -864,9 +888,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2])) {
-                __builtin_trap();
-            }
+            if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         }
         __syncthreads();
         for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];

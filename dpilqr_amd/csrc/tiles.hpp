@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void k_make_tiles(dpilqr_batch_desc D, const do
 // steps per wavefront: as many as fit ~48 KB of LDS, at most 8
 inline int make_tiles_steps(int k, int ns, int nc) {
     const int per_t = make_tiles_lds_doubles(k, ns, nc);
-    static const int cap = getenv("DPILQR_TILES_STEPS") ? atoi(getenv("DPILQR_TILES_STEPS")) : 8;   // tuning knob
+    static const int cap = route_int("DPILQR_TILES_STEPS", 8);   // tuning knob
     int ts = (48 * 1024 / 8) / per_t;
     return ts < 1 ? 1 : (ts > cap ? cap : ts);
 }

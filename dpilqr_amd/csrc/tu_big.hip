@@ -26,21 +26,21 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
     int nparts = 1;
 #ifndef DPILQR_BIG_S5_SEPARATE
     {
-        static const int cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-            return v;
-        }();
+        const int cus = device_cus();      // of the CURRENT device (remembered per device id)
         const int tn = (n + 1 + 15) / 16, npair = tn * (tn + 1) / 2, waves = kBigThreads / 64;
         const int slots8 = ((grid_items + 7) / 8) * 8;
         nparts = (npair + waves - 1) / waves;
         if (nparts > cus / slots8) nparts = cus / slots8;
-        const char* e = std::getenv("DPILQR_BIG_TEAM");
+        // (a debug route: null in a process without DPILQR_DEBUG_ROUTES=1, where nothing is read from the environment here; with
+        // the gate open the tests switch it from launch to launch)
+        const char* e = route_env("DPILQR_BIG_TEAM");
         if (e && *e) { const int v = std::atoi(e); nparts = v <= 0 ? 1 : (v < nparts ? v : nparts); }
         if (nparts < 2) nparts = 1;
     }
 #endif
-    const int team_late = std::getenv("DPILQR_BIG_TEAM_LATE") != nullptr;     // tests: see the kernel
+    // tests (gated like every route switch): DPILQR_BIG_TEAM_LATE=1 helpers report late, =2 helpers join and then stall (fault
+    // injection); DPILQR_BIG_SPIN_LOG2=s bounds every wait at 2^s polls instead of 2^22 -- packed into one kernel argument
+    const int team_dbg = (route_int("DPILQR_BIG_TEAM_LATE", 0) & 3) | ((route_int("DPILQR_BIG_SPIN_LOG2", 0) & 31) << 8);
     const int grid = nparts > 1 ? ((grid_items + 7) / 8) * 8 * nparts : grid_items;
     if (nparts > 1)
         hipLaunchKernelGGL((k_big_team_reset<R>), dim3((grid_items + 255) / 256), dim3(256), 0, st, static_cast<R*>(scratch),
@@ -49,7 +49,7 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
         int32_t rc = allow_lds(k_riccati_big<R, NS, NC>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((k_riccati_big<R, NS, NC>), dim3(grid), dim3(kBigThreads), lds, st, D, X, U, mu, K, d,
-                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch), grid_items, nparts, team_late);
+                           singular, items, n_items, gains_by_item, static_cast<R*>(scratch), grid_items, nparts, team_dbg);
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;

@@ -15,7 +15,7 @@ static int forward_threads(int k, int ngrp) {
     return t;
 }
 
-static bool no_wave_ro() { static const bool v = getenv("DPILQR_FORWARD_GENERIC") != nullptr; return v; }
+static bool no_wave_ro() { static const bool v = route_flag("DPILQR_FORWARD_GENERIC"); return v; }
 
 int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, double* X, double* U, const double* K,
                        const double* d, const double* alphas, int ngrp, double* Xc, double* Uc, double* Jc,
@@ -63,7 +63,7 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
     }
     // one solver iteration's line search for a batch of ONE model whose candidates fit a wavefront: the kernels
     // compiled for (model, agents), see forward_wave.hpp
-    static const bool no_wave = getenv("DPILQR_FORWARD_GENERIC") != nullptr;   // A/B switch
+    static const bool no_wave = route_flag("DPILQR_FORWARD_GENERIC");   // A/B switch
     if (!no_wave && mode == kModeLineSearch && hint_model(D) >= 0 && ngrp == DPILQR_N_ALPHA && items && n_items) {
         const int model = hint_model(D);
         {   // launches of at most one item per SIMD: two wavefronts per item, rollout and costs (tu_lsteam.hip)
@@ -104,7 +104,7 @@ int32_t launch_forward(const dpilqr_batch_desc& D, int mode, const double* x0, d
 #undef DPILQR_TRY_WAVE
     }
     // single-wave sub-problems are packed four to a workgroup (one wave per SIMD), see forward.hpp
-    static const bool no_pack = getenv("DPILQR_FORWARD_NO_PACK") != nullptr;   // diagnostic switch
+    static const bool no_pack = route_flag("DPILQR_FORWARD_NO_PACK");   // diagnostic switch
     const int ipb = (!no_pack && threads == 64 && 4 * lds_item <= (size_t)kMaxLds) ? 4 : 1;
     const size_t lds = lds_item * ipb;
     threads *= ipb;

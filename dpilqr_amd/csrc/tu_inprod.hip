@@ -16,7 +16,7 @@ int32_t launch_riccati_inprod(const dpilqr_batch_desc& D, const double* X, const
                               hipStream_t st) {
     if (grid_items <= 0 || !fused_wavefront_inprod_applies(D)) return DPILQR_EUNSUPPORTED;
     const int n = D.k * D.n_s, m = D.k * D.n_c;
-    static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 8;
+    static const int max_wv = route_int("DPILQR_MFMA_WAVES", 8);
     const int cus = device_cus();
 #define DPILQR_TRY_INPROD(NN, MM, PNS_)                                                                            \
     if (D.n_s == PNS_ && n <= NN && m <= MM) {                                                                     \

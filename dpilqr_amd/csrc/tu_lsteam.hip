@@ -14,8 +14,8 @@ namespace dpilqr {
 int32_t launch_linesearch_team(const dpilqr_batch_desc& D, double* X, double* U, const double* K, const double* d,
                                const double* alphas, double* Xc, double* Uc, const SolveState& S, const int32_t* items,
                                const int32_t* n_items, int grid_items, hipStream_t st) {
-    static const bool off = getenv("DPILQR_LS_NO_TEAM") != nullptr;   // A/B switch
-    static const int max_items = getenv("DPILQR_LS_TEAM_MAX") ? atoi(getenv("DPILQR_LS_TEAM_MAX")) : 1024;
+    static const bool off = route_flag("DPILQR_LS_NO_TEAM");   // A/B switch
+    static const int max_items = route_int("DPILQR_LS_TEAM_MAX", 1024);
     if (off || grid_items > max_items || grid_items <= 0 || hint_model(D) < 0) return DPILQR_EUNSUPPORTED;
     const int model = hint_model(D);
 #define DPILQR_TRY_LSTEAM(MODEL, KA)                                                                                \

@@ -27,18 +27,18 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     if (grid_items <= 0) return DPILQR_OK;
     // block_ns > 0: the caller guarantees that [A|B] is block diagonal with block_ns x (block_ns + block_nc) blocks
     // (tiles made by k_make_tiles from a MultiDynamicalModel); 0: arbitrary dense tiles (the plugin boundary).
-    static const bool no_bd = getenv("DPILQR_RICCATI_DENSE") != nullptr;   // A/B switch
+    static const bool no_bd = route_flag("DPILQR_RICCATI_DENSE");   // A/B switch
     const bool bd = !no_bd && block_ns == 4 && block_nc == 2 && n == 4 * (m / 2) && m % 2 == 0;
     // sweep selection: matrix-pipe kernel where instantiated, else the vector-pipe tiled kernel, else the generic one
     // (DPILQR_RICCATI=mfma|tiled|generic pins one for A/B measurements)
-    static const char* pick_env = getenv("DPILQR_RICCATI");
-    static const int pick = getenv("DPILQR_FORCE_GENERIC_RICCATI") ? 2
+    static const char* pick_env = route_env("DPILQR_RICCATI");
+    static const int pick = route_flag("DPILQR_FORCE_GENERIC_RICCATI") ? 2
                             : (!pick_env ? 0 : (!strcmp(pick_env, "tiled") ? 1 : (!strcmp(pick_env, "generic") ? 2 : 0)));
     if (pick == 0) {
 #define DPILQR_TRY_MFMA(NN, MM)                                                                                    \
     if (n == NN && m == MM) {                                                                                      \
         static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
-        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;            \
+        static const int max_wv = route_int("DPILQR_MFMA_WAVES", 12);            \
         /* wavefronts per workgroup = per CU: 4 (one per SIMD), 8, or 12 when the launch has the items for them */  \
         const int wv = (bd && grid_items > 2048 && max_wv >= 12 && MfmaCfg<NN, MM>::total * 8 * 12 <= kMaxLds) ? 12 \
                        : ((grid_items > 1024 && max_wv >= 8) ? 8 : 4);                                              \
@@ -63,7 +63,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
 #undef DPILQR_TRY_MFMA
         if (n == 24 && m == 12) {   // the all-MFMA (dense) instantiation only: the block-diagonal lane mapping stops at five agents
             static_assert(MfmaCfg<24, 12>::supported, "MFMA sweep not available for this size");
-            static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 8;
+            static const int max_wv = route_int("DPILQR_MFMA_WAVES", 8);
             const int wv = (grid_items > 1024 && max_wv >= 8) ? 8 : 4;
             g_sweep_waves = wv;
             const size_t lds_t = sizeof(double) * MfmaCfg<24, 12>::total * wv;
@@ -83,13 +83,13 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
     // instantiated size, which pads the records while loading them and stores the real block of the gains
     // (riccati_mfma.hpp, PAD).  Before: the workgroup sweep or the generic kernel -- slower than clusters twice the size
     // (profiles/r03_small_clusters.txt: three quadcopters 1.85 ms per 2048 items against 0.89 ms for four).
-    static const bool no_pad = getenv("DPILQR_RICCATI_NO_PAD") != nullptr;   // A/B switch
+    static const bool no_pad = route_flag("DPILQR_RICCATI_NO_PAD");   // A/B switch
     // (not two twelve-state agents: n_u = 8 padded to 12 is slower than their workgroup sweep, 1.72 against 1.51 ms per 512 items)
     if (pick == 0 && !no_pad && n <= 24 && m <= 12 && !(block_ns == 12 && n == 24)) {
 #define DPILQR_TRY_PAD(NN, MM)                                                                                     \
     if (n <= NN && m <= MM) {                                                                                      \
         static_assert(MfmaCfg<NN, MM>::supported, "MFMA sweep not available for this size");                       \
-        static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 8;             \
+        static const int max_wv = route_int("DPILQR_MFMA_WAVES", 8);             \
         const int wv = (grid_items > 1024 && max_wv >= 8) ? 8 : 4;                                                 \
         g_sweep_waves = wv;                                                                                        \
         const size_t lds_t = sizeof(double) * MfmaCfg<NN, MM>::total * wv;                                        \
@@ -108,7 +108,7 @@ int32_t launch_riccati(int B, int T, int n, int m, const double* tiles, const do
 #undef DPILQR_TRY_PAD
     }
     // larger clusters of the library's own (block-diagonal) tiles: one workgroup per sub-problem, riccati_wg.hpp
-    static const bool no_wg = getenv("DPILQR_RICCATI_NO_WG") != nullptr;   // A/B switch
+    static const bool no_wg = route_flag("DPILQR_RICCATI_NO_WG");   // A/B switch
     if (pick == 0 && !no_wg && block_ns > 0) {
 #define DPILQR_TRY_WG(KK, NS_, NC_)                                                                                 \
     if (block_ns == NS_ && block_nc == NC_ && n == KK * NS_ && m == KK * NC_) {                                     \
@@ -169,7 +169,7 @@ int32_t launch_riccati_fused(const dpilqr_batch_desc& D, const double* X, const 
     g_sweep_waves = 0;
     if (grid_items <= 0) return DPILQR_OK;
     const int n = D.k * D.n_s, m = D.k * D.n_c;
-    static const int max_wv = getenv("DPILQR_MFMA_WAVES") ? atoi(getenv("DPILQR_MFMA_WAVES")) : 12;
+    static const int max_wv = route_int("DPILQR_MFMA_WAVES", 12);
 #define DPILQR_TRY_FUSED(NN, MM)                                                                                   \
     if (n == NN && m == MM) {                                                                                      \
         using CF = MfmaCfg<NN, MM, true>;                                                                          \

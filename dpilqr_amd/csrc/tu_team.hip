@@ -16,7 +16,7 @@ namespace dpilqr {
 int32_t launch_riccati_team(const dpilqr_batch_desc& D, const double* X, const double* U, const double* mu, double* K, double* d,
                             int32_t* singular, const int32_t* items, const int32_t* n_items, int grid_items, int gains_by_item,
                             hipStream_t st) {
-    static const bool off = getenv("DPILQR_NO_TEAM") != nullptr;   // A/B switch
+    static const bool off = route_flag("DPILQR_NO_TEAM");   // A/B switch
     if (off || grid_items <= 0) return DPILQR_EUNSUPPORTED;
     const int n = D.k * D.n_s, m = D.k * D.n_c;
     const int cus = device_cus();

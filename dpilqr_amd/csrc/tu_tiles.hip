@@ -13,13 +13,13 @@ int32_t launch_make_tiles(const dpilqr_batch_desc& D, const double* X, const dou
                           const int32_t* items, const int32_t* n_items, int grid_items, bool sparse, bool dyn_only,
                           hipStream_t st) {
     if (grid_items <= 0) return DPILQR_OK;
-    static const bool force_dense = getenv("DPILQR_TILES_DENSE") != nullptr;   // A/B switch
+    static const bool force_dense = route_flag("DPILQR_TILES_DENSE");   // A/B switch
     if (force_dense) sparse = false;
     if (!sparse) dyn_only = false;
     // the solve loop's producer for a batch of one linear model whose (X, U)-independent entries are already in place:
     // kernels compiled per (model, agents), tiles_wave.hpp.  (Measured: for the other cases -- A, B to be written too,
     // or more than 6 agents -- the generic producer's sparse stores are the faster ones.)
-    static const bool no_wave = getenv("DPILQR_TILES_GENERIC") != nullptr;   // A/B switch
+    static const bool no_wave = route_flag("DPILQR_TILES_GENERIC");   // A/B switch
     if (sparse && dyn_only && !no_wave && hint_model(D) >= 0) {
         const int model = hint_model(D);
         // rows of L_xx beyond the proximity cost's dimensions hold w_ref (Q + Q^T) only: with one Q, Q_f for the batch they

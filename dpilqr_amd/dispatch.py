@@ -87,10 +87,12 @@ def device_constants(d, kc=None):
     batch per round and per cluster size, and six small uploads per batch were a tenth of the Monte-Carlo study's time."""
     kc = d["k"] if kc is None else int(kc)
     cache = d.setdefault("_dev", {})
+    kc = (torch.cuda.current_device(), kc)      # (the tensors live on ONE device: a process that moves to another gets its own copies)
     if kc not in cache:
-        cache[kc] = dict(model=to_dev(d["model"][:kc], torch.int32), n_dims=to_dev(d["n_dims"][:kc], torch.int32),
-                         Q=to_dev(d["Q"][:kc]), R=to_dev(d["R"][:kc]), Qf=to_dev(d["Qf"][:kc]),
-                         word=ProblemBatch.hint_word(d["model"][:kc], d["n_dims"][:kc], d["Q"][:kc], d["R"][:kc], d["Qf"][:kc]))
+        n_ = kc[1]
+        cache[kc] = dict(model=to_dev(d["model"][:n_], torch.int32), n_dims=to_dev(d["n_dims"][:n_], torch.int32),
+                         Q=to_dev(d["Q"][:n_]), R=to_dev(d["R"][:n_]), Qf=to_dev(d["Qf"][:n_]),
+                         word=ProblemBatch.hint_word(d["model"][:n_], d["n_dims"][:n_], d["Q"][:n_], d["R"][:n_], d["Qf"][:n_]))
     return cache[kc]
 
 

@@ -10,8 +10,10 @@
  *
  * Conventions
  *   - plain C: pointers + sizes, no C++/torch types.  Every entry point returns 0 on success or a
- *     negative DPILQR_E* code and never throws or aborts; dpilqr_last_error() holds the message of
- *     the calling thread's last failure.
+ *     negative DPILQR_E* code and never throws or aborts -- on the host or on the device: no kernel of the
+ *     library traps; dpilqr_last_error() holds the message of the calling thread's last failure.
+ *   - the environment does not steer the library: the A/B route switches of its experiments (DPILQR_NO_FUSED,
+ *     DPILQR_MFMA_WAVES, DPILQR_BIG_TEAM, ...) are ignored unless the process sets DPILQR_DEBUG_ROUTES=1.
  *   - every data pointer is a DEVICE pointer owned by the caller (torch.Tensor.data_ptr()); nothing is
  *     allocated behind the caller's back.  Workspace sizes come from *_workspace_bytes.  The one piece of
  *     host-side state -- the pinned mailbox and events through which the synchronous solve follows the device --
@@ -35,13 +37,14 @@
 extern "C" {
 #endif
 
-#define DPILQR_ABI_VERSION 3   /* 3: t_kill in dpilqr_solve_batch[_f32] / dpilqr_solve_enqueue, DPILQR_STATUS_KILLED */
+#define DPILQR_ABI_VERSION 4   /* 3: t_kill in dpilqr_solve_batch[_f32] / dpilqr_solve_enqueue, DPILQR_STATUS_KILLED
+                                  4: DPILQR_STATUS_FAULT; route switches honoured only under DPILQR_DEBUG_ROUTES=1 */
 
 /* error codes */
 #define DPILQR_OK 0
 #define DPILQR_EINVAL (-1)     /* bad argument (null pointer, size out of range, unknown model)   */
 #define DPILQR_EUNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. n_x too large)   */
-#define DPILQR_EHIP (-3)       /* a HIP runtime call failed                                       */
+#define DPILQR_EHIP (-3)       /* a HIP runtime call failed, or a kernel gave an item up (STATUS_FAULT)  */
 #define DPILQR_ENOGPU (-4)     /* no usable gfx950 device                                         */
 #define DPILQR_EWORKSPACE (-5) /* workspace too small                                             */
 
@@ -69,6 +72,12 @@ extern "C" {
 #define DPILQR_STATUS_SINGULAR 4          /* exactly zero pivot in Q_uu (np.linalg.solve would raise) */
 #define DPILQR_STATUS_KILLED 5            /* t_kill: the item's own solve time ran out after an accepted, not yet
                                              converged iteration, control.py:213-218; X, U = that accepted iterate   */
+#define DPILQR_STATUS_FAULT 6             /* the device gave this item up: a hand-over inside a team of workgroups (n_x > 60 with
+                                             fewer items than CUs) did not arrive within its bound.  No gains exist for the
+                                             iteration; X, U = the last accepted iterate.  dpilqr_solve_batch[_f32] then returns
+                                             DPILQR_EHIP with the count in dpilqr_last_error(); the other items' results are
+                                             valid and the HIP context stays usable.  Should not occur (a helper that joined a
+                                             team is resident); it replaces what used to be a device-side abort.          */
 
 #define DPILQR_N_ALPHA 10 /* ilqrSolver.N_LS_ITER, control.py:51 */
 
@@ -215,6 +224,11 @@ int32_t dpilqr_alphas(double* alphas_host);
  *   just accepted (so every item runs at least one iteration, as in the reference, and J/X/U are exactly what a solve
  *   with n_lqr_iter = n_bwd[item] returns).  The decision is taken on the device: no host read, no launch-ahead lag,
  *   and dpilqr_solve_enqueue honours it as well.
+ *   CONSEQUENCE of a shared device: the item's elapsed time is device wall time from its admission, and every launch it
+ *   takes part in also carries up to `window` other items -- the clock includes their work.  Which items are killed
+ *   therefore depends on B, `window` and whatever else the GPU runs, and differs from run to run; it is not the set the
+ *   reference would kill (one solve alone on a CPU core), and studies run with t_kill cannot be compared row by row with
+ *   the reference's.  n_lqr_iter is the deterministic budget (a KILLED item equals the n_lqr_iter = n_bwd solve).
  * workspace: dpilqr_solve_workspace_bytes(desc, window, K_out == NULL) bytes of device memory.           */
 int64_t dpilqr_solve_workspace_bytes(const dpilqr_batch_desc* desc, int32_t window, int32_t gains_in_workspace);
 /* Host-side state of the synchronous solve: a pinned mailbox (a few words the device posts its active-list counters

@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--arm":
 import numpy as np
 Bs = sys.argv[1:] or ["1", "4", "32"]
 res = {}
-for arm, env in (("team", {}), ("alone", {"DPILQR_BIG_TEAM": "0"})):
+for arm, env in (("team", {}), ("alone", {"DPILQR_DEBUG_ROUTES": "1", "DPILQR_BIG_TEAM": "0"})):
     f = f"/tmp/big_team_{arm}.npz"
     subprocess.run([sys.executable, __file__, "--arm", f, *Bs], check=True, env={**os.environ, **env}, timeout=600)
     res[arm] = np.load(f)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # An A/B build of the WHOLE library with other compiler flags (e.g. -ffp-contract=fast): every translation unit recompiled.
-#   bash scripts/build_all_variant.sh <tag> <flags ...>   ->  dpilqr_amd/variants/libdpilqr_hip_<tag>.so   (select with DPILQR_LIB)
+#   bash scripts/build_all_variant.sh <tag> <flags ...>   ->  dpilqr_amd/variants/libdpilqr_hip_<tag>.so   (select with DPILQR_DEBUG_ROUTES=1 DPILQR_LIB=...)
 # The given flags come after the library's own, so a repeated option (-ffp-contract=...) overrides it.
 set -e
 tag=$1; shift

@@ -1,7 +1,7 @@
 #!/bin/bash
 # An A/B build of the library: one translation unit recompiled with extra flags, linked with the current objects of the others.
 #   bash scripts/build_variant.sh <tag> <unit (e.g. tu_forward)> <flags ...>   ->  dpilqr_amd/variants/libdpilqr_hip_<tag>.so
-# Select it at run time with DPILQR_LIB=$PWD/dpilqr_amd/variants/libdpilqr_hip_<tag>.so (dpilqr_amd/_lib.py).  The directory is
+# Select it at run time with DPILQR_DEBUG_ROUTES=1 DPILQR_LIB=$PWD/dpilqr_amd/variants/libdpilqr_hip_<tag>.so (dpilqr_amd/_lib.py).  The directory is
 # git-ignored but travels to the GPU box.
 set -e
 tag=$1; unit=$2; shift 2

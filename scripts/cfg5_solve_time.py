@@ -30,6 +30,6 @@ if "--arm" in sys.argv:
               f"{1e3 * t / max(nb, 1):6.1f} ms per iteration, status {int(r['status'][0])}, J {float(r['J'][0]):.6g}", flush=True)
     sys.exit(0)
 iters = sys.argv[1] if len(sys.argv) > 1 else "8"
-for name, env in (("team of workgroups (default)", {}), ("single workgroup (DPILQR_BIG_TEAM=0)", {"DPILQR_BIG_TEAM": "0"})):
+for name, env in (("team of workgroups (default)", {}), ("single workgroup (DPILQR_BIG_TEAM=0)", {"DPILQR_DEBUG_ROUTES": "1", "DPILQR_BIG_TEAM": "0"})):
     print(f"== {name}", flush=True)
     subprocess.run([sys.executable, __file__, "--arm", iters], check=True, env={**os.environ, **env}, timeout=600)

@@ -10,6 +10,9 @@ GOLDEN = ROOT / "tests" / "golden"
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the library ignores its A/B route switches (DPILQR_BIG_TEAM, DPILQR_FORCE_BIG, ...) unless this gate is open; the tests that
+# compare routes need them (csrc/launch.hpp: route_env).  The gate is read once, at the library's first launch.
+os.environ.setdefault("DPILQR_DEBUG_ROUTES", "1")
 
 
 def pytest_configure(config):

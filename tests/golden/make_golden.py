@@ -23,6 +23,8 @@ Manifest:
                      solve_subproblem
   g9_chaos_*.npz     the reference on items the GPU decides differently from the oracle: x0 and 32 perturbed copies
                      (python tests/golden/make_golden.py g9; needs gpurun_out/flips/ from scripts/find_flips.py)
+  g10_harness.npz    the Monte-Carlo harness itself: the reference's scripts/analysis.py::multi_agent_run run as it is on a
+                     seeded stream (both branches; the distributed one through ignore_ids=[] as in G7): the draws and the rows
   g8_hetero_*.npz    the zero-padded human model (12 states / 4 controls) mixed with Quadcopter12D: a shim class
                      built from reference calls (the reference itself cannot mix 12- and 6-state agents)
 
@@ -673,11 +675,89 @@ def g9_chaos(flips_dir=None):
               f"max trajectory spread among members {dX.max():.2e}", flush=True)
 
 
+# --------------------------------------------------------------------------- G10
+def g10_harness():
+    """The Monte-Carlo harness itself (scripts/analysis.py:35-107): the REAL multi_agent_run, imported from where it lies and run
+    unmodified on a seeded global stream, for a few (model, team size, trial) cells.  Stored per trial: the seed, every draw of
+    the trial in the order the reference makes it -- (x0, xf) of random_setup, the centralized branch's warm start, the
+    distributed branch's (captured from np.random.rand itself, not re-derived) -- both branches' returned trajectories, and the
+    rows the reference logs.
+
+    One shim, the same as G7's: the distributed branch of the reference as shipped raises (quirk Q9: multi_agent_run passes no
+    ignore_ids and solve_distributed's default None is not iterable), so `solve_rhc` as seen by the analysis module appends
+    ignore_ids=[] to the positional arguments of the distributed call.  Nothing else is touched: loop order, RNG consumption,
+    weights, ids, STEP_SIZE and the logging are the reference's own code running."""
+    import importlib.util
+    import logging
+    spec = importlib.util.spec_from_file_location("ref_scripts_analysis", REF / "scripts" / "analysis.py")
+    ana = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ana)
+    real_rhc = ana.solve_rhc
+    multi_agent_run_ret = {}
+
+    def rhc_q9(problem, x0, N, *args, centralized=True, **kw):
+        a = tuple(args) if centralized else tuple(args) + ([],)
+        r = real_rhc(problem, x0, N, *a, centralized=centralized, **kw)
+        multi_agent_run_ret[bool(centralized)] = r
+        return r
+
+    ana.solve_rhc = rhc_q9
+    models = [dp.DoubleIntDynamics4D, dp.UnicycleDynamics4D, dp.QuadcopterDynamics6D]        # analysis.py:133-137
+    log = logging.getLogger(); log.setLevel(logging.INFO)
+    out = {}
+    dt, N, radius, energy, seed0 = 0.1, 20, 0.5, 10.0, 4
+    kw = dict(t_kill=None, dist_converge=0.1, t_diverge=3.0)
+    cells = [(dp.DoubleIntDynamics4D, 3, (0, 1)), (dp.UnicycleDynamics4D, 4, (0, 2)), (dp.QuadcopterDynamics6D, 3, (1,))]
+    tags = []
+    real_rand = np.random.rand
+    for model, n_agents, trials in cells:
+        n_d = 3 if model is dp.QuadcopterDynamics6D else 2
+        n_states = model(-1).n_x
+        for i_trial in trials:
+            # the harness's documented seed of a trial (dpilqr_amd/analysis.py: seed_of), restated here
+            seed = seed0 + 100003 * models.index(model) + 1009 * n_agents + i_trial
+            tag = f"{model.__name__}_{n_agents}_{i_trial}"
+            drawn = []
+
+            def recording_rand(*shape):
+                v = real_rand(*shape)
+                drawn.append(np.array(v))
+                return v
+
+            h = _Rows(); log.addHandler(h)
+            np.random.seed(seed)
+            np.random.rand = recording_rand
+            try:
+                with redirect_stdout(io.StringIO()):
+                    ana.multi_agent_run(model, [n_states] * n_agents, dt, N, radius, n_d=n_d, energy=energy, i_trial=i_trial,
+                                        verbose=False, **kw)
+            finally:
+                np.random.rand = real_rand
+                log.removeHandler(h)
+            after = np.random.get_state()[1][:4].copy()        # where the trial left the stream
+            warm = [v for v in drawn if v.shape == (N, n_agents * model(-1).n_u)]
+            assert len(warm) == 2, [v.shape for v in drawn]
+            np.random.seed(seed)
+            x0, xf = dp.random_setup(n_agents, n_states, is_rotation=False, rel_dist=n_agents, var=n_agents / 2, n_d=n_d,
+                                     random=True, energy=energy)        # (the trial's first draw, made again for the record)
+            (Xc, Uc, Jc), (Xd, Ud, Jd) = multi_agent_run_ret[True], multi_agent_run_ret[False]
+            assert np.array_equal(Xc[0], x0.ravel()) and np.array_equal(Xd[0], x0.ravel())
+            out.update({f"{tag}_seed": np.array(seed), f"{tag}_x0": x0, f"{tag}_xf": xf, f"{tag}_U_c": warm[0] * 0.01,
+                        f"{tag}_U_d": warm[1] * 0.01, f"{tag}_rows": np.array(h.rows), f"{tag}_Xc": Xc, f"{tag}_Uc": Uc,
+                        f"{tag}_Jc": np.array(Jc), f"{tag}_Xd": Xd, f"{tag}_Ud": Ud, f"{tag}_Jd": np.array(Jd),
+                        f"{tag}_stream_after": after})
+            tags.append(tag)
+            print(f"g10 {tag}: seed {seed}, {len(h.rows)} rows, Jc {Jc:.6g}, Jd {Jd:.6g}", flush=True)
+    out.update(tags=np.array(tags), dt=np.array(dt), N=np.array(N), radius=np.array(radius), energy=np.array(energy),
+               seed0=np.array(seed0), dist_converge=np.array(kw["dist_converge"]), t_diverge=np.array(kw["t_diverge"]))
+    np.savez_compressed(OUT / "g10_harness.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         print("generating", w, flush=True)
         {"g1": g1_models, "g2": g2_costs, "g3": g3_passes, "g4": g4_solves,
-         "g5": g5_dispatch, "g6": g6_scenarios, "g7": g7_callers, "g8": g8_hetero, "g9": g9_chaos}[w]()
+         "g5": g5_dispatch, "g6": g6_scenarios, "g7": g7_callers, "g8": g8_hetero, "g9": g9_chaos, "g10": g10_harness}[w]()
     for f in sorted(OUT.glob("*.npz")):
         print(f"{f.name:40s} {f.stat().st_size/1024:8.1f} KiB")

@@ -33,7 +33,7 @@ def test_every_symbol_exported(lib):
     L = lib.load()
     for name in declared_symbols():
         assert hasattr(L, name), f"{name} declared in dpilqr_hip.h but not exported"
-    assert L.dpilqr_abi_version() == 3
+    assert L.dpilqr_abi_version() == 4
 
 
 def test_host_only_entry_points(lib):
@@ -70,3 +70,52 @@ def test_no_gpu_means_loud_failure(lib):
     import dpilqr_amd as dp
     with pytest.raises(lib.DpilqrError):      # product code has no CPU fallback
         dp.DoubleIntDynamics4D(0.1, 100)(np.zeros(4), np.zeros(2))
+
+
+def test_route_switches_are_ignored_without_the_debug_gate(lib):
+    """A stray DPILQR_* variable in a production process's environment must not change which kernel serves a batch
+    (csrc/launch.hpp: route_env; the library's only getenv is behind DPILQR_DEBUG_ROUTES=1).  Observable without a GPU: the
+    solve's workspace is sized for the route -- tile records for the record-fed sweep, none for the fused sweep (DPILQR_NO_FUSED
+    flips that), the large-cluster sweep's scratch for DPILQR_FORCE_BIG."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys; sys.path.insert(0, %r)\n"
+        "from dpilqr_amd import _lib\n"
+        "L = _lib.load()\n"
+        # cfg2's hinted descriptor: five DoubleIntDynamics4D agents, planar, shared weights (batch.py packs the hints the same way)
+        "d = _lib.BatchDesc(64, 5, 4, 2, 50, 1 | (3 << 8) | (1 << 16) | (1 << 17), 0.1, 1.0, 200.0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0)\n"
+        "print(L.dpilqr_solve_workspace_bytes(C.byref(d), 64, 1), _lib.LIB_PATH)\n" % str(ROOT))
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("DPILQR_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        nbytes, path = out.stdout.split()
+        return int(nbytes), path
+
+    plain, path = run()
+    assert path.endswith("dpilqr_amd/libdpilqr_hip.so")
+    # without the gate: every switch ignored, the binding's library override too
+    assert run(DPILQR_NO_FUSED="1") == (plain, path)
+    assert run(DPILQR_FORCE_BIG="1") == (plain, path)
+    assert run(DPILQR_LIB="/nonexistent/libx.so") == (plain, path)
+    assert run(DPILQR_DEBUG_ROUTES="0", DPILQR_NO_FUSED="1") == (plain, path)
+    # with it: the record-fed route needs its tile records, the large-cluster route its scratch
+    assert run(DPILQR_DEBUG_ROUTES="1", DPILQR_NO_FUSED="1")[0] > plain
+    assert run(DPILQR_DEBUG_ROUTES="1", DPILQR_FORCE_BIG="1")[0] != plain
+
+
+def test_no_environment_reads_outside_the_gate():
+    """`grep getenv csrc/` shows one gate: dpilqr_hip.hip's route_env."""
+    hits = []
+    for f in sorted(p for p in (ROOT / "dpilqr_amd" / "csrc").iterdir() if p.is_file()):
+        for i, line in enumerate(f.read_text().splitlines(), 1):
+            code_part = line.split("//")[0]
+            if "getenv" in code_part:
+                hits.append((f.name, i))
+    assert hits and all(name == "dpilqr_hip.hip" for name, _ in hits) and len(hits) == 2, hits
+    for f in sorted(p for p in (ROOT / "dpilqr_amd" / "csrc").iterdir() if p.is_file()):
+        assert "__builtin_trap" not in f.read_text(), f.name       # include/dpilqr_hip.h: "never throws or aborts"

@@ -55,7 +55,7 @@ def test_same_symbols_and_never_a_device(twin):
     L, _lib = twin
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert L.dpilqr_abi_version() == 3
+    assert L.dpilqr_abi_version() == 4
     arch = C.create_string_buffer(32)
     assert L.dpilqr_device_info(0, None, None, arch, 32) == _lib.ENOGPU and arch.value == b"cpu-twin"
     assert L.dpilqr_solve_enqueue(*([None] * 3), 0, 0.0, 0.0, 0, None, 0, *([None] * 8), 0, 0, None) == _lib.EUNSUPPORTED

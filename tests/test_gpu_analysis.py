@@ -1,6 +1,7 @@
-"""The batched Monte-Carlo harness (dpilqr_amd/analysis.py; reference: scripts/analysis.py:35-174): its CSV equals, row
-for row, what per-trial solve_rhc runs log on the same seeded inputs -- and solve_rhc itself is pinned to the reference's
-own rows by G7 (tests/test_gpu_api.py::test_solve_rhc_vs_reference)."""
+"""The batched Monte-Carlo harness (dpilqr_amd/analysis.py; reference: scripts/analysis.py:35-174).  Pinned to the reference
+DIRECTLY by G10 (the real multi_agent_run on a seeded stream: test_harness_rows_equal_the_references_own); beside that its CSV
+equals, row for row, what per-trial solve_rhc runs log on the same seeded inputs -- and solve_rhc itself is pinned to the
+reference's own rows by G7 (tests/test_gpu_api.py::test_solve_rhc_vs_reference)."""
 import logging
 
 import numpy as np
@@ -37,6 +38,35 @@ def _same_rows(mine, ref):
         assert repr(a["subgraphs"]) == repr(b["subgraphs"]) and repr(a["t"]) == repr(b["t"])
         assert abs(a["J"] - b["J"]) <= 1e-6 * abs(b["J"]) and np.allclose(a["left"], b["left"], rtol=1e-6, atol=1e-9)
         assert len(a["times"]) == len(b["times"])                 # wall-clock seconds: the one field that cannot match
+
+
+def test_harness_rows_equal_the_references_own(dp, golden):
+    """G10 (tests/golden/make_golden.py g10): the reference's multi_agent_run itself, run on the harness's seed of each trial.
+    The batched harness on the same cells -- all trials of a cell in ONE call, as the study runs them -- logs the reference's
+    rows: every field but the wall-clock `times` (J and the distances to 1e-6), in the reference's order, and returns its
+    trajectories (1e-5 of the largest entry; the receding-horizon loop chains up to eleven solves)."""
+    from dpilqr_amd import analysis
+    from tests.test_host_logic import _g10_cells
+    z = golden("g10_harness")
+    dt, N, radius, energy, seed0 = float(z["dt"]), int(z["N"]), float(z["radius"]), float(z["energy"]), int(z["seed0"])
+    kw = dict(dist_converge=float(z["dist_converge"]), t_diverge=float(z["t_diverge"]))
+    cells = {}
+    for tag, model, n_agents, i_trial in _g10_cells(z):
+        cells.setdefault((model, n_agents), []).append((tag, i_trial))
+    assert len(cells) == 3
+    for (model, n_agents), trials in cells.items():
+        n_states, n_d = model(-1).n_x, (3 if model.__name__ == "QuadcopterDynamics6D" else 2)
+        got = []
+        res = analysis.multi_agent_run(model, [n_states] * n_agents, dt, N, radius, n_d=n_d, trials=[i for _, i in trials], seed0=seed0,
+                                       emit=got.append, energy=energy, t_kill=None, verbose=False, **kw)
+        ref_rows = [str(r) for tag, _ in trials for r in z[tag + "_rows"]]
+        _same_rows(got, ref_rows)
+        for tag, i in trials:
+            (Xc, Uc, Jc, _), (Xd, Ud, Jd, _) = res[i]
+            for mine, ref in ((Xc, z[tag + "_Xc"]), (Uc, z[tag + "_Uc"]), (Xd, z[tag + "_Xd"]), (Ud, z[tag + "_Ud"])):
+                assert mine.shape == ref.shape and np.max(np.abs(mine - ref)) <= 1e-5 * np.max(np.abs(ref)), tag
+            assert abs(Jc - float(z[tag + "_Jc"])) <= 1e-6 * abs(float(z[tag + "_Jc"])), tag
+            assert abs(Jd - float(z[tag + "_Jd"])) <= 1e-6 * abs(float(z[tag + "_Jd"])), tag
 
 
 @pytest.mark.parametrize("model_name,n_agents", [("DoubleIntDynamics4D", 3), ("UnicycleDynamics4D", 4), ("QuadcopterDynamics6D", 3)])

@@ -522,3 +522,47 @@ def test_team_at_other_sizes_and_families(dp, monkeypatch, model, k, ns, nc, nd,
         monkeypatch.delenv("DPILQR_BIG_TEAM")
         K1, d1 = pb.backward_pass(X, Ud, mu, dtype=dtype)
         assert torch.isfinite(K0).all() and torch.equal(K0, K1) and torch.equal(d0, d1), dtype
+
+
+def test_team_whose_helpers_stall_ends_in_a_status_not_a_dead_context(dp, monkeypatch):
+    """The team kernel's failure path is a return code (include/dpilqr_hip.h: "never throws or aborts"; it used to be five
+    __builtin_trap sites, which poison the HIP context of the whole process).  Fault injection: DPILQR_BIG_TEAM_LATE=2 makes the
+    helpers join the team and then never work; DPILQR_BIG_SPIN_LOG2 bounds every wait at 2^13 polls so that the main workgroup's
+    first wait for them expires in milliseconds.  Expected: the bare pass returns (its first gain offset NaN), the solve
+    retires the item with DPILQR_STATUS_FAULT after its first backward pass with X, U the initial rollout, dpilqr_solve_batch
+    reports DPILQR_EHIP with a message -- and the SAME process then runs the pass and the solve normally, with the results a
+    process that never saw the fault gets."""
+    import torch
+    from dpilqr_amd import _lib
+    models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(True, (6300,))
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, J = pb.rollout(x0, U0)
+    Ud = torch.as_tensor(U0, dtype=torch.float64, device="cuda")
+    mu = torch.ones(1, dtype=torch.float64, device="cuda")
+    K_ok, d_ok = pb.backward_pass(X, Ud, mu)
+    good = pb.solve(x0, U0, n_lqr_iter=2)
+    assert torch.isfinite(K_ok).all() and int(good["status"][0]) != _lib.STATUS_FAULT
+
+    monkeypatch.setenv("DPILQR_BIG_TEAM_LATE", "2")
+    monkeypatch.setenv("DPILQR_BIG_SPIN_LOG2", "13")
+    K_bad, d_bad = pb.backward_pass(X, Ud, mu)
+    torch.cuda.synchronize()                                     # the launch ENDS: no trap, no hang
+    assert torch.isnan(d_bad[0, 0, 0])
+    with pytest.raises(_lib.DpilqrError) as ei:
+        pb.solve(x0, U0, n_lqr_iter=2)
+    assert ei.value.code == _lib.EHIP and "gave up 1 of 1 items" in str(ei.value)
+    r = ei.value.results
+    assert int(r["status"][0]) == _lib.STATUS_FAULT and int(r["n_bwd"][0]) == 1 and int(r["n_fwd"][0]) == 0
+    assert torch.equal(r["X"], X) and torch.equal(r["U"], Ud)    # the last accepted iterate = the initial rollout
+    # the enqueue-only form: the status alone tells
+    r2, _ = pb.solve_enqueue(x0, U0, 3, n_lqr_iter=2)
+    torch.cuda.synchronize()
+    assert int(r2["status"][0]) == _lib.STATUS_FAULT
+
+    monkeypatch.delenv("DPILQR_BIG_TEAM_LATE")
+    monkeypatch.delenv("DPILQR_BIG_SPIN_LOG2")
+    K2, d2 = pb.backward_pass(X, Ud, mu)                          # the context is alive, the team works again
+    assert torch.equal(K2, K_ok) and torch.equal(d2, d_ok)
+    again = pb.solve(x0, U0, n_lqr_iter=2)
+    for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
+        assert torch.equal(again[key], good[key]), key

@@ -193,3 +193,40 @@ def test_monte_carlo_trial_inputs_follow_the_references_stream():
     Q, R, Qf = analysis.weights_of(analysis.MODELS[2], 6)
     assert Q[0, 0] == 50.0 and R.shape == (3, 3) and Qf[5, 5] == 1000.0          # analysis.py:62-69
     assert analysis.HEADER.split(",")[:4] == ["dynamics", "n_agents", "trial", "centralized"]
+
+
+def _g10_cells(z):
+    from dpilqr_amd import analysis
+    by_name = {m.__name__: m for m in analysis.MODELS}
+    for tag in z["tags"]:
+        name, n_agents, i_trial = str(tag).rsplit("_", 2)
+        yield str(tag), by_name[name], int(n_agents), int(i_trial)
+
+
+def test_harness_draws_are_the_references_own(golden):
+    """G10: the REAL scripts/analysis.py::multi_agent_run, run on a seeded stream (tests/golden/make_golden.py g10), recorded what
+    it drew: (x0, xf), then the centralized solve_rhc's warm start, then the distributed one's, captured from np.random.rand
+    itself.  analysis.trial_inputs -- what the batched harness feeds its trials -- reproduces every draw bit for bit on the
+    harness's own seed of the trial, and leaves the stream where the reference's whole trial left it (nothing else consumes
+    it: analysis.py:35-107, distributed.py:106-221)."""
+    from dpilqr_amd import analysis
+    z = golden("g10_harness")
+    N, energy, seed0 = int(z["N"]), float(z["energy"]), int(z["seed0"])
+    n = 0
+    for tag, model, n_agents, i_trial in _g10_cells(z):
+        seed = analysis.seed_of(model, n_agents, i_trial, seed0)
+        assert seed == int(z[tag + "_seed"]), tag
+        n_states, n_u = model(-1).n_x, n_agents * model(-1).n_u
+        n_d = 3 if model is analysis.QuadcopterDynamics6D else 2
+        x0, xf, U_c, U_d = analysis.trial_inputs(n_agents, n_states, n_u, N, energy, n_d, seed)
+        assert np.array_equal(x0, z[tag + "_x0"]) and np.array_equal(xf, z[tag + "_xf"]), tag
+        assert np.array_equal(U_c, z[tag + "_U_c"]) and np.array_equal(U_d, z[tag + "_U_d"]), tag
+        assert np.array_equal(np.random.get_state()[1][:4], z[tag + "_stream_after"]), tag
+        # the problem the harness builds carries the reference's weights, ids and goal
+        prob = analysis.build_problem(model, n_agents, float(z["dt"]), float(z["radius"]), xf, n_d)
+        assert prob.ids == [100 + i for i in range(n_agents)] and np.array_equal(prob.game_cost.xf.ravel(), z[tag + "_xf"].ravel())
+        rows = [_parse_row(str(r)) for r in z[tag + "_rows"]]
+        assert {r["model_name"] for r in rows} == {model.__name__} and {r["i_trial"] for r in rows} == {i_trial}
+        assert [r["centralized"] for r in rows if r["last"]] == [True, False]       # the centralized branch's rows, then the distributed one's
+        n += 1
+    assert n == 5
