@@ -141,6 +141,180 @@ def cpu_baseline_numpy(x0, xf, o, n=24):
                        f"{same}/{n}")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's other configurations in the same line (`configs`), run AFTER and OUTSIDE the headline's timed region: cfg3 and
+# cfg4 as many-scenario DP-iLQR calls at their stated sizes (reference path: dpilqr/distributed.py:25-103, one call per scenario
+# there), cfg5 as the ONE problem it is (fp64 and fp32), each with the CPU restatement timed beside it on a stated sample.
+G_ACC = 9.80665
+CFG_SCEN = {   # name: (model enum, class name, agents, n_s, n_c, n_d, T, scenarios, CPU-sample scenarios)
+    "cfg3": (3, "UnicycleDynamics4D", 15, 4, 2, 2, 100, 4096, 2),
+    "cfg4": (4, "QuadcopterDynamics6D", 10, 6, 3, 3, 75, 8192, 24),
+}
+
+
+def dense_flops_per_pass(n, m, T):
+    """T (4 n^3 + 8 n^2 m + 6 n m^2 + 2/3 m^3)"""
+    return T * (4.0 * n ** 3 + 8.0 * n * n * m + 6.0 * n * m * m + 2.0 * m ** 3 / 3.0)
+
+
+def scenario_config(name, scenarios=None, cpu=True):
+    """One many-scenario solve_distributed call of cfg3 / cfg4 (X = x0: the reference's first call): wall time with the inputs
+    resident in HBM and the stitched results left there, distinct sub-problems per second; the mid-size workgroup sweep
+    (k_riccati_wg, fused form -- what the solve loop launches for the configuration's full-size cluster) timed alone for its own
+    roofline; the C oracle on the distinct sub-problems of the first few scenarios as the CPU baseline."""
+    import torch
+    import dpilqr_amd as dp
+    from dpilqr_amd.dispatch import solve_scenarios_distributed
+    from dpilqr_amd.util import random_setup_batch
+    mdl, cls, k, ns, nc, nd, T, S, s_cpu = CFG_SCEN[name]
+    S = int(scenarios or S)
+    Q, R = (np.diag([1.0, 1, 0, 0]), np.eye(2)) if ns == 4 else (50.0 * np.eye(6), np.eye(3))     # scripts/analysis.py:62-69
+    Qf, dt, radius = 1000.0 * np.eye(ns), 0.1, 0.5
+    x0, xf = random_setup_batch((0, S), k, ns, var=k / 2, n_d=nd, energy=10.0)      # np.random.seed(s); random_setup(...), s = 0..S-1
+    ids = [100 + i for i in range(k)]
+    Model = getattr(dp, cls)
+    xf0 = xf[0].cpu().numpy()
+    prob = dp.ilqrProblem(dp.MultiDynamicalModel([Model(dt, i) for i in ids]),
+                          dp.GameCost([dp.ReferenceCost(xf0[i * ns:(i + 1) * ns], Q.copy(), R.copy(), Qf.copy(), id_) for i, id_ in enumerate(ids)],
+                                      dp.ProximityCost([ns] * k, radius, [nd] * k)))
+    U0 = torch.zeros((S, T, k * nc), dtype=torch.float64, device="cuda")
+    if mdl == 4:
+        U0[:, :, 0::3] = G_ACC                                                      # hover warm start (examples.py:122)
+    sw = min(S, 256)
+    solve_scenarios_distributed(prob, x0[:sw, None, :], U0[:sw], radius, xf=xf[:sw], device_out=True)      # warm: kernels, allocator
+    torch.cuda.synchronize()
+    walls = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        Xd, Ud, J, info = solve_scenarios_distributed(prob, x0[:, None, :], U0, radius, xf=xf, device_out=True)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    wall = min(walls)
+    out = {"workload": f"{name}: {S} random-goal scenarios x {k} {cls}, T={T}, proximity-graph split (radius {radius}) -> one batched "
+                       f"device solve per cluster size, stitched; scenarios s = 0..{S - 1} of scripts/analysis.py's distribution, inputs and "
+                       "results resident in HBM",
+           "scenarios": S, "wall_s": wall, "wall_s_runs": walls, "distinct_subproblems": int(info["n_unique"]),
+           "subproblems_total": int(info["n_subproblems"]), "subproblems_per_s": info["n_unique"] / wall, "scenarios_per_s": S / wall,
+           "cluster_sizes": {str(a): int(b) for a, b in sorted(info["sizes"].items())}, "stages_s": info["seconds"],
+           "finite_frac": float(torch.isfinite(J).double().mean().item())}
+    # the workgroup sweep alone, at the configuration's full cluster size: 2048 items at the iterate two iLQR iterations reach
+    Bs = 2048
+    n, m = k * ns, k * nc
+    pbs = dp.ProblemBatch([mdl] * k, [nd] * k, xf[:Bs], Q, R, Qf, radius, dt, T)
+    r2 = pbs.solve(x0[:Bs], U0[:Bs], n_lqr_iter=2)
+    mu = torch.full((Bs,), 0.125, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        pbs.backward_pass_fused(r2["X"], r2["U"], mu)
+    reps_ = 6
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps_):
+        pbs.backward_pass_fused(r2["X"], r2["U"], mu)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps_
+    useful = T * useful_flops_per_step(n, m, ns, k); dense = dense_flops_per_pass(n, m, T)
+    out["sweep_roofline"] = {"bound": "fp64", "kernel": f"k_riccati_wg<{n},{m},{ns},{nc},true>", "items": Bs, "launch_ms": ms,
+                             "launches_back_to_back": reps_, "achieved": Bs * useful / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": Bs * useful / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                             "flops_per_subproblem_pass": useful,
+                             "dense_count": {"flops_per_subproblem_pass": dense, "achieved": Bs * dense / (ms * 1e-3) / 1e12,
+                                             "frac": Bs * dense / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                             "hbm_bytes_per_subproblem_pass": 8 * ((T + 1) * n + T * m + T * (m * n + m)),
+                             "note": f"the fused mid-size sweep on {Bs} clusters of all {k} agents (the size that dominates a receding-horizon "
+                                     "second call), timed alone between one pair of HIP events; flops on data as in `roofline`"}
+    del pbs, r2
+    if cpu:
+        from oracle import oracle as orc
+        cores = orc.usable_cores()
+        _, _, _, inf = solve_scenarios_distributed(prob, x0[:s_cpu, None, :], U0[:s_cpu], radius, xf=xf[:s_cpu], device_out=True, audit=True)
+        n_sub, t_cpu = 0, 0.0
+        for kc, a in sorted(inf["audit"].items()):
+            proto = orc.Problem([mdl] * kc, [nd] * kc, a["xf"][0], Q, R, Qf, radius, dt, T)
+            t0 = time.perf_counter()
+            orc.solve_batch(proto, a["x0"], a["xf"], a["U0"], n_threads=cores)
+            t_cpu += time.perf_counter() - t0
+            n_sub += len(a["J"])
+        out["cpu_baseline"] = {"value": n_sub / t_cpu, "unit": "subproblems/s", "cores": cores, "kind": "port",
+                               "sample": f"the {n_sub} distinct sub-problems of scenarios 0..{s_cpu - 1} (cluster sizes "
+                                         f"{sorted(int(a_) for a_ in inf['audit'])}), oracle/ilqr_oracle.c, OpenMP over each size's batch on {cores} "
+                                         f"threads, {t_cpu:.2f} s wall"}
+    return out
+
+
+def cfg5_config(cpu=True, n_lqr_iter=8):
+    """BASELINE configs[4] as stated: ONE heterogeneous 20-agent problem (14 QuadcopterDynamics12D + 6 zero-padded HumanDynamics6D,
+    n_x = 240, n_u = 80, T = 150), solved whole -- 8 iLQR iterations, the large-cluster kernels (k_riccati_big as a team of
+    workgroups, k_forward<KDIRECT>) -- in fp64 and in fp32 (the tolerance study's two arms), with the C oracle on one core beside
+    them.  Scenario: tests/test_gpu_big.py::_cfg5_batch's (seed 6001, energy 100, hover warm start)."""
+    import torch
+    import dpilqr_amd as dp
+    from dpilqr_amd.util import random_setup
+    k, T = 20, 150
+    models = [7] * 14 + [8] * 6
+    nd = [3] * 14 + [2] * 6
+    np.random.seed(6001)
+    a, b = random_setup(k, 12, is_rotation=False, rel_dist=k, var=k / 2, n_d=3, random=True, energy=100.0)
+    x0, xf = a.ravel()[None], b.ravel()[None]
+    Q = np.stack([np.eye(12)] * 14 + [np.diag([1.0, 1, 1, 0, 0, 0] + [0.0] * 6)] * 6)
+    R = np.stack([np.eye(4)] * 14 + [np.diag([1.0, 1, 1e-9, 1e-9])] * 6)
+    Qf = np.stack([1000.0 * np.eye(12)] * k)
+    U0 = np.zeros((1, T, 80))
+    for i in range(14):
+        U0[:, :, 4 * i + 3] = G_ACC * 63.0 / 2000.0
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    out = {"workload": f"cfg5: one 20-agent problem (14 QuadcopterDynamics12D + 6 zero-padded HumanDynamics6D), n_x=240, n_u=80, T={T}, "
+                       f"whole solve, n_lqr_iter={n_lqr_iter}, seed 6001"}
+    res = {}
+    for name, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        pb.solve(x0, U0, n_lqr_iter=2, dtype=dtype); torch.cuda.synchronize()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = pb.solve(x0, U0, n_lqr_iter=n_lqr_iter, dtype=dtype)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        nb = int(r["n_bwd"][0])
+        res[name] = r
+        out[name] = {"solve_s": min(ts), "solve_s_runs": ts, "iterations": nb, "candidates_costed": int(r["n_fwd"][0]),
+                     "ms_per_iteration": 1e3 * min(ts) / max(nb, 1), "status": int(r["status"][0]), "J": float(r["J"][0]),
+                     "solves_per_s": 1.0 / min(ts)}
+    X64 = res["f64"]["X"].cpu().numpy(); X32 = res["f32"]["X"].cpu().numpy().astype(np.float64)
+    out["f32_vs_f64"] = {"rel_err_X": float(np.max(np.abs(X32 - X64)) / np.max(np.abs(X64))),
+                         "same_iterations": out["f32"]["iterations"] == out["f64"]["iterations"]}
+    # the backward pass alone (k_riccati_big<double,12,4>, a team of workgroups for the one item): useful / dense flops over its time
+    Xd, Ud = res["f64"]["X"], res["f64"]["U"]
+    mu = torch.ones(1, dtype=torch.float64, device="cuda")
+    pb.backward_pass(Xd, Ud, mu)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(3):
+        pb.backward_pass(Xd, Ud, mu)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    useful = T * useful_flops_per_step(240, 80, 12, 20); dense = dense_flops_per_pass(240, 80, T)
+    out["sweep_roofline"] = {"bound": "fp64", "kernel": "k_riccati_big<double,12,4>", "items": 1, "launch_ms": ms,
+                             "achieved": useful / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": useful / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_subproblem_pass": useful,
+                             "dense_count": {"flops_per_subproblem_pass": dense, "achieved": dense / (ms * 1e-3) / 1e12,
+                                             "frac": dense / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                             "note": "ONE item: the chain of T = 150 dependent steps on a team of workgroups (nine of 256 CUs); the launch "
+                                     "includes the workspace memset and the team reset"}
+    if cpu:
+        from oracle import oracle as orc
+        proto = orc.Problem(models, nd, xf[0], Q, R, Qf, 0.5, 0.1, T)
+        t0 = time.perf_counter()
+        o = orc.solve_batch(proto, x0, xf, U0, n_lqr_iter=n_lqr_iter, n_threads=1)
+        t_cpu = time.perf_counter() - t0
+        errX = float(np.max(np.abs(X64[0] - o["X"][0])) / np.max(np.abs(o["X"][0])))
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": f"the same problem, whole ({int(o['n_bwd'][0])} iterations), oracle/ilqr_oracle.c on one thread (one "
+                                         f"item: nothing to spread over cores), {t_cpu:.2f} s"}
+        out["parity_vs_oracle"] = {"same_decision_trace": bool(int(o["n_bwd"][0]) == out["f64"]["iterations"] and
+                                                               int(o["n_fwd"][0]) == out["f64"]["candidates_costed"]),
+                                   "rel_err_X": errX}
+    return out
+
+
 def _read(path):
     try:
         return Path(path).read_text().strip()
@@ -241,6 +415,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events in the timed run "
                     "(per-kernel breakdown; costs ~4 %% of throughput in dispatch gaps) instead of the Riccati sweep only")
     ap.add_argument("--cpu-sample", type=int, default=16384)
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (cfg3 / cfg4 / cfg5 after the headline; N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -301,14 +476,18 @@ def main():
     jobs = [job_of(0)]
     warm = make_job(args.warmup, seed_base + max_reps * args.steps * B) if args.warmup > 0 else None
     # N > 1: the results' home and the gathered results of all ranks, allocated once for the job's shape
-    rb = (ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank))
+    rb = (ResultBuffers(args.steps * B, T, N_X, N_U, chunk=args.gather_chunk, device=torch.device("cuda", local_rank), timeline=True)
           if (world > 1 or args.gather_path) else None)
+    gather_marks = {}                   # the last repetition's: host time and a stream event at the end of the solve, finish()'s own time
 
     def run(j, gather):
         if gather is not None:
             gather.begin()
             r = j["pb"].solve(j["x0"], j["U0"], n_lqr_iter=50, tol=1e-3, window=args.window, out=gather.out, progress=gather.progress)
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+            gather_marks.update(t_solve_end=time.perf_counter(), ev_solve_end=ev)
             gather.finish()             # the one collective of the path: what the solve's progress reports did not already send
+            gather_marks["finish_issue_s"] = time.perf_counter() - gather_marks["t_solve_end"]
             return r
         return j["pb"].solve(j["x0"], j["U0"], n_lqr_iter=50, tol=1e-3, window=args.window)
 
@@ -336,6 +515,17 @@ def main():
         r = run(job, rb)
         fence()
         own_times.append(time.perf_counter() - t0)
+        if rb is not None:              # (after the fence: every event has completed)
+            tl = rb.timeline_relative_to(gather_marks["t_solve_end"], gather_marks["ev_solve_end"])
+            gather_marks["timeline"] = {
+                "chunks": len(tl), "chunk_items": args.gather_chunk,
+                "issued_before_solve_end": sum(1 for _, dt_, _ in tl if dt_ <= 0.0),
+                "issue_s_rel_solve_end": [round(dt_, 6) for _, dt_, _ in tl],
+                "done_ms_rel_solve_end": [None if ms_ is None else round(ms_, 3) for _, _, ms_ in tl],
+                "finish_issue_s": gather_marks["finish_issue_s"], "region_s": own_times[-1],
+                "exposed_tail_ms": max([0.0] + [ms_ for _, _, ms_ in tl if ms_ is not None]),
+                "note": "this rank's last repetition: per chunk of the one all-gather, when it was issued (host clock) and when it completed "
+                        "(side-stream event) relative to the end of the solve -- negative: overlapped with the solve, positive: exposed"}
         dt = torch.tensor([own_times[-1]], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -515,6 +705,7 @@ def main():
                        "converged_frac": float((st == 1).mean()), "linesearch_failed_frac": float((st == 2).mean()),
                        "parallelism": (f"batch-sharded x{world}, one all-gather in chunks of {args.gather_chunk} items overlapped with the solve"
                                        if world > 1 else "single GPU")},
+            "gather_timeline": gather_marks.get("timeline"),
             "roofline": roofline, "roofline_tiles_through_hbm": tiled, "single_batch_1024": single,
             "kernel_ms_per_step": {k: v["ms"] / (args.steps * reps) for k, v in prof.items() if v["launches"]},
         }
@@ -547,6 +738,13 @@ def main():
                         "replayed along the GPU's own decisions from x0 and from 32 perturbed copies of x0 (+-1e-14..5e-13): accepted costs, "
                         "final X, U, J within 10 x the ensemble's spread, every decision that is not the oracle's own verdict on the "
                         "same iterate undetermined in the ensemble too (oracle/parity.py; calibrated in tests/test_parity_envelope.py)"}
+        if world == 1 and not args.no_configs:
+            # BASELINE's other configurations, untimed by the headline (the literal configs[1] batch is `single_batch_1024` above)
+            torch.cuda.empty_cache()
+            cpu_legs = not args.no_cpu_baseline
+            out["configs"] = {"cfg2_single_batch": dict(single, workload="configs[1] read literally: one batch of 1024 sub-problems alone"),
+                              "cfg3": scenario_config("cfg3", cpu=cpu_legs), "cfg4": scenario_config("cfg4", cpu=cpu_legs),
+                              "cfg5": cfg5_config(cpu=cpu_legs)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -6,6 +6,8 @@ process per GPU) solves its own slice with no data-path communication, and the p
 collective: an all-gather of the converged (X, U, J, status, n_bwd, n_fwd) -- RCCL over xGMI with the
 `nccl` backend, gloo in the CPU tests.
 """
+from time import perf_counter as _now
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -116,8 +118,12 @@ class ResultBuffers:
     index order on every rank, whenever each rank is ready -- the collectives match up by order.
     Works with backend nccl (= RCCL, device tensors, side stream) and gloo (CPU tensors, no streams: the CPU tests)."""
 
-    def __init__(self, B, T, n_x, n_u, chunk=None, group=None, device=None, dtype=torch.float64):
+    def __init__(self, B, T, n_x, n_u, chunk=None, group=None, device=None, dtype=torch.float64, timeline=False):
         self.group = group
+        # timeline=True: per chunk, when its gather was ISSUED (host clock) and an event behind it on the side stream (when it
+        # was DONE): bench.py --gpus N prints both relative to the end of the solve, so that the exposed tail of the one
+        # collective is visible in the first multi-GPU line anyone runs
+        self.timeline = [] if timeline else None
         self.collective = dist.is_initialized()            # no process group: one rank, the "gather" is a copy
         self.world = dist.get_world_size(group) if self.collective else 1
         self.B, self.T, self.n_x, self.n_u = int(B), int(T), int(n_x), int(n_u)
@@ -158,6 +164,11 @@ class ResultBuffers:
             with self._on_side():
                 while self._sent < full:
                     self._gather_chunk(self._sent)
+                    if self.timeline is not None:
+                        ev = None
+                        if self._side is not None:
+                            ev = torch.cuda.Event(enable_timing=True); ev.record(self._side)
+                        self.timeline.append((self._sent, _now(), ev))
                     self._sent += 1
 
     def finish(self):
@@ -183,6 +194,17 @@ class ResultBuffers:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._sent = 0
+        if self.timeline is not None:
+            self.timeline = []
+
+    def timeline_relative_to(self, t_host, ev_stream=None):
+        """[(chunk, seconds from t_host to the chunk's ISSUE on the host, milliseconds from ev_stream to its COMPLETION on the
+        side stream or None)]: negative = before the reference point (overlapped with the solve), positive = after it (exposed).
+        Call after the device has been synchronised."""
+        out = []
+        for c, t, ev in (self.timeline or []):
+            out.append((c, t - t_host, (ev_stream.elapsed_time(ev) if (ev is not None and ev_stream is not None) else None)))
+        return out
 
     def warm(self):
         self.begin()

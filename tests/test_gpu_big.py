@@ -564,5 +564,5 @@ def test_team_whose_helpers_stall_ends_in_a_status_not_a_dead_context(dp, monkey
     K2, d2 = pb.backward_pass(X, Ud, mu)                          # the context is alive, the team works again
     assert torch.equal(K2, K_ok) and torch.equal(d2, d_ok)
     again = pb.solve(x0, U0, n_lqr_iter=2)
-    for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):
-        assert torch.equal(again[key], good[key]), key
+    for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):       # (J: the last EVALUATED cost, NaN where tan() overflowed a candidate)
+        assert np.array_equal(again[key].cpu().numpy(), good[key].cpu().numpy(), equal_nan=True), key

@@ -215,3 +215,63 @@ def test_chunked_overlapped_gather(world, B, chunk):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+def _world8_worker(rank, world, port, n_chunks, chunk, q):
+    """bench.py's N = 8 shape on CPU: cfg2's real CHUNK COUNT (100 steps x 1024 items in chunks of 2048 = 50 collectives of X and
+    50 of U per job; items shrunk to a few doubles so that eight ranks' receive buffers fit a test), every rank reporting its
+    finished prefix at its own seeded-random pace -- ranks are whole chunks apart most of the time, as eight GPUs working
+    through different seeds are -- with the timeline switched on as bench.py has it."""
+    from dpilqr_amd.sharding import ResultBuffers
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, n, m = 1, 2, 1
+    B = n_chunks * chunk - 3                       # a ragged last chunk
+    rb = ResultBuffers(B, T, n, m, chunk=chunk, timeline=True)
+    rb.warm()
+    rng = np.random.default_rng(100 + rank)
+    ok = True
+    for job in range(2):
+        rb.begin()
+        base = 1e6 * job + 1e4 * rank
+        done = 0
+        while done < B:
+            upto = min(B, done + int(rng.integers(1, 5 * chunk if rank % 3 else chunk // 2 + 2)))      # some ranks crawl, some leap
+            idx = torch.arange(done, upto, dtype=torch.float64)
+            rb.out["X"][done:upto] = (base + idx)[:, None, None]; rb.out["U"][done:upto] = -(base + idx)[:, None, None]
+            rb.out["status"][done:upto] = 1; rb.out["n_bwd"][done:upto] = idx.to(torch.int32); rb.out["n_fwd"][done:upto] = 1
+            done = upto
+            if done < B and rng.random() < 0.7:     # (the solver does not report after every iteration either)
+                rb.progress(done, B)
+        rb.out["J"][:] = torch.arange(B, dtype=torch.float64) + base
+        t_end = __import__("time").perf_counter()
+        rb.finish()
+        tl = rb.timeline_relative_to(t_end)
+        ok &= [c for c, _, _ in tl] == list(range(n_chunks))                  # every chunk exactly once, in index order, on every rank
+        ok &= all(ms is None for _, _, ms in tl) and tl[-1][1] >= 0.0         # (CPU: no stream events; the last chunk can only follow the end)
+        g = rb.results()
+        idx = torch.arange(B, dtype=torch.float64)
+        for r in range(world):
+            b = 1e6 * job + 1e4 * r
+            ok &= torch.equal(g["X"][r, :, 0, 0], idx + b) and torch.equal(g["X"][r, :, T, n - 1], idx + b)
+            ok &= torch.equal(g["U"][r, :, 0, 0], -(idx + b)) and torch.equal(g["J"][r], idx + b)
+            ok &= torch.equal(g["n_bwd"][r], torch.arange(B).to(torch.int32))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_gather_world_8_with_cfg2s_chunk_count_and_ragged_progress():
+    """Eight ranks (the node the SCALE run uses), 50 chunks per job, two jobs on the same buffers: the collectives match up by
+    order however far apart the ranks' progress reports are; every rank ends with every rank's results."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, 50, 8, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
