@@ -201,8 +201,18 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
     const bool active = tid < KA * NG;
     const int g = active ? tid / KA : 0, a = active ? tid - (tid / KA) * KA : 0;
     const double alpha = alphas[g];
-    double* Xw = Xc + ((int64_t)slot * NG + g) * (int64_t)(T + 1) * n + a * NS;
-    double* Uw = Uc + ((int64_t)slot * NG + g) * (int64_t)T * m + a * NC;
+    // this lane's candidate rows: a base that is the same in every lane (scalar registers) + a 32-bit lane offset -- as two 64-bit
+    // per-lane pointers they were four of the registers the 14- and 15-agent kernels did not have
+    double* const Xw0 = Xc + (int64_t)slot * NG * (int64_t)(T + 1) * n;
+    double* const Uw0 = Uc + (int64_t)slot * NG * (int64_t)T * m;
+    int xw_off = g * (T + 1) * n + a * NS;
+    asm volatile("" : "+v"(xw_off));      // (a 32-bit value, not the 64-bit product it comes from)
+    // (U's offset is formed where it is used, from g and a -- two multiply-adds per step instead of a register held, or spilled, for it)
+    auto uw_off_at = [&](int t_) {
+        int g_ = g;
+        asm volatile("" : "+v"(g_));
+        return (unsigned)(g_ * (T * m) + a * NC + t_ * m);
+    };
 
     // ---- per-item constants, read once
     const ItemParams P = item_params(D, b);
@@ -227,14 +237,17 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
 #pragma unroll
     for (int i = 1; i < KA; ++i) homog = homog && (P.n_dims[i] == P.n_dims[0]);
     int pp[PPL > 0 ? PPL : 1];   // this lane's pairs, p = a + q * KA: i | j << 8 | n_dims << 16
+    auto make_pairs = [&](int a_) {
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        const int p = min(a + q * KA, NP1 - 1);
-        int ii = 0, rem = p;                              // p-th pair of itertools.combinations(range(KA), 2)
-        while (rem >= KA - 1 - ii) { rem -= KA - 1 - ii; ++ii; }
-        const int jj = ii + 1 + rem;
-        pp[q] = ii | (jj << 8) | ((homog ? 2 : min(P.n_dims[ii], P.n_dims[jj])) << 16);
-    }
+        for (int q = 0; q < PPL; ++q) {
+            const int p = min(a_ + q * KA, NP1 - 1);
+            int ii = 0, rem = p;                              // p-th pair of itertools.combinations(range(KA), 2)
+            while (rem >= KA - 1 - ii) { rem -= KA - 1 - ii; ++ii; }
+            const int jj = ii + 1 + rem;
+            pp[q] = ii | (jj << 8) | ((homog ? 2 : min(P.n_dims[ii], P.n_dims[jj])) << 16);
+        }
+    };
+    make_pairs(a);
 
     double* sK = lds + W::oK;
     double* sd = lds + W::od;
@@ -251,25 +264,28 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
     // K[t] LAST: loads return in order and K[t] is what a step consumes first (the staging at its top), so the one wait of a step
     // stands there, where everything outstanding is at least a step old.  With X[t] last the wait for it stood behind the
     // candidate stores of the step and drained them too -- a store's round trip in every step of the chain.
+    // (addresses: a base that is the same in every lane + an unsigned 32-bit element offset formed per step -- as per-lane 64-bit
+    // pointers hoisted out of the horizon loop the four of them were eight registers, spilled and reloaded in every step by the
+    // six- and eight-quadcopter kernels)
     auto fetch = [&](Stage& sg, int t) {
-        const double* Kt = Kb + (int64_t)t * mn;
+        const unsigned ko = (unsigned)(t * mn), xo = (unsigned)(t * n + a * NS), uo = (unsigned)(t * m + a * NC);
 #ifdef DPILQR_LS_K_FIRST   // A/B builds: the order of rounds 1-3
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
             const int e = min(tid + NTH * q, mn / 2 - 1);
-            sg.stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
+            sg.stK[q] = *reinterpret_cast<const v2d*>(Kb + (ko + 2u * (unsigned)e));
         }
 #endif
 #pragma unroll
-        for (int i = 0; i < NS; ++i) sg.xold[i] = Xb[(int64_t)t * n + a * NS + i];
+        for (int i = 0; i < NS; ++i) sg.xold[i] = Xb[xo + (unsigned)i];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) sg.u[i] = Ub[(int64_t)t * m + a * NC + i];
-        sg.std_ = db[(int64_t)t * m + min(tid, m - 1)];
+        for (int i = 0; i < NC; ++i) sg.u[i] = Ub[uo + (unsigned)i];
+        sg.std_ = db[(unsigned)(t * m + min(tid, m - 1))];
 #ifndef DPILQR_LS_K_FIRST
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
             const int e = min(tid + NTH * q, mn / 2 - 1);
-            sg.stK[q] = *reinterpret_cast<const v2d*>(Kt + 2 * e);
+            sg.stK[q] = *reinterpret_cast<const v2d*>(Kb + (ko + 2u * (unsigned)e));
         }
 #endif
     };
@@ -286,8 +302,23 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         const double* scp = scp0 + par * NG * NP1;
         const double* scr = scr0 + par * NG * KA;
         double prox = 0.0, ref = 0.0;
+        if constexpr (NPAIRS > 32) {
+            // (in chunks: fully unrolled, the 105 pair costs of a fifteen-agent cluster were all loaded before the first add -- 210
+            // registers for a moment, the source of the 27..29 spilled registers of the 14- and 15-agent kernels; the adds keep
+            // their order)
+            constexpr int CH = 8;
+#pragma unroll 1
+            for (int p0 = 0; p0 < NPAIRS; p0 += CH) {
+                double v[CH];
 #pragma unroll
-        for (int p = 0; p < NPAIRS; ++p) prox += scp[p];
+                for (int q = 0; q < CH; ++q) v[q] = scp[min(p0 + q, NP1 - 1)];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) prox = (p0 + q < NPAIRS) ? prox + v[q] : prox;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPAIRS; ++p) prox += scp[p];
+        }
 #pragma unroll
         for (int i = 0; i < KA; ++i) ref += scr[i];
         J += D.w_prox * prox + D.w_ref * ref;
@@ -342,8 +373,8 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         // operations retire in order, so the wait for that prefetch at the top of the next step then never
         // includes a younger store's round trip (the stores are invisible to the compiler's wait counts)
         if (active) {
-            store_vec(Xw + (int64_t)t * n, x, NS);
-            if (t > 0) store_vec(Uw + (int64_t)(t - 1) * m, ut, NC);
+            store_vec(Xw0 + (unsigned)(xw_off + t * n), x, NS);
+            if (t > 0) store_vec(Uw0 + uw_off_at(t - 1), ut, NC);
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) ut[i] = u[i];
@@ -415,8 +446,8 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
     }
 #endif
     if (active) {
-        store_vec(Xw + (int64_t)T * n, x, NS);
-        if (T > 0) store_vec(Uw + (int64_t)(T - 1) * m, ut, NC);
+        store_vec(Xw0 + (unsigned)(xw_off + T * n), x, NS);
+        if (T > 0) store_vec(Uw0 + uw_off_at(T - 1), ut, NC);
     }
     {
         // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:112)
@@ -426,6 +457,13 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         }
         wave_sync<NW>();
         if (a == 0 && T > 0) stage_cost(J, (T & 1) ^ 1);
+        if constexpr (NS >= 6 || NW > 1) {
+            // the terminal step's pair table, made again from a lane id the optimiser cannot see through: the offsets the horizon
+            // loop derives from it need not stay alive across the loop for this one use (they were spilled before it and reloaded here)
+            int a2 = a;
+            asm volatile("" : "+v"(a2));
+            make_pairs(a2);
+        }
         double Qf[NS * NS], uz[NC];
 #pragma unroll
         for (int i = 0; i < NS * NS; ++i) Qf[i] = P.Qf[a * NS * NS + i];
@@ -440,7 +478,13 @@ __global__ __launch_bounds__((64 * WaveFwdLds<MODEL, KA>::NW * WaveFwdLds<MODEL,
         wave_sync<NW>();
         if (a == 0) stage_cost(J, T & 1);
     }
-    if (active && a == 0) lds[W::oJ + g] = J;
+    if constexpr (NS >= 6 || NW > 1) {      // (g from the lane id again: not a register kept, or spilled, across the horizon loop for this one store)
+        int tid2 = tid;
+        asm volatile("" : "+v"(tid2));
+        if (active && a == 0) lds[W::oJ + tid2 / KA] = J;
+    } else {
+        if (active && a == 0) lds[W::oJ + g] = J;
+    }
     // the candidates' trajectory stores (issued behind the compiler's back) must have landed before the copy below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -57,6 +57,26 @@ def test_workgroup_sweeps_stay_within_their_spill_bounds(table):
     assert big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 256            # cfg3's 15-unicycle clusters: two per CU
 
 
+def test_line_search_of_every_baseline_config_does_not_spill(table):
+    """The line search / rollout kernels BASELINE's configurations launch: cfg2 (five DoubleIntDynamics4D), cfg3 (clusters of 1..15
+    UnicycleDynamics4D), cfg4 (1..10 QuadcopterDynamics6D); cfg5's twenty-agent problem takes k_forward<..., KDIRECT> (tu_bigfwd).
+    Through round 5 <3,14>, <3,15>, <4,6>, <4,7>, <4,8> spilled 1..29 registers, a few of them reloaded in every step of the
+    horizon loop.  What they held: the 105 pair costs of a fifteen-agent cluster loaded at once before the first add of their sum
+    (now in chunks of eight, same order of adds); per-lane 64-bit pointers for the trajectory loads and candidate stores (now a
+    scalar base + a 32-bit lane offset formed per step); the pair table's derived offsets and the candidate index kept alive across
+    the loop for one use behind it (now made again there)."""
+    names = ["k_linesearch_wave<0, 5>", "k_rollout_wave<0, 5>"]
+    names += [f"k_linesearch_wave<3, {k}>" for k in range(1, 16)] + [f"k_rollout_wave<3, {k}>" for k in range(1, 16)]
+    names += [f"k_linesearch_wave<4, {k}>" for k in range(1, 11)] + [f"k_rollout_wave<4, {k}>" for k in range(1, 11)]
+    for k in names:
+        r = table[k]
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (k, r)
+    # (the other families' six-agent kernels: DoubleIntDynamics6D, HumanDynamicsLin6D lost their spills with the same changes;
+    # HumanDynamics6D's keeps 22, Quadcopter12D's up to 54 at one wavefront per SIMD -- neither is on a BASELINE configuration's path)
+    for k in ("k_linesearch_wave<1, 6>", "k_linesearch_wave<6, 6>"):
+        assert table[k]["vgpr_spill_count"] == 0, (k, table[k])
+
+
 def test_line_search_team_kernels_do_not_spill(table):
     """The two-wavefront line search (k_linesearch_team): the per-agent constants live in the cost wavefront's registers, the
     rollout's state in the other's -- no spills at any size (the one-wavefront quadcopter kernels spill from five agents on)."""
