@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cost.hpp"
 #include "models.hpp"
 
@@ -70,12 +72,39 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 }
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
 
+// the value lane `src` holds, `src` the same in every lane (v_readlane: no trip through the LDS crossbar)
+__device__ __forceinline__ double lane_get(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ float lane_get(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+// wave-wide maximum of an unsigned key, the same in every lane: DPP inside the 16-lane rows, row_bcast across them (twelve vector
+// instructions and a v_readlane; no trip through the LDS crossbar)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define DPILQR_UMAX_DPP(CTRL, ROWS, BC) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, BC));
+    DPILQR_UMAX_DPP(0xB1, 0xf, true) DPILQR_UMAX_DPP(0x4E, 0xf, true) DPILQR_UMAX_DPP(0x141, 0xf, true) DPILQR_UMAX_DPP(0x140, 0xf, true)
+    DPILQR_UMAX_DPP(0x142, 0xa, false)       // row_bcast:15 -> rows 1 and 3
+    DPILQR_UMAX_DPP(0x143, 0xc, false)       // row_bcast:31 -> rows 2 and 3: lane 63 has seen every lane
+#undef DPILQR_UMAX_DPP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// magnitude of a finite or infinite value as unsigned keys that order like it (a NaN: 0, 0 -- it never wins a maximum)
+__device__ __forceinline__ void mag_keys(double x, unsigned& hi, unsigned& lo) {
+    const bool num = x == x;
+    hi = num ? ((unsigned)__double2hiint(x) & 0x7fffffffu) : 0u;
+    lo = num ? (unsigned)__double2loint(x) : 0u;
+}
+__device__ __forceinline__ void mag_keys(float x, unsigned& hi, unsigned& lo) {
+    hi = (x == x) ? ((unsigned)__float_as_int(x) & 0x7fffffffu) : 0u;
+    lo = 0u;
+}
+
 // Scratch of one workgroup in global memory, in elements of R.  Every matrix has the same leading dimension ldw (a
 // multiple of 16 >= n + 1, so that a 16-wide operand tile never leaves its row) and the control-indexed ones have mk
 // rows (m rounded up to the 16-row blocks of the substitution); padding is zeroed once by the host and never written.
 struct BigScratch {
     int n, m, n1, ldw, mk;
-    int64_t oP, oV, oG, oKd, oT3, oQuu, oSync, total;
+    int64_t oP, oV, oG, oKd, oT3, oQuu, oSync, oStage, stage_elems, total;
     __host__ __device__ BigScratch(int n_, int m_) : n(n_), m(m_) {
         n1 = n + 1;
         ldw = big_round_up(n1, 16);
@@ -87,7 +116,16 @@ struct BigScratch {
         oKd = o;  o += (int64_t)mk * ldw;
         oT3 = o;  o += (int64_t)mk * ldw;
         oQuu = o; o += (int64_t)mk * mk;
-        oSync = (o + 3) & ~(int64_t)3; o = oSync + 32;   // the team's four words (k_riccati_big, nparts > 1), 16-byte aligned in either type
+        oSync = (o + 3) & ~(int64_t)3; o = oSync + 32;   // the team's words (k_riccati_big, nparts > 1), 16-byte aligned in either type
+        // twelve-state clusters (3 m == n: the only family with four controls per twelve states): two buffers for a step's plugin
+        // data -- [A|B] blocks, x - x_f, u, pair derivatives and their per-agent sums -- which a helper workgroup of the team
+        // evaluates a step ahead for the main one (k_riccati_big, `staged`)
+        stage_elems = 0;
+        if (3 * m == n && n % 12 == 0) {
+            const int k12 = n / 12, np = k12 * (k12 - 1) / 2;
+            stage_elems = ((int64_t)(16 * n + n + m + 12 * np + 12 * k12 + 16) + 15) & ~(int64_t)15;
+        }
+        oStage = o; o += 2 * stage_elems;
         total = (o + 31) & ~(int64_t)31;
     }
 };
@@ -133,7 +171,7 @@ struct BigLds {   // offsets in elements of R (all even)
 // part's wait ends, as failed) and leaves; the main workgroup then marks the item (singular[b] = 2, which the line search turns
 // into DPILQR_STATUS_FAULT and dpilqr_solve_batch into DPILQR_EHIP; the gain offsets d of the item are NaN for callers of the bare
 // pass) and leaves too.  The launch ends normally and the HIP context stays usable (include/dpilqr_hip.h: "never aborts").
-struct BigTeam { int flag_k, done, joined, mode, done1; };     // five words per item, zeroed by the launcher
+struct BigTeam { int flag_k, done, joined, mode, done1, done4, staged; };     // seven words per item, zeroed by the launcher
 constexpr int kBigSpinLog2 = 22;       // polls per wait before giving up (tests lower it: tu_big.hip, DPILQR_BIG_SPIN_LOG2)
 constexpr int kBigGaveUp = 1 << 30;    // a counter at or above this: some part of the team gave up
 
@@ -160,6 +198,8 @@ __device__ __forceinline__ void big_give_up(BigTeam* team) {
         __hip_atomic_store(&team->flag_k, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->done, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->done1, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->done4, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->staged, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->mode, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -169,7 +209,7 @@ __global__ void k_big_team_reset(R* scratch_all, int64_t stride, int64_t o_sync,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)s * stride + o_sync);
-    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0;
+    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0; team->done4 = 0; team->staged = 0;
 }
 
 template <typename R, int NS, int NC>
@@ -370,6 +410,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     const int tid = tid_p_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g16 = lane >> 4, c16 = lane & 15; \
     (void)wave; (void)g16; (void)c16; (void)lane;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)slot * S.total + S.oSync);
+    R* const gStage = scratch_all + (int64_t)slot * S.total + S.oStage;
+    const int nStage1 = O.QQ - O.AB, nStage2 = O.p - O.E;          // [A|B] blocks ; x - x_f, u, pair derivatives, their sums
+    const bool staged_ok = S.stage_elems >= nStage1 + nStage2;       // (the scratch holds the two buffers: twelve-state clusters)
     const int spin_log2 = (team_dbg >> 8) ? (team_dbg >> 8) : kBigSpinLog2;
     // the main workgroup's way out when the team has failed: the item is marked (for callers of the bare pass, who hand over no
     // `singular`: the first gain offset of the item is NaN), the launch goes on
@@ -407,10 +450,8 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         for (int t = T - 1; t >= 0; --t) {
             if (kTeamS1 && t < T - 1) {
                 // S1 of this step with the team (the first step's ran before the team was decided): P of the previous step is
-                // complete when EVERY part has added itself to `done`; then the step's plugin data, as on the main workgroup
+                // complete when EVERY part has added itself to `done`.  The step's plugin data are in place already (below).
                 if (!big_wait_ge(&team->done, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
-                stage_step(t, false);
-                __syncthreads();
                 {
                     const int part_ = part, nparts_ = nparts;
 #include "riccati_big_s1.inc"
@@ -419,7 +460,35 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (kTeamS1 && t > 0) {
+                // The NEXT step's plugin data, now: they depend on (X, U) alone, and from here to the main workgroup's word
+                // "K is ready" a helper has a quarter of a millisecond to spare (the LU and the substitution run there).  Part 1
+                // also stores them for the main workgroup, which then loads 53 KB at the top of its next step instead of
+                // evaluating twenty linearisations and 190 pair derivatives there, on the critical path (47 k clocks of a step's
+                // 420 k; round 6).  Two buffers by the step's parity: the main workgroup reads step t - 1's while step t - 2's is
+                // written only after every part, the main one included, has finished step t - 1's S1.
+                stage_step(t - 1, false);
+                __syncthreads();
+                if (part == 1 && staged_ok) {
+                    R* gS = gStage + (int64_t)((t - 1) & 1) * S.stage_elems;
+                    int tid_c = threadIdx.x;       // (opaque: hoisted out of the horizon loop the copy's per-lane addresses were spilled)
+                    asm volatile("" : "+v"(tid_c));
+                    for (int e = tid_c; e < nStage1; e += kBigThreads) gS[e] = lds[O.AB + e];
+                    for (int e = tid_c; e < nStage2; e += kBigThreads) gS[nStage1 + e] = lds[O.E + e];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (threadIdx.x == 0) __hip_atomic_store(&team->staged, T - (t - 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
+            {
+                const int part_ = part, nparts_ = nparts;
+#include "riccati_big_s4.inc"
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done4, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
             {
                 const int part_ = part, nparts_ = nparts;
 #include "riccati_big_pairs.inc"
@@ -442,7 +511,23 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #define BPHASE(i)
 #endif
     for (int t = T - 1; t >= 0; --t) {
-        stage_step(t, false);
+        if (kTeamS1 && coop && staged_ok) {
+            // the team's part 1 has evaluated this step's plugin data while this workgroup factorised and substituted (the helper
+            // loop above): they are loaded, not made
+            if (!big_wait_ge(&team->staged, T - t, &sFlag[2], spin_log2)) { gave_up(); return; }
+            const R* gS = gStage + (int64_t)(t & 1) * S.stage_elems;
+            int tid_c = threadIdx.x;
+            asm volatile("" : "+v"(tid_c));
+            for (int e = tid_c; e < nStage1; e += kBigThreads) lds[O.AB + e] = gS[e];
+            for (int e = tid_c; e < nStage2; e += kBigThreads) lds[O.E + e] = gS[nStage1 + e];
+            // the LU buffer as stage_step leaves it: zero inside, identity on the padding's diagonal
+            for (int e = tid_c; e < mk * ldlu; e += kBigThreads) {
+                const int r = e / ldlu, c = e - r * ldlu;
+                sLU[e] = (r == c && r >= m) ? (R)1.0 : (R)0.0;
+            }
+        } else {
+            stage_step(t, false);
+        }
         __syncthreads();
         BPHASE(0)
 
@@ -489,7 +574,176 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // and every later access goes through sPerm
         for (int r = tid; r < mk; r += kBigThreads) sPerm[r] = r;
         __syncthreads();
-#ifndef DPILQR_BIG_LU_PLAIN
+#if !defined(DPILQR_BIG_LU_PLAIN) && !defined(DPILQR_BIG_LU_COLUMN)
+        // BLOCKED, trailing update on the matrix pipe (round 6).  Panels of FOUR columns -- the reduction depth of one 16x16x4
+        // product.  Per panel: (A) the first wavefront factorises it in registers, lane = position (two per lane beyond 64
+        // rows): the arg-max is a wave-wide maximum (DPP within the 16-lane rows, two exchanges across them) and a ballot -- the
+        // first position that holds it, dgetf2's idamax --, the pivot row goes out by v_readlane, the exchange is two lanes
+        // trading contents, the reciprocal is computed once on a value every lane holds; (B) the same wavefront forms the
+        // panel's rows of U to the right, one column per lane, three dependent multiply-adds; (C) all sixteen wavefronts apply
+        // the panel to the trailing block, one 16x16x4 product per tile: A = -L (a lane's position, reduction row g), B = U
+        // (reduction row g, a lane's column), C = the tile as it stands.  Two workgroup barriers per panel, 40 per
+        // factorisation instead of 80, and no chain of LDS round trips per column.  Same pivots (partial pivoting, first
+        // position of the largest magnitude), the same reciprocal 1 / pivot, the same multipliers a * (1 / pivot), every entry
+        // updated by the same multiply-adds in the same order (the matrix pipe accumulates its four reduction rows in
+        // ascending order).  The multipliers are stored as such (the column form stored a and scaled at the end).
+        // (The column form with its look-ahead wavefront: -DDPILQR_BIG_LU_COLUMN, A/B builds.  Round 5's blocked attempt -- sixteen-
+        // column panels, the trailing block on the vector pipe one thread per row -- was slower than the column form.)
+        for (int K0 = 0; K0 < m; K0 += 4) {
+            const int nbp = min(4, m - K0), base = K0 + nbp;
+            if (wave == 0) {
+                // Lanes are ROWS for the whole panel and nothing moves: a row's POSITION is a label that changes hands at an
+                // exchange (the row at position K0 + j takes the pivot's old position), a pivot row simply stops taking part.
+                // The arg-max works on the magnitudes' bit patterns (unsigned keys order like the magnitudes): the high words'
+                // wave maximum, then the low words' among the lanes that hold it -- integer DPP reductions --, then a ballot.
+                // Two instantiations: rows K0 .. K0 + 63 only (every panel but the first four at n_u = 80), or a second row per lane.
+                auto panel = [&](auto two_tag) __attribute__((always_inline)) {
+                    constexpr bool TWO = decltype(two_tag)::value;
+                    const int p0 = K0 + lane, p1 = p0 + 64;
+                    const bool in0 = p0 < m, in1 = TWO && p1 < m;
+                    const int r0 = sPerm[min(p0, mk - 1)], r1 = TWO ? sPerm[min(p1, mk - 1)] : 0;
+                    int pos0 = p0, pos1 = p1;
+                    bool act0 = in0, act1 = in1;
+                    R a0[4], a1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a0[j] = (in0 && j < nbp) ? sLU[r0 * ldlu + K0 + j] : (R)0.0;
+                        a1[j] = (in1 && j < nbp) ? sLU[r1 * ldlu + K0 + j] : (R)0.0;
+                    }
+                    int pvl[4] = {0, 0, 0, 0};                            // the pivots: lane | chunk << 6 (the same in every lane)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j >= nbp) break;
+                        const R x0 = a0[j], x1 = a1[j];
+                        // every lane divides for ITS candidate while the maximum is being found: the pivot's reciprocal is then
+                        // one lane read away (the division, a dozen dependent instructions, used to follow the search)
+                        const R i0 = (x0 == (R)0.0) ? (R)0.0 : (R)1.0 / x0;
+                        const R i1 = TWO ? ((x1 == (R)0.0) ? (R)0.0 : (R)1.0 / x1) : (R)0.0;
+                        unsigned h0, l0k, h1 = 0u, l1k = 0u;
+                        mag_keys(x0, h0, l0k);
+                        if (TWO) mag_keys(x1, h1, l1k);
+                        h0 = act0 ? h0 : 0u; l0k = act0 ? l0k : 0u;
+                        h1 = act1 ? h1 : 0u; l1k = act1 ? l1k : 0u;
+                        const unsigned hm = wave_max_u32(TWO ? max(h0, h1) : h0);
+                        bool c0 = act0 && h0 == hm, c1 = act1 && h1 == hm;
+                        unsigned lm = 0u;
+                        if constexpr (sizeof(R) == 8) {
+                            lm = wave_max_u32(TWO ? max(c0 ? l0k : 0u, c1 ? l1k : 0u) : (c0 ? l0k : 0u));
+                            c0 = c0 && l0k == lm; c1 = c1 && l1k == lm;
+                        }
+                        const bool ok = (hm | lm) != 0u;              // a positive (or infinite) magnitude exists
+                        unsigned long long k0, k1 = 0ull;
+                        if (ok) {
+                            k0 = __builtin_amdgcn_ballot_w64(c0);
+                            if (TWO) k1 = __builtin_amdgcn_ballot_w64(c1);
+                        } else {     // no positive finite candidate -- singular, or poisoned: flagged; position K0 + j keeps its row
+                            k0 = __builtin_amdgcn_ballot_w64(act0 && pos0 == K0 + j);
+                            if (TWO) k1 = __builtin_amdgcn_ballot_w64(act1 && pos1 == K0 + j);
+                        }
+                        int pc = (!TWO || k0 != 0ull) ? 0 : 1;
+                        int pl = (!TWO || k0 != 0ull) ? __builtin_ctzll(k0) : __builtin_ctzll(k1);
+                        if (__builtin_popcountll(k0) + __builtin_popcountll(k1) > 1) {
+                            // several rows hold the maximum: dgetf2 takes the first POSITION (rare; a scalar loop over the tied lanes)
+                            int bestp = 0x7fffffff;
+                            for (unsigned long long w = k0; w != 0ull; w &= w - 1) {
+                                const int l = __builtin_ctzll(w), pp_ = __builtin_amdgcn_readlane(pos0, l);
+                                if (pp_ < bestp) { bestp = pp_; pl = l; pc = 0; }
+                            }
+                            for (unsigned long long w = k1; w != 0ull; w &= w - 1) {
+                                const int l = __builtin_ctzll(w), pp_ = __builtin_amdgcn_readlane(pos1, l);
+                                if (pp_ < bestp) { bestp = pp_; pl = l; pc = 1; }
+                            }
+                        }
+                        pvl[j] = pl | (pc << 6);
+                        // the exchange, on the labels: whoever stands at K0 + j takes the pivot's position, the pivot takes K0 + j
+                        const int ppos = (TWO && pc) ? __builtin_amdgcn_readlane(pos1, pl) : __builtin_amdgcn_readlane(pos0, pl);
+                        pos0 = (act0 && pos0 == K0 + j) ? ppos : pos0;
+                        if (TWO) pos1 = (act1 && pos1 == K0 + j) ? ppos : pos1;
+                        const bool me = lane == pl;
+                        if (TWO && pc) { pos1 = me ? K0 + j : pos1; act1 = act1 && !me; }
+                        else { pos0 = me ? K0 + j : pos0; act0 = act0 && !me; }
+                        const R inv = (TWO && pc) ? lane_get(i1, pl) : lane_get(i0, pl);      // (pv == 0) ? 0 : 1 / pv, the pivot lane's own
+                        if (lane == 0) {
+                            if (!ok) sFlag[0] = 1;            // zero (or NaN) pivot: np.linalg.solve would raise
+                            sInv[K0 + j] = inv;
+                        }
+                        // the multipliers of the rows still in play, and their entries of the panel's later columns (a row that is
+                        // out of play multiplies by zero: its entries stay as they are)
+                        a0[j] = act0 ? x0 * inv : x0;
+                        const R m0 = act0 ? a0[j] : (R)0.0;
+                        R m1 = (R)0.0;
+                        if (TWO) { a1[j] = act1 ? x1 * inv : x1; m1 = act1 ? a1[j] : (R)0.0; }
+#pragma unroll
+                        for (int jj = j + 1; jj < 4; ++jj) {
+                            const R prj = (TWO && pc) ? lane_get(a1[jj], pl) : lane_get(a0[jj], pl);
+                            a0[jj] = fma(-m0, prj, a0[jj]);
+                            if (TWO) a1[jj] = fma(-m1, prj, a1[jj]);
+                        }
+                    }
+                    if (in0) sPerm[pos0] = r0;
+                    if (in1) sPerm[pos1] = r1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (in0 && j < nbp) sLU[r0 * ldlu + K0 + j] = a0[j];
+                        if (in1 && j < nbp) sLU[r1 * ldlu + K0 + j] = a1[j];
+                    }
+                    // (B) the panel's rows of U right of it: column c of the pivot rows R_1 .. R_3 takes the eliminations of the
+                    // panel's earlier columns
+                    int Rr[4];
+                    auto of_pivot = [&](int j_, R v0, R v1) -> R {
+                        return (TWO && (pvl[j_] >> 6)) ? lane_get(v1, pvl[j_] & 63) : lane_get(v0, pvl[j_] & 63);
+                    };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        Rr[j] = ((TWO && (pvl[j] >> 6)) ? __builtin_amdgcn_readlane(r1, pvl[j] & 63) : __builtin_amdgcn_readlane(r0, pvl[j] & 63)) * ldlu;
+                    R lmq[6];      // l10, l20, l21, l30, l31, l32: pivot row j's multipliers of the columns before it
+                    lmq[0] = of_pivot(1, a0[0], a1[0]); lmq[1] = of_pivot(2, a0[0], a1[0]); lmq[2] = of_pivot(2, a0[1], a1[1]);
+                    lmq[3] = of_pivot(3, a0[0], a1[0]); lmq[4] = of_pivot(3, a0[1], a1[1]); lmq[5] = of_pivot(3, a0[2], a1[2]);
+                    for (int c = base + lane; c < m; c += 64) {
+                        const R u0 = sLU[Rr[0] + c];
+                        if (nbp > 1) {
+                            const R u1 = fma(-lmq[0], u0, sLU[Rr[1] + c]);
+                            sLU[Rr[1] + c] = u1;
+                            if (nbp > 2) {
+                                const R u2 = fma(-lmq[2], u1, fma(-lmq[1], u0, sLU[Rr[2] + c]));
+                                sLU[Rr[2] + c] = u2;
+                                if (nbp > 3) sLU[Rr[3] + c] = fma(-lmq[5], u2, fma(-lmq[4], u1, fma(-lmq[3], u0, sLU[Rr[3] + c])));
+                            }
+                        }
+                    }
+                };
+                if ((m - K0) > 64) panel(std::true_type{});
+                else panel(std::false_type{});
+            }
+            __syncthreads();
+            // (C) the trailing block: positions and columns from `base` on, 16 x 16 tiles dealt to the wavefronts
+            if (base < m) {
+                const int tb = base >> 4, nt = ((m + 15) >> 4) - tb;
+                for (int tl = wave; tl < nt * nt; tl += kBigThreads / 64) {
+                    const int it = tb + tl / nt, jt = tb + tl - (tl / nt) * nt;
+                    const int pos_a = 16 * it + c16, col = 16 * jt + c16;
+                    const bool red = g16 < nbp;
+                    const R a = (red && pos_a >= base && pos_a < m) ? -sLU[sPerm[pos_a] * ldlu + K0 + g16] : (R)0.0;
+                    const R b = (red && col >= base && col < m) ? sLU[sPerm[K0 + (red ? g16 : 0)] * ldlu + col] : (R)0.0;
+                    acc_t cc;
+                    int rw[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int pos = 16 * it + Mfma<R>::row(v, g16);
+                        rw[v] = sPerm[min(pos, mk - 1)] * ldlu + min(col, mk - 1);
+                        cc[v] = sLU[rw[v]];
+                    }
+                    cc = Mfma<R>::mac(a, b, cc);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int pos = 16 * it + Mfma<R>::row(v, g16);
+                        if (pos >= base && pos < m && col >= base && col < m) sLU[rw[v]] = cc[v];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#elif !defined(DPILQR_BIG_LU_PLAIN)
         // With LOOK-AHEAD (round 3): while fifteen wavefronts apply column kk's eliminations to the columns from kk + 2 on, the
         // first wavefront applies them to column kk + 1 alone and then searches THAT column's pivot, exchanges and inverts --
         // the search, the exchange and the fp64 division were a third of every column's critical path (238 k of a step's 1.47 M
@@ -648,12 +902,14 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             __syncthreads();
         }
 #endif
+#if defined(DPILQR_BIG_LU_PLAIN) || defined(DPILQR_BIG_LU_COLUMN)
         // multipliers l = a / pivot in place (exactly the values the elimination used)
         for (int e = tid; e < m * 32; e += kBigThreads) {
             const int ps = e >> 5;
             R* row = sLU + sPerm[ps] * ldlu;
             for (int c = (e & 31); c < ps; c += 32) row[c] *= sInv[c];
         }
+#endif
         }
         __syncthreads();
         BPHASE(2)
@@ -827,45 +1083,18 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         __syncthreads();
         BPHASE(3)
 
-        { BIG_LANE_TERMS()
-        // ---- S4: T3^T[c][i] = sum_a Q_uu[a][c] K[a][i]   (K^T Q_uu, associated as the reference's K.T @ Q_uu @ K)
+#ifdef DPILQR_BIG_S5_SEPARATE
         {
-            const int ti_n = (m + 15) / 16, tj_n = (n + 15) / 16, tj2 = (tj_n + 1) / 2;
-            for (int job = wave; job < ti_n * tj2; job += kBigThreads / 64) {
-                const int it = job / tj2, jt0 = 2 * (job - it * tj2);
-                acc_t acc[2];
-                acc[0] = acc_t{0, 0, 0, 0}; acc[1] = acc_t{0, 0, 0, 0};
-                const int jt1 = min(jt0 + 1, tj_n - 1);
-                // second tile clamped to a valid column block when tj_n is odd (its result is then not stored)
-                const R* px = gQuu + (int64_t)g16 * mk + 16 * it + c16;
-                const R* py = gKd + (int64_t)g16 * ldw + 16 * jt0 + c16;
-                {
-                    for (int ks = 0; ks < mk; ks += 4) {
-                        const R a = px[(int64_t)ks * mk];
-                        const R b0 = py[(int64_t)ks * ldw], b1 = py[(int64_t)ks * ldw + 16 * (jt1 - jt0)];
-                        acc[0] = Mfma<R>::mac(a, b0, acc[0]);
-                        acc[1] = Mfma<R>::mac(a, b1, acc[1]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q == 1 && jt0 + 1 >= tj_n) break;
-                    const int col = 16 * (jt0 + q) + c16;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int row = 16 * it + Mfma<R>::row(v, g16);
-                        if (row < m && col < n) gT3[(int64_t)row * ldw + col] = acc[q][v];
-                    }
-                }
-            }
-        }
+            const int part_ = 0, nparts_ = 1;
+#include "riccati_big_s4.inc"
         }
         __syncthreads();
         BPHASE(4)
+#endif
 
 #ifndef DPILQR_BIG_S5_SEPARATE
         {
-        if (nparts > 1 && t == T - 1) {     // the team or alone: decided once, when the first step's operands are in place
+        if (nparts > 1 && t == T - 1) {     // the team or alone: decided once, when the first step's gains are in place
             if (threadIdx.x == 0) {
                 const int joined = __hip_atomic_load(&team->joined, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 const int mode = (joined == nparts - 1) ? 1 : 2;
@@ -875,11 +1104,24 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             __syncthreads();
             coop = sFlag[3];
         }
-        if (coop) {      // K, T3^T, [Q_ux|Q_u], Q_xx of this step are in the scratch: every thread's stores done, then the word
+        if (coop) {      // [K|d], [Q_ux|Q_u], Q_xx, Q_uu of this step are in the scratch: every thread's stores done, then the word
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(&team->flag_k, T - t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        {   // S4 (round 6: the team's too -- one more hand-over, every part's tiles of T3^T stored before any part's S5 reads them)
+            const int part_ = 0, nparts_ = coop ? nparts : 1;
+#include "riccati_big_s4.inc"
+        }
+        if (coop) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done4, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
+        } else {
+            __syncthreads();
+        }
+        BPHASE(4)
         {
             const int part_ = 0, nparts_ = coop ? nparts : 1;
 #include "riccati_big_pairs.inc"
@@ -891,7 +1133,11 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         }
         __syncthreads();
-        for (int i = tid; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+        {   // (opaque lane id: hoisted out of the horizon loop this loop's per-lane address was spilled)
+            int tid_v = threadIdx.x;
+            asm volatile("" : "+v"(tid_v));
+            for (int i = tid_v; i < n; i += kBigThreads) sp[i] = gV[(int64_t)i * ldw + n];
+        }
         }
 #else
         // ---- S5: V = ((Q_xx + T3 [K|d]) + [K|d]^T [Q_ux|Q_u]) + ([K|d]^T [Q_ux|Q_u])^T   rows < n, columns <= n
