@@ -176,22 +176,40 @@ constexpr int kBigSpinLog2 = 22;       // polls per wait before giving up (tests
 constexpr int kBigGaveUp = 1 << 30;    // a counter at or above this: some part of the team gave up
 
 __device__ __forceinline__ int big_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// thread 0 waits until *p >= target (bounded); every thread leaves behind an acquire fence.  false: the wait expired, or another
-// part gave up
+// thread 0 waits until *p >= target (bounded), then ITS wavefront invalidates the CU's vector cache -- one agent-scope acquire per
+// workgroup, completed (s_waitcnt) before the barrier lets the other wavefronts load (the recipe of the hand-off guide; round 5
+// had every one of the sixteen wavefronts fence behind the barrier: sixteen invalidates of the same cache, 2 - 4 x the time).
+// false: the wait expired, or another part gave up
 __device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok, int spin_log2) {
-    if (threadIdx.x == 0) {
-        int it = 0, ok = 1, v;
-        while ((v = big_ld(p)) < target) {      // (relaxed: an acquire here invalidates the caches at every poll -- measured, 2 .. 5 x slower passes)
-            __builtin_amdgcn_s_sleep(4);
-            if ((++it >> spin_log2) != 0) { ok = 0; break; }
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) {
+            int it = 0, ok = 1, v;
+            while ((v = big_ld(p)) < target) {      // (relaxed: an acquire here invalidates the caches at every poll -- measured, 2 .. 5 x slower passes)
+                __builtin_amdgcn_s_sleep(4);
+                if ((++it >> spin_log2) != 0) { ok = 0; break; }
+            }
+            if (v >= kBigGaveUp) ok = 0;
+            *s_ok = ok;
         }
-        if (v >= kBigGaveUp) ok = 0;
-        *s_ok = ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (behind the poll in program order: lane 0's loop is this wavefront's)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (every wavefront drops what its caches hold of the other parts' data)
     return *s_ok != 0;
 }
+// a part's arrival / the main workgroup's word, behind every wavefront's `s_waitcnt vmcnt(0)` and the workgroup barrier: an agent-scope
+// release (the XCD's L2 written back: the parts of a team normally share an XCD, but nothing here relies on it).
+// (team_dbg & 4: TIMING EXPERIMENTS ONLY -- relaxed, i.e. without the write-back: what the release costs.  Results are then
+// valid only while every part of the team shares an XCD.)
+__device__ __forceinline__ void big_arrive(int* p, int team_dbg) {
+    if (team_dbg & 4) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void big_publish(int* p, int v, int team_dbg) {
+    if (team_dbg & 4) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // a part gives up: every wait of the team, current or future, ends as failed; helpers that have not looked yet see mode 3 and leave
 __device__ __forceinline__ void big_give_up(BigTeam* team) {
     if (threadIdx.x == 0) {
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) big_arrive(&team->done1, team_dbg);
             }
             if (kTeamS1 && t > 0) {
                 // The NEXT step's plugin data, now: they depend on (X, U) alone, and from here to the main workgroup's word
@@ -477,7 +495,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     for (int e = tid_c; e < nStage2; e += kBigThreads) gS[nStage1 + e] = lds[O.E + e];
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (threadIdx.x == 0) __hip_atomic_store(&team->staged, T - (t - 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (threadIdx.x == 0) big_publish(&team->staged, T - (t - 1), team_dbg);
                 }
             }
             if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
@@ -487,7 +505,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done4, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_arrive(&team->done4, team_dbg);
             if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
             {
                 const int part_ = part, nparts_ = nparts;
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_arrive(&team->done, team_dbg);
         }
         return;
     }
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (kTeamS1 && coop) {      // the team's S1: every part's block products stored, then Q_uu -- the other parts' entries of it -- into the LU buffer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_arrive(&team->done1, team_dbg);
             if (!big_wait_ge(&team->done1, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
             for (int e = threadIdx.x; e < m * m; e += kBigThreads) {
                 const int a = e / m, c = e - a * m;
@@ -1107,7 +1125,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (coop) {      // [K|d], [Q_ux|Q_u], Q_xx, Q_uu of this step are in the scratch: every thread's stores done, then the word
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(&team->flag_k, T - t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_publish(&team->flag_k, T - t, team_dbg);
         }
         {   // S4 (round 6: the team's too -- one more hand-over, every part's tiles of T3^T stored before any part's S5 reads them)
             const int part_ = 0, nparts_ = coop ? nparts : 1;
@@ -1116,7 +1134,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (coop) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done4, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_arrive(&team->done4, team_dbg);
             if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         } else {
             __syncthreads();
@@ -1129,7 +1147,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (coop) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) big_arrive(&team->done, team_dbg);
             if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         }
         __syncthreads();

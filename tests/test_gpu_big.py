@@ -566,3 +566,32 @@ def test_team_whose_helpers_stall_ends_in_a_status_not_a_dead_context(dp, monkey
     again = pb.solve(x0, U0, n_lqr_iter=2)
     for key in ("X", "U", "J", "status", "n_bwd", "n_fwd"):       # (J: the last EVALUATED cost, NaN where tan() overflowed a candidate)
         assert np.array_equal(again[key].cpu().numpy(), good[key].cpu().numpy(), equal_nan=True), key
+
+
+def test_team_hand_overs_under_uneven_load(dp, monkeypatch):
+    """The team's hand-overs (one relaxed poll, ONE agent-scope acquire by the polling wavefront, the workgroup barrier; arrivals
+    behind every wavefront's drained stores and an agent-scope release) with the chip busy and uneven: a copy stream of a few
+    hundred MB runs beside every team pass (other workgroups take CUs and L2, the parts start at different times, the caches are
+    warm with the previous pass's lines of the same addresses).  Ten passes of one item and of three, every word of the gains
+    compared with the single workgroup's."""
+    import torch
+    for B in (1, 3):
+        models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(True, tuple(range(6400, 6400 + B)))
+        pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+        X, J = pb.rollout(x0, U0)
+        Ud = torch.as_tensor(U0, dtype=torch.float64, device="cuda")
+        mu = torch.ones(B, dtype=torch.float64, device="cuda")
+        monkeypatch.setenv("DPILQR_BIG_TEAM", "0")
+        K0, d0 = pb.backward_pass(X, Ud, mu)
+        monkeypatch.delenv("DPILQR_BIG_TEAM")
+        src = torch.empty(96 << 20, dtype=torch.float32, device="cuda").normal_()      # 384 MB: past L2 and the Infinity Cache
+        dst = torch.empty_like(src)
+        side = torch.cuda.Stream()
+        for rep in range(10):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 3):
+                    dst.copy_(src); src.mul_(1.0000001)
+            K1, d1 = pb.backward_pass(X, Ud, mu)
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(K0, K1) and torch.equal(d0, d1), (B, rep)
