@@ -104,7 +104,7 @@ __device__ __forceinline__ void mag_keys(float x, unsigned& hi, unsigned& lo) {
 // rows (m rounded up to the 16-row blocks of the substitution); padding is zeroed once by the host and never written.
 struct BigScratch {
     int n, m, n1, ldw, mk;
-    int64_t oP, oV, oG, oKd, oT3, oQuu, oSync, oStage, stage_elems, total;
+    int64_t oP, oV, oG, oKd, oT3, oQuu, oSync, oStage, stage_elems, oLU, lu_elems, total;
     __host__ __device__ BigScratch(int n_, int m_) : n(n_), m(m_) {
         n1 = n + 1;
         ldw = big_round_up(n1, 16);
@@ -126,6 +126,10 @@ struct BigScratch {
             stage_elems = ((int64_t)(16 * n + n + m + 12 * np + 12 * k12 + 16) + 15) & ~(int64_t)15;
         }
         oStage = o; o += 2 * stage_elems;
+        // ... and, for the same clusters, the LU factors (m_k x (m_k + 2)) and the row permutation, which the main workgroup hands to
+        // the team for the substitution's column tiles
+        lu_elems = stage_elems > 0 ? (((int64_t)mk * (mk + 2) + mk + 16 + 15) & ~(int64_t)15) : 0;
+        oLU = o; o += lu_elems;
         total = (o + 31) & ~(int64_t)31;
     }
 };
@@ -171,7 +175,7 @@ struct BigLds {   // offsets in elements of R (all even)
 // part's wait ends, as failed) and leaves; the main workgroup then marks the item (singular[b] = 2, which the line search turns
 // into DPILQR_STATUS_FAULT and dpilqr_solve_batch into DPILQR_EHIP; the gain offsets d of the item are NaN for callers of the bare
 // pass) and leaves too.  The launch ends normally and the HIP context stays usable (include/dpilqr_hip.h: "never aborts").
-struct BigTeam { int flag_k, done, joined, mode, done1, done4, staged; };     // seven words per item, zeroed by the launcher
+struct BigTeam { int flag_k, done, joined, mode, done1, done4, staged, flag_lu, doneK; };     // nine words per item, zeroed by the launcher
 constexpr int kBigSpinLog2 = 22;       // polls per wait before giving up (tests lower it: tu_big.hip, DPILQR_BIG_SPIN_LOG2)
 constexpr int kBigGaveUp = 1 << 30;    // a counter at or above this: some part of the team gave up
 
@@ -218,6 +222,8 @@ __device__ __forceinline__ void big_give_up(BigTeam* team) {
         __hip_atomic_store(&team->done1, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->done4, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->staged, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->flag_lu, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->doneK, kBigGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&team->mode, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -227,7 +233,7 @@ __global__ void k_big_team_reset(R* scratch_all, int64_t stride, int64_t o_sync,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)s * stride + o_sync);
-    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0; team->done4 = 0; team->staged = 0;
+    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0; team->done4 = 0; team->staged = 0; team->flag_lu = 0; team->doneK = 0;
 }
 
 template <typename R, int NS, int NC>
@@ -431,6 +437,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     R* const gStage = scratch_all + (int64_t)slot * S.total + S.oStage;
     const int nStage1 = O.QQ - O.AB, nStage2 = O.p - O.E;          // [A|B] blocks ; x - x_f, u, pair derivatives, their sums
     const bool staged_ok = S.stage_elems >= nStage1 + nStage2;       // (the scratch holds the two buffers: twelve-state clusters)
+    R* const gLU = scratch_all + (int64_t)slot * S.total + S.oLU;   // the factors and the permutation, for the team's substitution
+    int* const gLUperm = reinterpret_cast<int*>(gLU + (int64_t)mk * ldlu);
+    const bool lu_ok = S.lu_elems >= (int64_t)mk * ldlu + mk;
     const int spin_log2 = (team_dbg >> 8) ? (team_dbg >> 8) : kBigSpinLog2;
     // the main workgroup's way out when the team has failed: the item is marked (for callers of the bare pass, who hand over no
     // `singular`: the first gain offset of the item is NaN), the launch goes on
@@ -448,6 +457,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #else
     constexpr bool kTeamS1 = (sizeof(R) == 8 && NS == 12 && NC == 4);
 #endif
+    constexpr bool kTeamSolve = kTeamS1;      // ... and the substitution's column tiles (round 6)
     int coop = 0;      // 1: this pass is run by the team
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
         // (tests: DPILQR_BIG_TEAM_LATE=1 makes the helpers report a few milliseconds late -- after the main workgroup's decision --
@@ -498,7 +508,28 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     if (threadIdx.x == 0) big_publish(&team->staged, T - (t - 1), team_dbg);
                 }
             }
-            if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
+            if (kTeamSolve && lu_ok && t < T - 1) {
+                // the substitution's column tiles (the first step's ran before the team was decided): the main workgroup's factors
+                // from the scratch into this workgroup's LU buffer, this part's tiles, then every part's arrival = [K | d] complete
+                if (!big_wait_ge(&team->flag_lu, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
+                {
+                    int tid_c = threadIdx.x;
+                    asm volatile("" : "+v"(tid_c));
+                    for (int e = tid_c; e < mk * ldlu; e += kBigThreads) sLU[e] = gLU[e];
+                    if (tid_c < mk) sPerm[tid_c] = gLUperm[tid_c];
+                }
+                __syncthreads();
+                {
+                    const int part_ = part, nparts_ = nparts;
+#include "riccati_big_solve.inc"
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) big_arrive(&team->doneK, team_dbg);
+                if (!big_wait_ge(&team->doneK, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
+            } else {
+                if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
+            }
             {
                 const int part_ = part, nparts_ = nparts;
 #include "riccati_big_s4.inc"
@@ -932,173 +963,32 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         __syncthreads();
         BPHASE(2)
 
-        { BIG_LANE_TERMS()
-        // ---- S3b: [K | d] = -Q_uu^-1 [Q_ux | Q_u] by blocked substitution on the matrix pipe (round 5).  A wavefront owns a
-        // tile of sixteen right-hand sides (columns 16 jt .. 16 jt + 15 of [Q_ux | Q_u]: sixteen tiles at n_x = 240, one per
-        // wavefront) and walks the block rows I of the factors: the block row's updates Y_I -= L_IJ Y_J (80 % of the
-        // substitution's flops) are 16x16x4 products -- the factors' entries straight from LDS through the row permutation, the
-        // solved blocks Y_J read back from the scratch in the operand order (for fp64 a lane reads exactly the four entries it
-        // stored itself: D's row g + 4 v is the B operand's row 4 q + g at q = v) -- and the 16 x 16 diagonal block is solved
-        // inside the tile: lane (g, c) holds rows row(v, g) of column c, the pivot row's entry goes to the column's other
-        // three lanes by a lane shuffle, every lane updates its four rows.  Round 4's form -- one right-hand side per THREAD,
-        // 241 of 1024 threads busy, sixteen-row blocks of y, of the solved block and of a factor row in registers (112 of a lane's
-        // 128 registers; with S5 the reason the kernel spilled) -- took 301 k of a step's 1.43 M clocks.
+        // ---- S3b: the blocked substitution (riccati_big_solve.inc).  With the team (round 6, twelve-state fp64): the factors and
+        // the permutation go to the scratch, one word tells the helpers, and the sixteen column tiles are dealt over ALL parts -- two
+        // wavefronts each, a SIMD to itself, instead of sixteen wavefronts sharing four SIMDs (the phase is bound by the issue of
+        // the in-tile pivot steps, 95 k clocks of a step's 360 k); every part's arrival then says "all of [K | d] is in place".
+        const bool team_solve = kTeamSolve && coop && lu_ok;
+        if (team_solve) {
+            int tid_c = threadIdx.x;
+            asm volatile("" : "+v"(tid_c));
+            for (int e = tid_c; e < mk * ldlu; e += kBigThreads) gLU[e] = sLU[e];
+            if (tid_c < mk) gLUperm[tid_c] = sPerm[tid_c];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) big_publish(&team->flag_lu, T - t, team_dbg);
+        }
         {
-            const int nb = mk / 16, ntile = ldw / 16;
-            constexpr int NBR = 5;            // block rows that stay in registers (config 5: n_u = 80 = 5 x 16)
-            // the unit-lower / upper diagonal block solved inside a tile; the factors' entries of the NEXT pivot are requested
-            // before the current pivot's shuffle (the fences keep the scheduler from hoisting all sixty loads: 120 registers)
-            auto solve_lower = [&](int I, acc_t& y) {
-                int prow[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) prow[v] = sPerm[16 * I + Mfma<R>::row(v, g16)] * ldlu + 16 * I;
-#pragma unroll
-                for (int ip = 0; ip < 15; ++ip) {
-                    R lc[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) lc[v] = sLU[prow[v] + ip];
-                    const R yp = lane_bcast(y[Mfma<R>::reg_of(ip)], Mfma<R>::group_of(ip) * 16 + c16);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (Mfma<R>::row(v, g16) > ip) y[v] = fma(-lc[v], yp, y[v]);
-                    if (ip % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            auto solve_upper = [&](int I, acc_t& y) {        // leaves -x in y
-                int prow[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) prow[v] = sPerm[16 * I + Mfma<R>::row(v, g16)] * ldlu + 16 * I;
-#pragma unroll
-                for (int ip = 15; ip >= 0; --ip) {
-                    R uc[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) uc[v] = sLU[prow[v] + ip];
-                    const R dc = sLU[sPerm[16 * I + ip] * ldlu + 16 * I + ip];
-                    const R s_ = lane_bcast(y[Mfma<R>::reg_of(ip)], Mfma<R>::group_of(ip) * 16 + c16);
-                    const R nx = -(s_ / dc);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int r = Mfma<R>::row(v, g16);
-                        if (r < ip) y[v] = fma(uc[v], nx, y[v]);
-                        else if (r == ip) y[v] = nx;
-                    }
-                    if (ip % 2 == 0) __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            // (row offsets inside the step's gain block and inside the scratch are 32-bit; g_row is the lane's group index made
-            // opaque per column tile: rows do not depend on the tile, and hoisted out of the tile loop twenty rows' 64-bit
-            // addresses of [K | d], K and the scratch were eighty registers, spilled)
-            R* const Kt = Kout + (gslot * T + t) * (int64_t)m * n;
-            R* const dt_out = dout + (gslot * T + t) * (int64_t)m;
-            auto store_gains = [&](int I, const acc_t& y, int col, int g_row) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int a = 16 * I + Mfma<R>::row(v, g_row);
-                    if (a < m && col <= n) {
-                        gKd[a * ldw + col] = y[v];
-                        // (the gains stream out -- 23 MB per item and pass at n_x = 240 -- and must not push the scratch out of the caches)
-                        if (col < n) __builtin_nontemporal_store(y[v], Kt + a * n + col);
-                        else __builtin_nontemporal_store(y[v], dt_out + a);
-                    }
-                }
-            };
-            if (sizeof(R) == 8 && nb <= NBR) {
-                // fp64, everything of a column tile in registers: the right-hand sides of all block rows are requested at once, a
-                // solved block is the later blocks' matrix-pipe operand as it stands (D's row g + 4 v IS the B operand's row
-                // 4 q + g at q = v), nothing goes through the scratch but the final [K | d].  (fp32's D rows are 4 g + v: the
-                // operand needs a 4 x 4 exchange between the lane groups; with it the float instantiations spilled, and the
-                // tolerance study's arm is not the one to optimise: it takes the read-back form below.)
-                for (int jt = wave; jt < ntile; jt += kBigThreads / 64) {
-                    const int col = 16 * jt + c16;
-                    int g_row = g16;
-                    asm volatile("" : "+v"(g_row));
-                    acc_t y[NBR];
-                    auto operand = [&](int J, int q) -> R { return y[J][q]; };
-#pragma unroll
-                    for (int I = 0; I < NBR; ++I) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int r = 16 * I + Mfma<R>::row(v, g16);
-                            y[I][v] = (I < nb && r < m) ? gG[(int64_t)sPerm[min(r, mk - 1)] * ldw + col] : (R)0.0;
-                        }
-                    }
-#pragma unroll
-                    for (int I = 0; I < NBR; ++I) {              // L y = P b
-                        if (I < nb) {
-                            const int arow = sPerm[16 * I + c16] * ldlu;
-#pragma unroll
-                            for (int J = 0; J < I; ++J)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) y[I] = Mfma<R>::mac(-sLU[arow + 16 * J + 4 * q + g16], operand(J, q), y[I]);
-                            solve_lower(I, y[I]);
-                        }
-                    }
-#pragma unroll
-                    for (int I = NBR - 1; I >= 0; --I) {         // U x = y ; [K | d] = -x  (the solved blocks hold -x: the updates add U (-x))
-                        if (I < nb) {
-                            const int arow = sPerm[16 * I + c16] * ldlu;
-#pragma unroll
-                            for (int J = NBR - 1; J > I; --J)
-                                if (J < nb) {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) y[I] = Mfma<R>::mac(sLU[arow + 16 * J + 4 * q + g16], operand(J, q), y[I]);
-                                }
-                            solve_upper(I, y[I]);
-                            store_gains(I, y[I], col, g_row);
-                        }
-                    }
-                }
-            } else {
-            // more than NBR block rows (n_u > 80): the solved blocks are read back from the scratch in the operand order (for fp64 a
-            // lane reads exactly the four entries it stored itself)
-            for (int jt = wave; jt < ntile; jt += kBigThreads / 64) {
-                const int col = 16 * jt + c16;
-                for (int I = 0; I < nb; ++I) {                   // L y = P b
-                    acc_t y;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int r = 16 * I + Mfma<R>::row(v, g16);
-                        y[v] = (r < m) ? gG[(int64_t)sPerm[r] * ldw + col] : (R)0.0;
-                    }
-                    const int arow = sPerm[16 * I + c16] * ldlu;
-                    for (int J = 0; J < I; ++J) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const R a = -sLU[arow + 16 * J + 4 * q + g16];
-                            const R b = gKd[(int64_t)(16 * J + 4 * q + g16) * ldw + col];
-                            y = Mfma<R>::mac(a, b, y);
-                        }
-                    }
-                    solve_lower(I, y);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col] = y[v];
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block is read back (by this wavefront only) as an operand
-                }
-                for (int I = nb - 1; I >= 0; --I) {              // U x = y ; [K | d] = -x  (the scratch holds -x: the updates add U (-x))
-                    acc_t y;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) y[v] = gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col];
-                    const int arow = sPerm[16 * I + c16] * ldlu;
-                    for (int J = nb - 1; J > I; --J) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const R a = sLU[arow + 16 * J + 4 * q + g16];
-                            const R b = gKd[(int64_t)(16 * J + 4 * q + g16) * ldw + col];
-                            y = Mfma<R>::mac(a, b, y);
-                        }
-                    }
-                    solve_upper(I, y);
-                    // (columns beyond n are padding: their entries must still reach the scratch, the later blocks read them back)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) gKd[(int64_t)(16 * I + Mfma<R>::row(v, g16)) * ldw + col] = y[v];
-                    store_gains(I, y, col, g16);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-            }
+            const int part_ = 0, nparts_ = team_solve ? nparts : 1;
+#include "riccati_big_solve.inc"
         }
+        if (team_solve) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) big_arrive(&team->doneK, team_dbg);
+            if (!big_wait_ge(&team->doneK, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
+        } else {
+            __syncthreads();
         }
-        __syncthreads();
         BPHASE(3)
 
 #ifdef DPILQR_BIG_S5_SEPARATE
