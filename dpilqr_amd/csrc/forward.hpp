@@ -19,11 +19,26 @@
 
 namespace dpilqr {
 
+// 16x16x4 matrix-pipe tile (the same helper as riccati_big.hpp's Mfma<R>; this header is compiled in other translation units): lane
+// (g = lane / 16, c = lane % 16) supplies A[row c][reduction g], B[reduction g][column c] and owns rows row(v, g) of column c of D
+template <typename R> struct FwdMfma;
+template <> struct FwdMfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mac(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int v, int g) { return g + 4 * v; }
+};
+template <> struct FwdMfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mac(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int v, int g) { return 4 * g + v; }
+};
+
 constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step (per chunk, kdirect): ceil(n_u*n_x / threads) must not exceed this
 
 struct ForwardLds {   // offsets in elements of the arithmetic type
-    int Kt, dt, dx, xs, cref, cpair, J, ctl, total;
+    int Kt, dt, dx, xs, cref, cpair, J, ctl, du, total;
     int cw, rs;   // kdirect: columns of K[t] per chunk, elements per chunk column (>= m)
+    int mt;       // kdirect: m rounded up to the matrix pipe's 16-row tiles (the row stride of `du`)
     // kdirect: K[t] goes through LDS in CHUNKS of cw columns (large clusters: K[t] alone is 154 KB at n_x = 240, n_u = 80), two
     // chunk buffers used in turn, a chunk stored column by column with row a NC + c of a column at c k + a (the lanes of a candidate --
     // its agents -- read consecutive words, the candidates the same ones: with an agent's NC rows contiguous the reads were 5-way
@@ -50,6 +65,9 @@ struct ForwardLds {   // offsets in elements of the arithmetic type
         cpair = o; o += 2 * ngrp * (npairs > 0 ? npairs : 1);
         J = o;     o += ngrp;
         ctl = o;   o += 2;
+        o = (o + 1) & ~1;
+        mt = ((m + 15) / 16) * 16;
+        du = o;    o += kdirect ? ngrp * mt : 0;      // kdirect: K[t] dx of every candidate, from the matrix pipe's tiles to the agents' lanes
         total = (o + 1) & ~1;
     }
 };
@@ -88,7 +106,7 @@ __device__ __forceinline__ R sum_in_order(const R* p, int count) {
 //   R     : arithmetic type (double; float in the fp32 arm of BASELINE config 5's tolerance study)
 // Everything a step needs from HBM (K[t], d[t], X[t], U[t]) is fetched one step ahead into registers.
 // Returns J on the a == 0 lane of each candidate.
-template <typename R, int NS, int NC, bool GAINS, bool KDIRECT>
+template <typename R, int NS, int NC, bool GAINS, bool KDIRECT, bool PIPE = false>
 __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool homog, int tid, int nth, bool active,
                           int g, int a, int ngrp, const R* x_init, const R* __restrict__ Xold,
                           const R* __restrict__ Uold, const R* __restrict__ Kb,
@@ -199,9 +217,26 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
 #pragma unroll
         for (int c = 0; c < NC; ++c) ksum[c] = 0.0;
         if constexpr (KDIRECT && GAINS) {
-            // K[t] dx, chunk by chunk: this chunk from the registers into its buffer, the next one requested (the first of step t + 1
-            // behind the last of step t), one barrier, the chunk's columns added in ascending order.  The buffer written in one
-            // round was last read two rounds earlier, and every thread has passed the barrier in between.
+            // K[t] dx of ALL candidates at once, chunk by chunk: this chunk from the registers into its buffer, the next one requested
+            // (the first of step t + 1 behind the last of step t), one barrier, then -- round 6 -- the chunk's columns on the MATRIX
+            // PIPE: du[row][candidate] += K[row][j] dx_candidate[j] is a (m x cw)(cw x n_alpha) product, 16 x 16 x 4 tiles with the
+            // candidates as the tile's columns (10 of 16), the row tiles dealt to the wavefronts, accumulated over the chunks -- j
+            // ascending, one multiply-add per term.  Rounds 2-5 walked a chunk's columns per (candidate, agent) lane: every entry of
+            // K[t] read from LDS once per candidate, 68 k of a step's 170 k clocks at cfg5's size.  The buffer written in one round
+            // was last read two rounds earlier, and every thread has passed the barrier in between.
+            typedef typename FwdMfma<R>::acc_t acc_t;
+            const int wv = tid >> 6, ln = tid & 63, g16 = ln >> 4, c16 = ln & 15, nw = nth >> 6;
+            const int tiles = O.mt / 16;
+            // (PIPE: the launcher's promise that every wavefront has at most two row tiles and a tile's sixteen columns hold the
+            // candidates -- forward_on_pipe below; otherwise the lanes' own sums, another instantiation)
+            constexpr bool on_pipe = PIPE;
+            acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+            const int it0 = wv, it1 = wv + nw;
+            // this lane's A rows (K[t]'s rows 16 it + c16, where they stand inside a chunk column) and its B column (candidate c16)
+            const int r0 = 16 * it0 + c16, r1 = 16 * it1 + c16;
+            const int ao0 = (r0 % NC) * k + r0 / NC, ao1 = (r1 % NC) * k + r1 / NC;
+            const bool av0 = it0 < tiles && r0 < m, av1 = it1 < tiles && r1 < m, bv = c16 < ngrp;
+            const R* dxc = lds + O.dx + (par * ngrp + (bv ? c16 : 0)) * n;
             for (int ch = 0; ch < n_chunks; ++ch) {
                 R* sKc = lds + O.Kt + ck_buf * (O.cw * O.rs + 2);
                 const int left = n - ch * O.cw, cwa = left < O.cw ? left : O.cw;
@@ -211,7 +246,22 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 if (ch + 1 < n_chunks) fetch_chunk(t, ch + 1);
                 else if (t + 1 < T) fetch_chunk(t + 1, 0);
                 lds_handoff(single_wave);
-                if (active) {
+                if constexpr (on_pipe) {
+                    const R* dxp = dxc + ch * O.cw;
+                    for (int j4 = 0; j4 < cwa; j4 += 4) {
+                        const int jj = j4 + g16;
+                        const bool jv = jj < cwa;
+                        const int jc = jv ? jj : 0;
+                        const R bq = (bv && jv) ? dxp[jc] : (R)0.0;
+                        const R a0q = (av0 && jv) ? sKc[jc * O.rs + ao0] : (R)0.0;
+                        acc0 = FwdMfma<R>::mac(a0q, bq, acc0);
+                        if (it1 < tiles) {
+                            const R a1q = (av1 && jv) ? sKc[jc * O.rs + ao1] : (R)0.0;
+                            acc1 = FwdMfma<R>::mac(a1q, bq, acc1);
+                        }
+                    }
+                } else {
+                  if (active) {
                     const R* colp = sKc + a;
                     const R* dxp = sdx + ch * O.cw;
                     // eight columns' operands requested before the first is used (one wavefront per SIMD: nothing else hides an
@@ -235,8 +285,24 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
 #pragma unroll
                         for (int c = 0; c < NC; ++c) ksum[c] += colp[jj * O.rs + c * k] * dxj;
                     }
+                  }
                 }
                 ck_buf ^= 1;
+            }
+            if constexpr (on_pipe) {
+                // the tiles' entries to where the agents' lanes find them: du[candidate][row]
+                R* sdu = lds + O.du;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ra = 16 * it0 + FwdMfma<R>::row(v, g16), rb = 16 * it1 + FwdMfma<R>::row(v, g16);
+                    if (bv && it0 < tiles) sdu[c16 * O.mt + ra] = acc0[v];
+                    if (bv && it1 < tiles) sdu[c16 * O.mt + rb] = acc1[v];
+                }
+                lds_handoff(single_wave);
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) ksum[c] = sdu[g * O.mt + a * NC + c];
+                }
             }
         }
         if (active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), summed in the reference's order
@@ -354,7 +420,11 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
 // (n_alpha * k <= 64, e.g. cfg2's 50) four of them share a 256-thread workgroup, one wave each with its own
 // LDS slice and no workgroup barrier -- the same SIMD-placement argument as for the sweep (riccati_tiled.hpp).
 // R: arithmetic type; KDIRECT: K[t] is not staged in LDS (large clusters); lds_per_item in elements of R.
-template <typename R, int NS, int NC, bool KDIRECT>
+// the launcher's test for the matrix-pipe form of K[t] dx (KDIRECT, candidates / line-search mode): row tiles of 16 controls, at most
+// two per wavefront; the candidates are a tile's columns
+inline bool forward_on_pipe(int m, int threads, int ngrp) { return ((m + 15) / 16) <= 2 * (threads / 64) && ngrp <= 16; }
+
+template <typename R, int NS, int NC, bool KDIRECT, bool PIPE = false>
 __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(dpilqr_batch_desc D, int mode, const R* __restrict__ x0, R* X,
                                                   R* U, const R* __restrict__ K, const R* __restrict__ d,
                                                   const double* __restrict__ alphas, int ngrp, R* Xc, R* Uc,
@@ -398,8 +468,8 @@ __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(
     const int64_t cslot = (mode == kModeLineSearch) ? slot : b;
     R* Xw = active ? Xc + (cslot * ngrp + g) * (int64_t)(T + 1) * n : nullptr;
     R* Uw = active ? Uc + (cslot * ngrp + g) * (int64_t)T * m : nullptr;
-    const R J = horizon_pass<R, NS, NC, true, KDIRECT>(D, P, homog, tid, nth, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
-                                                       Xw, Uw, lds);
+    const R J = horizon_pass<R, NS, NC, true, KDIRECT, PIPE>(D, P, homog, tid, nth, active, g, a, ngrp, Xb, Xb, Ub, Kb, db, alpha,
+                                                             Xw, Uw, lds);
     if (mode == kModeCandidates) {
         if (active && a == 0) Jc[(int64_t)b * ngrp + g] = (double)J;
         return;

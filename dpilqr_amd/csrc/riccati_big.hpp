@@ -640,6 +640,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // column panels, the trailing block on the vector pipe one thread per row -- was slower than the column form.)
         for (int K0 = 0; K0 < m; K0 += 4) {
             const int nbp = min(4, m - K0), base = K0 + nbp;
+#ifdef DPILQR_PHASE_STAMPS
+            const unsigned long long lu_t0 = __builtin_amdgcn_s_memtime();
+#endif
             if (wave == 0) {
                 // Lanes are ROWS for the whole panel and nothing moves: a row's POSITION is a label that changes hands at an
                 // exchange (the row at position K0 + j takes the pivot's old position), a pivot row simply stops taking part.
@@ -764,6 +767,9 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 if ((m - K0) > 64) panel(std::true_type{});
                 else panel(std::false_type{});
             }
+#ifdef DPILQR_PHASE_STAMPS
+            bph[5] += __builtin_amdgcn_s_memtime() - lu_t0;      // (slot 5, "S5": the panels, wave 0's clock)
+#endif
             __syncthreads();
             // (C) the trailing block: positions and columns from `base` on, 16 x 16 tiles dealt to the wavefronts
             if (base < m) {

@@ -20,11 +20,21 @@ static int32_t launch_forward_big_t(const dpilqr_batch_desc& D, int mode, const 
     if (threads > 256)
         return fail(DPILQR_EUNSUPPORTED, "k*n_alpha=%d exceeds the 256-thread workgroup of the forward pass", D.k * groups);
     const size_t lds = (forward_lds_bytes(n, m, D.k, ngrp, true, sizeof(R)) + 15) & ~(size_t)15;
+    // K[t] dx on the matrix pipe where every wavefront gets at most two row tiles (forward.hpp: forward_on_pipe) -- config 5's
+    // shape and every cluster of the reference's families at ten candidates; a rollout has no gains
+    const bool pipe = mode != kModeRollout && forward_on_pipe(m, threads, ngrp);
     DISPATCH_FAMILY(D.n_s, {
-        int32_t rc = allow_lds(k_forward<R, NS, NC, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_forward<R, NS, NC, true>), dim3(grid_items), dim3(threads), lds, st, D, mode, x0, X, U, K, d,
-                           alphas, ngrp, Xc, Uc, Jc, S, items, n_items, 1, (int)(lds / sizeof(R)));
+        if (pipe) {
+            int32_t rc = allow_lds(k_forward<R, NS, NC, true, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_forward<R, NS, NC, true, true>), dim3(grid_items), dim3(threads), lds, st, D, mode, x0, X, U, K, d,
+                               alphas, ngrp, Xc, Uc, Jc, S, items, n_items, 1, (int)(lds / sizeof(R)));
+        } else {
+            int32_t rc = allow_lds(k_forward<R, NS, NC, true, false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_forward<R, NS, NC, true, false>), dim3(grid_items), dim3(threads), lds, st, D, mode, x0, X, U, K, d,
+                               alphas, ngrp, Xc, Uc, Jc, S, items, n_items, 1, (int)(lds / sizeof(R)));
+        }
     })
     HIP_TRY(hipGetLastError());
     return DPILQR_OK;
