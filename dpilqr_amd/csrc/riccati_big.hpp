@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #else
     constexpr bool kTeamS1 = (sizeof(R) == 8 && NS == 12 && NC == 4);
 #endif
-    constexpr bool kTeamSolve = kTeamS1;      // ... and the substitution's column tiles (round 6)
+    constexpr bool kTeamSolve = kTeamS1 || (NS == 12 && NC == 4);      // ... and the substitution's column tiles (round 6; twelve-state clusters, either type)
     int coop = 0;      // 1: this pass is run by the team
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
         // (tests: DPILQR_BIG_TEAM_LATE=1 makes the helpers report a few milliseconds late -- after the main workgroup's decision --
