@@ -14,7 +14,10 @@ python scripts/sweep_waves_ab.py 64 256 512 1024 2048 6144 2>&1 | q > gpurun_out
 ROUND=$R bash scripts/profile_wg.sh > gpurun_out/${R}_profile_wg.log 2>&1
 python scripts/montecarlo.py cfg4 8192 gpurun_out/${R}_cfg4_8192_scenarios.json > gpurun_out/${R}_cfg4.log 2>&1
 python scripts/montecarlo.py cfg3 4096 gpurun_out/${R}_cfg3_4096_scenarios.json > gpurun_out/${R}_cfg3.log 2>&1
-python scripts/bench_big.py 1 32 256 2>&1 | q > gpurun_out/${R}_cfg5_bench_big.txt
+python scripts/bench_big.py 1 8 32 256 2>&1 | q > gpurun_out/${R}_cfg5_bench_big.txt
+python scripts/big_team_check.py 1 8 32 64 128 2>&1 | q > gpurun_out/${R}_big_team.txt
+python scripts/cfg5_solve_time.py 8 2>&1 | q > gpurun_out/${R}_cfg5_solve.txt
+python scripts/bench_ls_sizes.py uni4:15 uni4:14 uni4:12 uni4:8 quad6:10 quad6:8 quad6:6 2>&1 | q > gpurun_out/${R}_ls_sizes.txt
 python scripts/kernel_resources.py > gpurun_out/${R}_kernel_resources.csv 2>/dev/null
 tail -3 gpurun_out/${R}_cfg4.log | cut -c1-300; tail -3 gpurun_out/${R}_cfg3.log | cut -c1-300; tail -4 gpurun_out/${R}_cfg5_bench_big.txt | cut -c1-200
 cut -c1-250 gpurun_out/${R}_bench_20steps.json; cut -c1-250 gpurun_out/${R}_bench_100steps.json

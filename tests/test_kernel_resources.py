@@ -96,6 +96,15 @@ def test_in_sweep_production_kernels_do_not_spill(table):
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (k, r)
 
 
+def test_large_cluster_forward_pass_does_not_spill(table):
+    """config 5's line search (k_forward<double, 12, 4, KDIRECT, PIPE>: K[t] dx of all candidates on the matrix pipe, round 6):
+    512 registers per lane at one wavefront per SIMD, none spilled (the form that walked K[t]'s columns per lane spilled 12)."""
+    r = table["k_forward<double, 12, 4, true, true>"]
+    assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
+    for k in ("k_forward<float, 12, 4, true, true>", "k_forward<double, 6, 3, true, true>", "k_forward<double, 4, 2, true, true>"):
+        assert table[k]["vgpr_spill_count"] == 0, (k, table[k])
+
+
 def test_large_cluster_sweep_does_not_spill(table):
     """k_riccati_big (n_x > 60, fp32 arm) runs sixteen wavefronts per workgroup, i.e. 128 registers per lane.  Through round 4
     it spilled 32..66 vector registers (and died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in builds that spilled 82 and
