@@ -175,7 +175,7 @@ struct BigLds {   // offsets in elements of R (all even)
 // part's wait ends, as failed) and leaves; the main workgroup then marks the item (singular[b] = 2, which the line search turns
 // into DPILQR_STATUS_FAULT and dpilqr_solve_batch into DPILQR_EHIP; the gain offsets d of the item are NaN for callers of the bare
 // pass) and leaves too.  The launch ends normally and the HIP context stays usable (include/dpilqr_hip.h: "never aborts").
-struct BigTeam { int flag_k, done, joined, mode, done1, done4, staged, flag_lu, doneK; };     // nine words per item, zeroed by the launcher
+struct BigTeam { int flag_k, done, joined, mode, done1, done4, staged, flag_lu, doneK, xccs; };     // ten words per item, zeroed by the launcher
 constexpr int kBigSpinLog2 = 22;       // polls per wait before giving up (tests lower it: tu_big.hip, DPILQR_BIG_SPIN_LOG2)
 constexpr int kBigGaveUp = 1 << 30;    // a counter at or above this: some part of the team gave up
 
@@ -195,23 +195,39 @@ __device__ __forceinline__ bool big_wait_ge(int* p, int target, int* s_ok, int s
             if (v >= kBigGaveUp) ok = 0;
             *s_ok = ok;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (behind the poll in program order: lane 0's loop is this wavefront's)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     return *s_ok != 0;
 }
-// a part's arrival / the main workgroup's word, behind every wavefront's `s_waitcnt vmcnt(0)` and the workgroup barrier: an agent-scope
-// release (the XCD's L2 written back: the parts of a team normally share an XCD, but nothing here relies on it).
-// (team_dbg & 4: TIMING EXPERIMENTS ONLY -- relaxed, i.e. without the write-back: what the release costs.  Results are then
-// valid only while every part of the team shares an XCD.)
-__device__ __forceinline__ void big_arrive(int* p, int team_dbg) {
-    if (team_dbg & 4) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// a part's arrival / the main workgroup's word, behind every wavefront's `s_waitcnt vmcnt(0)` and the workgroup barrier.
+// Two kinds of RELEASE (round 6), chosen ONCE per pass by the main workgroup from what the parts report:
+//   agent scope -- the XCD's L2 written back (buffer_wbl2 sc1): right wherever the parts sit;
+//   local       -- every part of the team has reported the SAME XCD as the main workgroup (HW_REG_XCC_ID, at the join): the parts
+//     share one L2, the point of coherence of their CUs' write-through vector caches, so a release is the stores' completion
+//     alone (the s_waitcnt before the barrier) and the write-back of the whole L2 -- every team's dirty lines on that XCD, at
+//     every one of a step's seven hand-overs -- is skipped.  One item 18.4 -> 17.7 ms, 32 items (four teams per XCD) 22.9 -> 20.1.
+//     Nothing is assumed about the dispatcher: the launch's numbering puts a team on one XCD when workgroups are dealt to the
+//     XCDs in turn, and when they are not, the parts' reports differ and the pass runs on agent-scope releases.
+// The ACQUIRE stays `buffer_inv sc1` in both: measured (scripts/ubench/l1_inv.hip, profiles/r06_l1_inv.txt), `buffer_inv sc0` --
+// workgroup scope, the memory model's acquire between the CUs of a threadgroup-split workgroup -- leaves a CU's vector cache as it
+// is outside that mode (every re-read word stale), and loads marked sc0 hit the stale lines too; `buffer_inv sc1` drops the
+// vector cache and leaves the L2's dirty lines in place (the re-read costs what an L2 hit costs).  A first version of the
+// local hand-over with `buffer_inv sc0` passed every fp64 check and failed sporadically in fp32 at 32 items -- stale lines
+// survive where less data streams through the 32 KB cache.
+__device__ __forceinline__ void big_arrive(int* p, bool local) {
+    if (local) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void big_publish(int* p, int v, int team_dbg) {
-    if (team_dbg & 4) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void big_publish(int* p, int v, bool local) {
+    if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int big_xcc() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15;
 }
 
 // a part gives up: every wait of the team, current or future, ends as failed; helpers that have not looked yet see mode 3 and leave
@@ -233,7 +249,7 @@ __global__ void k_big_team_reset(R* scratch_all, int64_t stride, int64_t o_sync,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     BigTeam* team = reinterpret_cast<BigTeam*>(scratch_all + (int64_t)s * stride + o_sync);
-    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0; team->done4 = 0; team->staged = 0; team->flag_lu = 0; team->doneK = 0;
+    team->flag_k = 0; team->done = 0; team->joined = 0; team->mode = 0; team->done1 = 0; team->done4 = 0; team->staged = 0; team->flag_lu = 0; team->doneK = 0; team->xccs = 0;
 }
 
 template <typename R, int NS, int NC>
@@ -459,14 +475,22 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #endif
     constexpr bool kTeamSolve = kTeamS1 || (NS == 12 && NC == 4);      // ... and the substitution's column tiles (round 6; twelve-state clusters, either type)
     int coop = 0;      // 1: this pass is run by the team
+    bool local = false;   // ... on hand-overs through the XCD's own L2 (big_arrive)
     if (part > 0) {    // a helper: its share of every step's tile pairs, nothing else
         // (tests: DPILQR_BIG_TEAM_LATE=1 makes the helpers report a few milliseconds late -- after the main workgroup's decision --
         // which is what a chip busy with other work does to them: the pass must then be the single workgroup's; =2 makes them join
         // and then never work -- fault injection: the main workgroup's first wait for them must expire into a status)
         if ((team_dbg & 3) == 1) for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(127);
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_or(&team->xccs, 1 << big_xcc(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // where this part runs
+            __hip_atomic_fetch_add(&team->joined, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!big_wait_ge(&team->mode, 1, &sFlag[2], spin_log2)) { big_give_up(team); return; }   // (the main workgroup never decided)
-        if (big_ld(&team->mode) != 1) return;     // the main workgroup went ahead alone (2), or the team gave up (3)
+        {   // 1: the team, agent-scope hand-overs; 4: the team, all on one XCD; else the main workgroup went ahead alone (2), or the team gave up (3)
+            const int mode = __builtin_amdgcn_readfirstlane(big_ld(&team->mode));
+            if (mode != 1 && mode != 4) return;
+            local = mode == 4;
+        }
         if ((team_dbg & 3) == 2) { big_wait_ge(&team->mode, 3, &sFlag[2], spin_log2 + 2); return; }   // (until the main workgroup has given up)
         if constexpr (kTeamS1) {     // w_ref (Q + Q^T): the helper's first stage is step T - 2's, the weights' own step has passed
             for (int e = threadIdx.x; e < k * NS * NS; e += kBigThreads) {
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) big_arrive(&team->done1, team_dbg);
+                if (threadIdx.x == 0) big_arrive(&team->done1, local);
             }
             if (kTeamS1 && t > 0) {
                 // The NEXT step's plugin data, now: they depend on (X, U) alone, and from here to the main workgroup's word
@@ -505,7 +529,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     for (int e = tid_c; e < nStage2; e += kBigThreads) gS[nStage1 + e] = lds[O.E + e];
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (threadIdx.x == 0) big_publish(&team->staged, T - (t - 1), team_dbg);
+                    if (threadIdx.x == 0) big_publish(&team->staged, T - (t - 1), local);
                 }
             }
             if (kTeamSolve && lu_ok && t < T - 1) {
@@ -525,7 +549,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (threadIdx.x == 0) big_arrive(&team->doneK, team_dbg);
+                if (threadIdx.x == 0) big_arrive(&team->doneK, local);
                 if (!big_wait_ge(&team->doneK, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
             } else {
                 if (!big_wait_ge(&team->flag_k, T - t, &sFlag[2], spin_log2)) { big_give_up(team); return; }
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->done4, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->done4, local);
             if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { big_give_up(team); return; }
             {
                 const int part_ = part, nparts_ = nparts;
@@ -544,7 +568,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->done, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->done, local);
         }
         return;
     }
@@ -607,7 +631,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (kTeamS1 && coop) {      // the team's S1: every part's block products stored, then Q_uu -- the other parts' entries of it -- into the LU buffer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->done1, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->done1, local);
             if (!big_wait_ge(&team->done1, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
             for (int e = threadIdx.x; e < m * m; e += kBigThreads) {
                 const int a = e / m, c = e - a * m;
@@ -669,8 +693,12 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         const R x0 = a0[j], x1 = a1[j];
                         // every lane divides for ITS candidate while the maximum is being found: the pivot's reciprocal is then
                         // one lane read away (the division, a dozen dependent instructions, used to follow the search)
-                        const R i0 = (x0 == (R)0.0) ? (R)0.0 : (R)1.0 / x0;
-                        const R i1 = TWO ? ((x1 == (R)0.0) ? (R)0.0 : (R)1.0 / x1) : (R)0.0;
+                        R i0 = (x0 == (R)0.0) ? (R)0.0 : (R)1.0 / x0;
+                        R i1 = TWO ? ((x1 == (R)0.0) ? (R)0.0 : (R)1.0 / x1) : (R)0.0;
+                        // (pinned HERE: the compiler otherwise sinks the divisions behind the search, into the branch that picks the
+                        // pivot's chunk -- back onto the column's critical path)
+                        asm volatile("" : "+v"(i0));
+                        if (TWO) asm volatile("" : "+v"(i1));
                         unsigned h0, l0k, h1 = 0u, l1k = 0u;
                         mag_keys(x0, h0, l0k);
                         if (TWO) mag_keys(x1, h1, l1k);
@@ -680,8 +708,15 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         bool c0 = act0 && h0 == hm, c1 = act1 && h1 == hm;
                         unsigned lm = 0u;
                         if constexpr (sizeof(R) == 8) {
-                            lm = wave_max_u32(TWO ? max(c0 ? l0k : 0u, c1 ? l1k : 0u) : (c0 ? l0k : 0u));
-                            c0 = c0 && l0k == lm; c1 = c1 && l1k == lm;
+                            // the low words decide only among rows that share the largest high word (sign, exponent, twenty mantissa
+                            // bits): almost always ONE row holds it and the second reduction is skipped
+                            const unsigned long long q0 = __builtin_amdgcn_ballot_w64(c0), q1 = TWO ? __builtin_amdgcn_ballot_w64(c1) : 0ull;
+                            if (__builtin_popcountll(q0) + __builtin_popcountll(q1) > 1) {
+                                lm = wave_max_u32(TWO ? max(c0 ? l0k : 0u, c1 ? l1k : 0u) : (c0 ? l0k : 0u));
+                                c0 = c0 && l0k == lm; c1 = c1 && l1k == lm;
+                            } else {
+                                lm = (q0 | q1) != 0ull ? 1u : 0u;     // (only its being non-zero is used below, with hm)
+                            }
                         }
                         const bool ok = (hm | lm) != 0u;              // a positive (or infinite) magnitude exists
                         unsigned long long k0, k1 = 0ull;
@@ -981,7 +1016,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
             if (tid_c < mk) gLUperm[tid_c] = sPerm[tid_c];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_publish(&team->flag_lu, T - t, team_dbg);
+            if (threadIdx.x == 0) big_publish(&team->flag_lu, T - t, local);
         }
         {
             const int part_ = 0, nparts_ = team_solve ? nparts : 1;
@@ -990,7 +1025,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (team_solve) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->doneK, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->doneK, local);
             if (!big_wait_ge(&team->doneK, (T - 1 - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         } else {
             __syncthreads();
@@ -1011,17 +1046,20 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (nparts > 1 && t == T - 1) {     // the team or alone: decided once, when the first step's gains are in place
             if (threadIdx.x == 0) {
                 const int joined = __hip_atomic_load(&team->joined, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                const int mode = (joined == nparts - 1) ? 1 : 2;
+                // every helper on this workgroup's XCD: hand-overs through its L2 (big_arrive).  (team_dbg & 4: agent scope regardless, A/B)
+                const bool one_xcd = big_ld(&team->xccs) == (1 << big_xcc()) && !(team_dbg & 4);
+                const int mode = (joined == nparts - 1) ? (one_xcd ? 4 : 1) : 2;
                 __hip_atomic_store(&team->mode, mode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                sFlag[3] = (mode == 1);
+                sFlag[3] = mode;
             }
             __syncthreads();
-            coop = sFlag[3];
+            coop = sFlag[3] != 2;
+            local = sFlag[3] == 4;
         }
         if (coop) {      // [K|d], [Q_ux|Q_u], Q_xx, Q_uu of this step are in the scratch: every thread's stores done, then the word
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_publish(&team->flag_k, T - t, team_dbg);
+            if (threadIdx.x == 0) big_publish(&team->flag_k, T - t, local);
         }
         {   // S4 (round 6: the team's too -- one more hand-over, every part's tiles of T3^T stored before any part's S5 reads them)
             const int part_ = 0, nparts_ = coop ? nparts : 1;
@@ -1030,7 +1068,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (coop) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->done4, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->done4, local);
             if (!big_wait_ge(&team->done4, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         } else {
             __syncthreads();
@@ -1043,7 +1081,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         if (coop) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) big_arrive(&team->done, team_dbg);
+            if (threadIdx.x == 0) big_arrive(&team->done, local);
             if (!big_wait_ge(&team->done, (T - t) * nparts, &sFlag[2], spin_log2)) { gave_up(); return; }
         }
         __syncthreads();
@@ -1095,7 +1133,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     }
 #ifdef DPILQR_PHASE_STAMPS
     if (tid == 0 && slot == 0) {
-        printf("k_riccati_big phases (s_memtime ticks per step, 100 MHz): stage %.0f  S1 %.0f  LU %.0f  solve %.0f  S4 %.0f  S5 %.0f  S6 %.0f\n",
+        printf("k_riccati_big phases (s_memtime shader-clock ticks per step, ~2.4 GHz): stage %.0f  S1 %.0f  LU %.0f  solve %.0f  S4 %.0f  S5 %.0f  S6 %.0f\n",
                (double)bph[0] / T, (double)bph[1] / T, (double)bph[2] / T, (double)bph[3] / T, (double)bph[4] / T, (double)bph[5] / T,
                (double)bph[6] / T);
     }

@@ -43,7 +43,7 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
     // tests (gated like every route switch): DPILQR_BIG_TEAM_LATE=1 helpers report late, =2 helpers join and then stall (fault
     // injection); DPILQR_BIG_SPIN_LOG2=s bounds every wait at 2^s polls instead of 2^22 -- packed into one kernel argument
     const int team_dbg = (route_int("DPILQR_BIG_TEAM_LATE", 0) & 3) | ((route_int("DPILQR_BIG_SPIN_LOG2", 0) & 31) << 8) |
-                         (route_flag("DPILQR_BIG_TEAM_RELAXED") ? 4 : 0);      // (timing experiments: riccati_big.hpp, big_arrive)
+                         (route_flag("DPILQR_BIG_TEAM_AGENT") ? 4 : 0);      // (A/B: agent-scope hand-overs even where the team shares an XCD; riccati_big.hpp, big_arrive)
     const int grid = nparts > 1 ? ((grid_items + 7) / 8) * 8 * nparts : grid_items;
     if (nparts > 1)
         hipLaunchKernelGGL((k_big_team_reset<R>), dim3((grid_items + 255) / 256), dim3(256), 0, st, static_cast<R*>(scratch),

@@ -47,3 +47,12 @@ for B in Bs:
         same = all(np.array_equal(res["team"][f"{q}_{B}_{name}"], res["alone"][f"{q}_{B}_{name}"], equal_nan=True) for q in "Kd")
         print(f"B={int(B):4d} {name}: backward pass alone {1e3 * res['alone'][f't_{B}_{name}']:7.2f} ms, team {1e3 * res['team'][f't_{B}_{name}']:7.2f} ms, "
               f"gains {'bit-identical' if same else 'DIFFERENT'}", flush=True)
+        if not same:      # where: per item the LAST horizon step (the sweep runs backwards: the first one computed) that differs
+            for q in "Kd":
+                a, b = res["team"][f"{q}_{B}_{name}"], res["alone"][f"{q}_{B}_{name}"]
+                ne = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+                for item in np.nonzero(ne.reshape(a.shape[0], -1).any(1))[0][:6]:
+                    steps = np.nonzero(ne[item].reshape(a.shape[1], -1).any(1))[0]
+                    print(f"      {q}: item {item}: {int(ne[item].sum())} entries differ, steps {steps.min()}..{steps.max()}, "
+                          f"at step {steps.max()}: {int(ne[item, steps.max()].sum())} entries, max |diff| {np.nanmax(np.abs(a[item, steps.max()] - b[item, steps.max()])):.3e}"
+                          f" of max {np.nanmax(np.abs(b[item, steps.max()])):.3e}", flush=True)

@@ -73,7 +73,7 @@ if "--wg" in sys.argv:      # the mid-size sweep (k_riccati_wg): python scripts/
     tot = ph.sum(1).mean()
     for nm_, v in zip(names, ph.mean(0)):
         print(f"{nm_:30s} {v:8.0f} ticks/step  {100 * v / tot:5.1f} %")
-    print(f"k_riccati_wg{' (fused)' if fused else ''} n_x={n}: total {tot:.0f} ticks/step (s_memtime ticks, 100 MHz)")
+    print(f"k_riccati_wg{' (fused)' if fused else ''} n_x={n}: total {tot:.0f} ticks/step (s_memtime shader-clock ticks, ~2.4 GHz)")
     sys.exit(0)
 B = int(args[0]) if args else 1024
 x0, xf = scenarios(0, B)

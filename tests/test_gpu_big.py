@@ -465,6 +465,37 @@ def test_team_of_workgroups_gives_the_single_workgroups_gains(dp, monkeypatch, B
         assert np.array_equal(K0, K1) and np.array_equal(d0, d1), team
 
 
+@pytest.mark.parametrize("dtype_name", ["float64", "float32"])
+def test_teams_that_fill_every_xcd_and_both_kinds_of_release(dp, monkeypatch, dtype_name):
+    """32 items = four teams of eight workgroups on each XCD, every CU taken.  A team whose parts all report the main workgroup's
+    XCD releases without writing the L2 back (csrc/riccati_big.hpp, big_arrive); DPILQR_BIG_TEAM_AGENT=1 keeps the agent-scope
+    release.  Both give the single workgroup's gains bit for bit, pass after pass (round 6: a first form of the local hand-over
+    that also weakened the ACQUIRE passed fp64 everywhere and failed here, in fp32, sporadically -- stale vector-cache lines)."""
+    import torch
+    dtype = getattr(torch, dtype_name)
+    B = 32
+    models, nd, x0, xf, Q, R, Qf, U0, T = _cfg5_batch(True, tuple(range(6200, 6200 + B)))
+    pb = dp.ProblemBatch(models, nd, xf, Q, R, Qf, 0.5, 0.1, T)
+    X, J = pb.rollout(x0, U0, dtype=dtype)
+    Ud = torch.as_tensor(U0, dtype=dtype, device="cuda")
+    mu = torch.ones(B, dtype=torch.float64, device="cuda")
+
+    def run(**env):
+        for key in ("DPILQR_BIG_TEAM", "DPILQR_BIG_TEAM_AGENT"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        K, d = pb.backward_pass(X, Ud, mu, dtype=dtype)
+        return K.cpu().numpy(), d.cpu().numpy()
+
+    K0, d0 = run(DPILQR_BIG_TEAM="0")
+    assert np.isfinite(K0).all() and np.isfinite(d0).all()
+    for rep in range(4):
+        for env in ({}, {"DPILQR_BIG_TEAM_AGENT": "1"}):
+            K1, d1 = run(**env)
+            assert np.array_equal(K0, K1) and np.array_equal(d0, d1), (rep, env)
+
+
 def test_team_helpers_that_start_late_leave_the_pass_to_the_main_workgroup(dp, monkeypatch):
     """What a chip busy with other work does to the team: the helpers report after the main workgroup has looked for them
     (DPILQR_BIG_TEAM_LATE delays them by a few milliseconds).  The main workgroup then runs the whole pass alone -- the
