@@ -33,6 +33,7 @@ template <> struct FwdMfma<float> {
     __device__ static __forceinline__ int row(int v, int g) { return 4 * g + v; }
 };
 
+constexpr int kFwdBatch = 12;  // PIPE: reduction steps of K[t] dx per register set of A operands, two sets (forward.hpp, horizon_pass)
 constexpr int kMaxStage = 16;  // K[t] elements a thread stages per step (per chunk, kdirect): ceil(n_u*n_x / threads) must not exceed this
 
 struct ForwardLds {   // offsets in elements of the arithmetic type
@@ -131,7 +132,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
     // read consecutive columns of a row (coalesced) and store column by column (ForwardLds)
     const int n_chunks = KDIRECT ? (n + O.cw - 1) / O.cw : 0;
     int ck_src[KDIRECT ? kMaxStage : 1], ck_dst[KDIRECT ? kMaxStage : 1];
-    if constexpr (KDIRECT && GAINS) {
+    if constexpr (KDIRECT && GAINS && !PIPE) {
 #pragma unroll
         for (int q = 0; q < kMaxStage; ++q) {
             const int e = tid + q * nth;
@@ -141,7 +142,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
         }
     }
     auto fetch_chunk = [&](int t, int ch) {  // registers <- HBM for chunk ch of K[t]
-        if constexpr (KDIRECT && GAINS) {
+        if constexpr (KDIRECT && GAINS && !PIPE) {
             const R* Kt = Kb + (int64_t)t * mn + ch * O.cw;
             const int left = n - ch * O.cw;   // columns of the matrix from this chunk's first on
             // (no load behind a test: an element outside the chunk -- e >= m cw, or column jj = dst / rs >= left in the last chunk --
@@ -180,11 +181,29 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
             for (int i = 0; i < NS; ++i) Xw[a * NS + i] = x[i];
         }
     }
+    // PIPE: this lane's A operands (see the products below), kFwdBatch reduction steps per set, two sets used in turn
+    R pkA0[PIPE ? kFwdBatch : 1], pkA1[PIPE ? kFwdBatch : 1], pkB0[PIPE ? kFwdBatch : 1], pkB1[PIPE ? kFwdBatch : 1];
+    bool pk_two = false;
+    int64_t pk_o0 = 0, pk_o1 = 0;
+    if constexpr (PIPE && KDIRECT && GAINS) {
+        const int wv = tid >> 6, ln = tid & 63, g16 = ln >> 4, c16 = ln & 15, nw = nth >> 6;
+        const int r0 = 16 * wv + c16, r1 = 16 * (wv + nw) + c16;
+        const bool pk_v0 = r0 < m, pk_v1 = r1 < m;
+        pk_two = __builtin_amdgcn_readfirstlane((int)(16 * (wv + nw) < O.mt)) != 0;    // this wavefront has a second row tile
+        pk_o0 = (int64_t)(pk_v0 ? r0 : 0) * n; pk_o1 = (int64_t)(pk_v1 ? r1 : 0) * n;
+        (void)g16;
+    }
     fetch(0);
     fetch_chunk(0, 0);
     int ck_buf = 0;   // KDIRECT: the chunk buffer the next chunk goes into
     R J = 0.0;
 
+#ifdef DPILQR_FWD_STAMPS      // diagnostic builds only: thread 0's clock per part of a step (scripts/r06_fwd_phases.sh)
+    unsigned long long fph[6] = {0, 0, 0, 0, 0, 0}, fph_t = __builtin_amdgcn_s_memtime();
+#define FPHASE(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); fph[i] += now_ - fph_t; fph_t = now_; }
+#else
+#define FPHASE(i)
+#endif
     for (int t = 0; t < T; ++t) {
         const int par = t & 1;
         R* sKt = lds + O.Kt + par * (KDIRECT ? 0 : mn);
@@ -213,30 +232,117 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
         }
         if (t + 1 < T) fetch(t + 1);
         lds_handoff(single_wave);
+        FPHASE(0)
         R ksum[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) ksum[c] = 0.0;
         if constexpr (KDIRECT && GAINS) {
-            // K[t] dx of ALL candidates at once, chunk by chunk: this chunk from the registers into its buffer, the next one requested
-            // (the first of step t + 1 behind the last of step t), one barrier, then -- round 6 -- the chunk's columns on the MATRIX
-            // PIPE: du[row][candidate] += K[row][j] dx_candidate[j] is a (m x cw)(cw x n_alpha) product, 16 x 16 x 4 tiles with the
-            // candidates as the tile's columns (10 of 16), the row tiles dealt to the wavefronts, accumulated over the chunks -- j
-            // ascending, one multiply-add per term.  Rounds 2-5 walked a chunk's columns per (candidate, agent) lane: every entry of
-            // K[t] read from LDS once per candidate, 68 k of a step's 170 k clocks at cfg5's size.  The buffer written in one round
-            // was last read two rounds earlier, and every thread has passed the barrier in between.
-            typedef typename FwdMfma<R>::acc_t acc_t;
-            const int wv = tid >> 6, ln = tid & 63, g16 = ln >> 4, c16 = ln & 15, nw = nth >> 6;
-            const int tiles = O.mt / 16;
-            // (PIPE: the launcher's promise that every wavefront has at most two row tiles and a tile's sixteen columns hold the
-            // candidates -- forward_on_pipe below; otherwise the lanes' own sums, another instantiation)
-            constexpr bool on_pipe = PIPE;
-            acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
-            const int it0 = wv, it1 = wv + nw;
-            // this lane's A rows (K[t]'s rows 16 it + c16, where they stand inside a chunk column) and its B column (candidate c16)
-            const int r0 = 16 * it0 + c16, r1 = 16 * it1 + c16;
-            const int ao0 = (r0 % NC) * k + r0 / NC, ao1 = (r1 % NC) * k + r1 / NC;
-            const bool av0 = it0 < tiles && r0 < m, av1 = it1 < tiles && r1 < m, bv = c16 < ngrp;
-            const R* dxc = lds + O.dx + (par * ngrp + (bv ? c16 : 0)) * n;
+            // K[t] dx of ALL candidates at once.  PIPE (round 6): du[row][candidate] += K[row][j] dx_candidate[j] is a (m x n)(n x
+            // n_alpha) product on the MATRIX PIPE, 16 x 16 x 4 tiles with the candidates as the tile's columns (10 of 16), the row tiles
+            // dealt to the wavefronts (forward_on_pipe: at most two each) -- j ascending, one multiply-add per term.  Otherwise
+            // (rounds 2-5) chunk by chunk through LDS: this chunk from the registers into its buffer, the next one requested (the first
+            // of step t + 1 behind the last of step t), one barrier, then every (candidate, agent) lane walks the chunk's columns --
+            // every entry of K[t] read from LDS once per candidate, 68 k of a step's 170 k clocks at cfg5's size.  The buffer written
+            // in one round was last read two rounds earlier, and every thread has passed the barrier in between.
+            if constexpr (PIPE) {
+                // Round 6, second form: the matrix pipe's A operand straight from global memory.  Lane (g16, c16) of a row tile supplies
+                // K[t][16 it + c16][4 s + g16] in reduction step s -- its own row, every fourth column -- so a wavefront's load is sixteen
+                // 32-byte pieces of sixteen rows, four consecutive steps share a cache line, and nothing is staged: no chunk buffers, no
+                // barrier per chunk, no round of global latency per chunk (ten chunks per step, each one load in flight deep, were 45 k
+                // of a step's 160 k clocks at cfg5's size; scripts/r06_fwd_phases.sh).  Two register sets of kFwdBatch reduction steps
+                // each are requested before the first product and a set is requested again as soon as its products are issued.
+                // (Measured and dropped: touching K[t + 1]'s cache lines a step ahead so that they wait in the L2 -- no change.)
+                // The wavefront's own instruction stream matters as much (one wavefront per SIMD issues an instruction every four
+                // clocks at best; a first version spent ~40 instructions per reduction step on addresses, clamps and selects): a step
+                // is ONE 64-bit address per row tile and batch, every load and every LDS read of the batch at an immediate offset from
+                // it, and no select at all -- rows of K beyond n_u and candidates beyond n_alpha produce rows / columns of the tile
+                // that nobody reads (a product's rows and columns do not mix), so their operands are whatever the clamped addresses
+                // hold.  Only a batch that reaches past column n_x (none at cfg5's size) takes the form with clamps and zeroed
+                // operands.  Same products, same order: j ascending, one multiply-add per term.  The phase: 45 k -> 25 k clocks per step
+                // (of which 14 k without any operand load: 120 dependent products of 64 clocks on the wavefront that holds two row
+                // tiles, the LDS reads, the hand-over of du); the ten-candidate pass 9.96 -> 8.3 ms.
+                typedef typename FwdMfma<R>::acc_t acc_t;
+                const int wv = tid >> 6, ln = tid & 63, g16 = ln >> 4, c16 = ln & 15, nw = nth >> 6;
+                const int tiles = O.mt / 16;
+                acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+                const int it0 = wv, it1 = wv + nw;
+                const bool two = pk_two;
+                const bool bv = c16 < ngrp;
+                const R* dxc = lds + O.dx + (par * ngrp + (bv ? c16 : 0)) * n;
+                const int nks = (n + 3) >> 2;
+                const R* Kt = Kb + (int64_t)t * mn;
+                auto whole = [&](int s0) { return 4 * (s0 + kFwdBatch) <= n; };     // every column of the batch exists, in every lane group
+                auto load = [&](R (&k0)[kFwdBatch], R (&k1)[kFwdBatch], int s0) __attribute__((always_inline)) {
+                    if (whole(s0)) {
+                        const R* q0 = Kt + pk_o0 + 4 * s0 + g16;
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) k0[q] = q0[4 * q];
+                        if (two) {      // (wave-uniform, and known to be: a branch, not a masked region around every load)
+                            const R* q1 = Kt + pk_o1 + 4 * s0 + g16;
+#pragma unroll
+                            for (int q = 0; q < kFwdBatch; ++q) k1[q] = q1[4 * q];
+                        }
+                    } else {        // (no load behind a test: a column beyond the row's end reads the row's last entry instead)
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) k0[q] = Kt[pk_o0 + min(4 * (s0 + q) + g16, n - 1)];
+                        if (two) {
+#pragma unroll
+                            for (int q = 0; q < kFwdBatch; ++q) k1[q] = Kt[pk_o1 + min(4 * (s0 + q) + g16, n - 1)];
+                        }
+                    }
+                };
+                auto products = [&](const R (&k0)[kFwdBatch], const R (&k1)[kFwdBatch], int s0) __attribute__((always_inline)) {
+                    R bq[kFwdBatch];
+                    if (whole(s0)) {
+                        const R* d0 = dxc + 4 * s0 + g16;
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) bq[q] = d0[4 * q];
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) acc0 = FwdMfma<R>::mac(k0[q], bq[q], acc0);
+                        if (two) {
+#pragma unroll
+                            for (int q = 0; q < kFwdBatch; ++q) acc1 = FwdMfma<R>::mac(k1[q], bq[q], acc1);
+                        }
+                    } else {        // a column beyond the last: both operands zero, the product adds nothing
+                        bool jv[kFwdBatch];
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) {
+                            const int jj = 4 * (s0 + q) + g16;
+                            jv[q] = jj < n;
+                            R b = dxc[jv[q] ? jj : 0];
+                            asm volatile("" : "+v"(b));      // (requested whatever jv says: behind the test, every read is a masked region with its own wait)
+                            bq[q] = jv[q] ? b : (R)0.0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < kFwdBatch; ++q) acc0 = FwdMfma<R>::mac(jv[q] ? k0[q] : (R)0.0, bq[q], acc0);
+                        if (two) {
+#pragma unroll
+                            for (int q = 0; q < kFwdBatch; ++q) acc1 = FwdMfma<R>::mac(jv[q] ? k1[q] : (R)0.0, bq[q], acc1);
+                        }
+                    }
+                };
+                load(pkA0, pkA1, 0);
+                load(pkB0, pkB1, kFwdBatch);
+                for (int s0 = 0; s0 < nks; s0 += 2 * kFwdBatch) {
+                    products(pkA0, pkA1, s0);
+                    if (s0 + 2 * kFwdBatch < nks) load(pkA0, pkA1, s0 + 2 * kFwdBatch);
+                    if (s0 + kFwdBatch < nks) products(pkB0, pkB1, s0 + kFwdBatch);
+                    if (s0 + 3 * kFwdBatch < nks) load(pkB0, pkB1, s0 + 3 * kFwdBatch);
+                }
+                // the tiles' entries to where the agents' lanes find them: du[candidate][row]
+                R* sdu = lds + O.du;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ra = 16 * it0 + FwdMfma<R>::row(v, g16), rb = 16 * it1 + FwdMfma<R>::row(v, g16);
+                    if (bv && it0 < tiles) sdu[c16 * O.mt + ra] = acc0[v];
+                    if (bv && two) sdu[c16 * O.mt + rb] = acc1[v];
+                }
+                lds_handoff(single_wave);
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) ksum[c] = sdu[g * O.mt + a * NC + c];
+                }
+            } else {
             for (int ch = 0; ch < n_chunks; ++ch) {
                 R* sKc = lds + O.Kt + ck_buf * (O.cw * O.rs + 2);
                 const int left = n - ch * O.cw, cwa = left < O.cw ? left : O.cw;
@@ -246,21 +352,6 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 if (ch + 1 < n_chunks) fetch_chunk(t, ch + 1);
                 else if (t + 1 < T) fetch_chunk(t + 1, 0);
                 lds_handoff(single_wave);
-                if constexpr (on_pipe) {
-                    const R* dxp = dxc + ch * O.cw;
-                    for (int j4 = 0; j4 < cwa; j4 += 4) {
-                        const int jj = j4 + g16;
-                        const bool jv = jj < cwa;
-                        const int jc = jv ? jj : 0;
-                        const R bq = (bv && jv) ? dxp[jc] : (R)0.0;
-                        const R a0q = (av0 && jv) ? sKc[jc * O.rs + ao0] : (R)0.0;
-                        acc0 = FwdMfma<R>::mac(a0q, bq, acc0);
-                        if (it1 < tiles) {
-                            const R a1q = (av1 && jv) ? sKc[jc * O.rs + ao1] : (R)0.0;
-                            acc1 = FwdMfma<R>::mac(a1q, bq, acc1);
-                        }
-                    }
-                } else {
                   if (active) {
                     const R* colp = sKc + a;
                     const R* dxp = sdx + ch * O.cw;
@@ -286,31 +377,18 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                         for (int c = 0; c < NC; ++c) ksum[c] += colp[jj * O.rs + c * k] * dxj;
                     }
                   }
-                }
                 ck_buf ^= 1;
             }
-            if constexpr (on_pipe) {
-                // the tiles' entries to where the agents' lanes find them: du[candidate][row]
-                R* sdu = lds + O.du;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int ra = 16 * it0 + FwdMfma<R>::row(v, g16), rb = 16 * it1 + FwdMfma<R>::row(v, g16);
-                    if (bv && it0 < tiles) sdu[c16 * O.mt + ra] = acc0[v];
-                    if (bv && it1 < tiles) sdu[c16 * O.mt + rb] = acc1[v];
-                }
-                lds_handoff(single_wave);
-                if (active) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) ksum[c] = sdu[g * O.mt + a * NC + c];
-                }
             }
         }
+        FPHASE(1)
         if (active && a == 0 && t > 0) {  // stage cost of step t-1 (other parity), summed in the reference's order
             const R* cr = lds + O.cref + ((par ^ 1) * ngrp + g) * k;
             const R* cp = lds + O.cpair + ((par ^ 1) * ngrp + g) * np1;
             const R prox = sum_in_order(cp, npairs), ref = sum_in_order(cr, k);
             J += w_prox * prox + w_ref * ref;
         }
+        FPHASE(2)
         if (active) {
             if (GAINS) {  // du = K[t] dx + alpha d[t] (control.py:106), this agent's NC rows, j ascending
                 R sum[NC];
@@ -345,6 +423,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 }
             }
             lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, ut, xf, Qa, Ra, false);
+            FPHASE(3)
             // the candidate's pairs dealt evenly: agent a takes (a, a + 1), ..., (a, a + k / 2) mod k -- at most k / 2 each instead of
             // k - 1 for agent 0 -- each computed as (lower, higher) and put where the sum in combinations order finds it
             for (int dd = 1; 2 * dd <= k; ++dd) {
@@ -355,6 +434,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 lds[O.cpair + (par * ngrp + g) * np1 + pair_index(lo, hi, k)] =
                     pair_cost(sxs + lo * NS, sxs + hi * NS, nd, radius);
             }
+            FPHASE(4)
             if (Uw) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) Uw[(int64_t)t * m + a * NC + c] = ut[c];
@@ -368,7 +448,13 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 for (int i = 0; i < NS; ++i) Xw[(int64_t)(t + 1) * n + a * NS + i] = x[i];
             }
         }
+        FPHASE(5)
     }
+#ifdef DPILQR_FWD_STAMPS
+    if (tid == 0 && blockIdx.x == 0)
+        printf("horizon_pass<NS %d, GAINS %d> phases (thread 0's shader clocks per step): stage+handoff %.0f  K dx %.0f  stage-cost sum %.0f  du + ref_cost %.0f  pair costs %.0f  integrate + stores %.0f\n",
+               NS, (int)GAINS, (double)fph[0] / T, (double)fph[1] / T, (double)fph[2] / T, (double)fph[3] / T, (double)fph[4] / T, (double)fph[5] / T);
+#endif
     {
         // last stage cost, then the terminal cost cost(X[T], 0, terminal=True) (control.py:91,112)
         const int par = T & 1;

@@ -15,6 +15,8 @@
 
 #include <type_traits>
 
+#include "trig_inline.hpp"
+
 namespace dpilqr {
 
 constexpr double kGrav = 9.80665;  // bbdynamics.cpp:11
@@ -182,9 +184,25 @@ template <> struct ModelDef<kQuadcopter12D> {
     static constexpr double kCz = 9976479919918.0 / 271597947137541.0;
     template <typename R> __device__ static void f(const R* x, const R* u, R* o) {
         // (sincos: one argument reduction per angle for both values -- the same values as sin(), cos())
-        R sps, cps, sth, cth, sph, cph;
-        sincos_r(x[3], &sps, &cps); sincos_r(x[4], &sth, &cth); sincos_r(x[5], &sph, &cph);
-        const R tth = tan(x[4]);
+        // fp64, round 6: the three sincos and the tan as ONE basic block (trig_inline.hpp: the library's own small-argument
+        // algorithm, bit for bit, its branch taken once for all four) -- their dependent chains interleave and tan(theta) shares
+        // theta's reduction; an angle of 2^30 or more, or not finite, in any lane sends the wavefront to the library calls
+        R sps, cps, sth, cth, sph, cph, tth;
+        bool done = false;
+        if constexpr (sizeof(R) == 8) {
+            if (trig_small_all(x[3], x[4], x[5])) {
+                const TrigRed r3 = trig_reduce(x[3]), r4 = trig_reduce(x[4]), r5 = trig_reduce(x[5]);
+                double s_[3], c_[3];
+                trig_sincos(x[3], r3, &s_[0], &c_[0]); trig_sincos(x[4], r4, &s_[1], &c_[1]); trig_sincos(x[5], r5, &s_[2], &c_[2]);
+                sps = s_[0]; cps = c_[0]; sth = s_[1]; cth = c_[1]; sph = s_[2]; cph = c_[2];
+                tth = trig_tan(x[4], r4);
+                done = true;
+            }
+        }
+        if (!done) {
+            sincos_r(x[3], &sps, &cps); sincos_r(x[4], &sth, &cth); sincos_r(x[5], &sph, &cph);
+            tth = tan(x[4]);
+        }
         const R vx = x[6], vy = x[7], vz = x[8], wx = x[9], wy = x[10], wz = x[11];
         o[0] = vx * cps * cth + vy * (sph * sth * cps - sps * cph) + vz * (sph * sps + sth * cph * cps);
         o[1] = vx * sps * cth + vy * (sph * sps * sth + cph * cps) + vz * (-sph * cps + sps * sth * cph);
