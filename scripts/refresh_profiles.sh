@@ -18,6 +18,9 @@ python scripts/bench_big.py 1 8 32 256 2>&1 | q > gpurun_out/${R}_cfg5_bench_big
 python scripts/big_team_check.py 1 8 32 64 128 2>&1 | q > gpurun_out/${R}_big_team.txt
 python scripts/cfg5_solve_time.py 8 2>&1 | q > gpurun_out/${R}_cfg5_solve.txt
 python scripts/bench_ls_sizes.py uni4:15 uni4:14 uni4:12 uni4:8 quad6:10 quad6:8 quad6:6 2>&1 | q > gpurun_out/${R}_ls_sizes.txt
-python scripts/kernel_resources.py > gpurun_out/${R}_kernel_resources.csv 2>/dev/null
+python scripts/kernel_resources.py --csv gpurun_out/${R}_kernel_resources.csv > /dev/null 2>&1
+ROUND=$R bash scripts/profile_configs.sh > gpurun_out/${R}_profile_configs.log 2>&1
+scripts/ubench/l1_inv > gpurun_out/${R}_l1_inv_raw.txt 2>&1; scripts/ubench/mfma_chain > gpurun_out/${R}_mfma_chain.txt 2>&1; scripts/ubench/trig_inline_check > gpurun_out/${R}_trig_inline_check.txt 2>&1
+bash scripts/r06_fwd_phases.sh > /dev/null 2>&1
 tail -3 gpurun_out/${R}_cfg4.log | cut -c1-300; tail -3 gpurun_out/${R}_cfg3.log | cut -c1-300; tail -4 gpurun_out/${R}_cfg5_bench_big.txt | cut -c1-200
 cut -c1-250 gpurun_out/${R}_bench_20steps.json; cut -c1-250 gpurun_out/${R}_bench_100steps.json
