@@ -71,8 +71,9 @@ __device__ inline void pair_quadraticize(const R* pa, const R* pb, int nd, R rad
 
 // ReferenceCost.__call__ (cost.py:79-83) for one agent: ((e @ M) @ e) [+ ((u @ R) @ u)].  The weights and the goal
 // come from the descriptor (fp64) and are rounded to the arithmetic type on use.
-template <int NS, int NC, typename R>
-__device__ inline R ref_cost(const R* x, const R* u, const double* xf, const double* M, const double* Rm, bool terminal) {
+// W: the weights' and the goal's storage type -- double in the descriptor, R where a kernel has staged them (forward.hpp: LDS)
+template <int NS, int NC, typename R, typename W = double>
+__device__ inline R ref_cost(const R* x, const R* u, const W* xf, const W* M, const W* Rm, bool terminal) {
     R e[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) e[i] = x[i] - R(xf[i]);

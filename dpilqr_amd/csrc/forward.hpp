@@ -84,12 +84,36 @@ __device__ __forceinline__ void lds_handoff(bool single_wave) {
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// p[0] + p[1] + ... + p[count - 1] added in that order (the reference's stage-cost sums), the loads eight at a time: one thread
-// per candidate walks 190 pair costs at cfg5's size, and a load -> add -> load chain is an LDS round trip per term
+// p[0] + p[1] + ... + p[count - 1] added in that order (the reference's stage-cost sums).  One thread per candidate walks 190 pair
+// costs at cfg5's size while the rest of its wavefront waits: the loads sixteen at a time and a set AHEAD of the additions (a
+// load -> add -> load chain is an LDS round trip per term; eight at a time without the look-ahead: 7 k of a step's 135 k clocks)
 template <typename R>
 __device__ __forceinline__ R sum_in_order(const R* p, int count) {
+    constexpr int W = 16;
     R s = 0.0;
     int i = 0;
+    if (count >= 2 * W) {
+        R va[W], vb[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) va[q] = p[q];
+        for (; i + 2 * W <= count; i += 2 * W) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) vb[q] = p[i + W + q];
+#pragma unroll
+            for (int q = 0; q < W; ++q) s += va[q];
+            // (the set after next; beyond the end it re-reads the array's last full set -- never used)
+            const int nx = i + 3 * W <= count ? i + 2 * W : count - W;
+#pragma unroll
+            for (int q = 0; q < W; ++q) va[q] = p[nx + q];
+#pragma unroll
+            for (int q = 0; q < W; ++q) s += vb[q];
+        }
+        if (i + W <= count) {      // va holds p[i .. i + W)
+#pragma unroll
+            for (int q = 0; q < W; ++q) s += va[q];
+            i += W;
+        }
+    }
     for (; i + 8 <= count; i += 8) {
         R v[8];
 #pragma unroll
@@ -127,6 +151,22 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
     const double* Qa = P.Q + a * NS * NS;
     const double* Ra = P.R + a * NC * NC;
     const double* Qfa = P.Qf + a * NS * NS;
+    // PIPE (round 6): the running cost's weights and the goals staged once in LDS, in the arithmetic type, where the chunk buffers of
+    // the other form would be: every lane read its agent's Q -- 144 entries at twelve states -- from global memory at every step, one
+    // load instruction per entry with twenty distinct lines in it, and the four wavefronts' 576 such instructions per step were 13 k of
+    // a step's 135 k clocks at cfg5's size (the one-wavefront rollout: 3 k).  Rows of an agent 1 mod 2 doubles apart from the next
+    // agent's: the candidates of an agent read one word, the agents of a candidate different banks.
+    constexpr int kWq = NS * NS + 1, kWr = NC * NC, kWx = NS;
+    constexpr bool w_lds = PIPE && KDIRECT && GAINS;      // (the launcher's promise that they fit: forward_on_pipe)
+    R* const sWq = lds + O.Kt;
+    R* const sWr = sWq + k * kWq;
+    R* const sWx = sWr + k * kWr;
+    if (w_lds) {
+        for (int e = tid; e < k * NS * NS; e += nth) sWq[(e / (NS * NS)) * kWq + e % (NS * NS)] = (R)P.Q[e];
+        for (int e = tid; e < k * kWr; e += nth) sWr[e] = (R)P.R[e];
+        for (int e = tid; e < k * kWx; e += nth) sWx[e] = (R)P.xf[e];
+        lds_handoff(single_wave);
+    }
 
     // KDIRECT: K[t] in chunks of O.cw columns.  Element e = tid + q nth of a chunk is (row e / cw, column e % cw): consecutive threads
     // read consecutive columns of a row (coalesced) and store column by column (ForwardLds)
@@ -173,6 +213,15 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
         }
     };
 
+    // the dimensions of this agent's pairs (min of the two agents' n_dims, cost.py:145), two bits per partner offset: read from the
+    // descriptor once -- inside the pair loop the two loads per pair and step were most of its 10 k clocks at cfg5's size
+    unsigned long long nd_pack = 0ull;
+    if (active && !homog) {
+        for (int dd = 1; 2 * dd <= k && dd < 32; ++dd) {
+            const int o = a + dd < k ? a + dd : a + dd - k;
+            nd_pack |= (unsigned long long)(min(P.n_dims[a], P.n_dims[o]) & 3) << (2 * dd);
+        }
+    }
     if (active) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = x_init[a * NS + i];
@@ -422,15 +471,18 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                     ut[c] = ut[c] + du;
                 }
             }
-            lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, ut, xf, Qa, Ra, false);
+            if constexpr (w_lds) lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC, R, R>(x, ut, sWx + a * kWx, sWq + a * kWq, sWr + a * kWr, false);
+            else lds[O.cref + (par * ngrp + g) * k + a] = ref_cost<NS, NC>(x, ut, xf, Qa, Ra, false);
             FPHASE(3)
             // the candidate's pairs dealt evenly: agent a takes (a, a + 1), ..., (a, a + k / 2) mod k -- at most k / 2 each instead of
             // k - 1 for agent 0 -- each computed as (lower, higher) and put where the sum in combinations order finds it
+            // (measured and dropped, round 6: four pairs at a time -- positions requested together, one test for the square root per group;
+            // the loop got no faster, 9.1 k clocks per step, and the other phases' register shuffling cost more than it saved)
             for (int dd = 1; 2 * dd <= k; ++dd) {
                 if (2 * dd == k && a >= dd) break;
                 const int o = a + dd < k ? a + dd : a + dd - k;
                 const int lo = a < o ? a : o, hi = a < o ? o : a;
-                const int nd = homog ? 2 : min(P.n_dims[lo], P.n_dims[hi]);
+                const int nd = homog ? 2 : (dd < 32 ? (int)((nd_pack >> (2 * dd)) & 3ull) : min(P.n_dims[lo], P.n_dims[hi]));
                 lds[O.cpair + (par * ngrp + g) * np1 + pair_index(lo, hi, k)] =
                     pair_cost(sxs + lo * NS, sxs + hi * NS, nd, radius);
             }
@@ -481,7 +533,7 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
                 if (2 * dd == k && a >= dd) break;
                 const int o = a + dd < k ? a + dd : a + dd - k;
                 const int lo = a < o ? a : o, hi = a < o ? o : a;
-                const int nd = homog ? 2 : min(P.n_dims[lo], P.n_dims[hi]);
+                const int nd = homog ? 2 : (dd < 32 ? (int)((nd_pack >> (2 * dd)) & 3ull) : min(P.n_dims[lo], P.n_dims[hi]));
                 lds[O.cpair + (par * ngrp + g) * np1 + pair_index(lo, hi, k)] =
                     pair_cost(sxs + lo * NS, sxs + hi * NS, nd, radius);
             }
@@ -508,7 +560,12 @@ __device__ R horizon_pass(const dpilqr_batch_desc& D, const ItemParams& P, bool 
 // R: arithmetic type; KDIRECT: K[t] is not staged in LDS (large clusters); lds_per_item in elements of R.
 // the launcher's test for the matrix-pipe form of K[t] dx (KDIRECT, candidates / line-search mode): row tiles of 16 controls, at most
 // two per wavefront; the candidates are a tile's columns
-inline bool forward_on_pipe(int m, int threads, int ngrp) { return ((m + 15) / 16) <= 2 * (threads / 64) && ngrp <= 16; }
+// ... and the running cost's weights and goals fit the LDS the chunk buffers of the other form would take (horizon_pass: sWq)
+inline bool forward_on_pipe(int n, int m, int k, int threads, int ngrp) {
+    const ForwardLds O(n, m, k, ngrp, true);
+    const int ns = n / k, nc = m / k;
+    return ((m + 15) / 16) <= 2 * (threads / 64) && ngrp <= 16 && 2 * (O.cw * O.rs + 2) >= k * (ns * ns + 1 + nc * nc + ns);
+}
 
 template <typename R, int NS, int NC, bool KDIRECT, bool PIPE = false>
 __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(dpilqr_batch_desc D, int mode, const R* __restrict__ x0, R* X,

@@ -22,7 +22,7 @@ static int32_t launch_forward_big_t(const dpilqr_batch_desc& D, int mode, const 
     const size_t lds = (forward_lds_bytes(n, m, D.k, ngrp, true, sizeof(R)) + 15) & ~(size_t)15;
     // K[t] dx on the matrix pipe where every wavefront gets at most two row tiles (forward.hpp: forward_on_pipe) -- config 5's
     // shape and every cluster of the reference's families at ten candidates; a rollout has no gains
-    const bool pipe = mode != kModeRollout && forward_on_pipe(m, threads, ngrp);
+    const bool pipe = mode != kModeRollout && forward_on_pipe(n, m, D.k, threads, ngrp);
     DISPATCH_FAMILY(D.n_s, {
         if (pipe) {
             int32_t rc = allow_lds(k_forward<R, NS, NC, true, true>, lds);
