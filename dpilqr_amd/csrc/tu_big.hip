@@ -19,8 +19,12 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
     if (grid_items <= 0) return DPILQR_OK;
     const size_t lds = sizeof(R) * (size_t)BigLds(D.k, D.n_s, D.n_c).total;
     // Few items (config 5 is one problem): a team of workgroups per item, the helpers taking their share of S5 + S6's tile pairs
-    // (riccati_big.hpp, BigTeam) -- as many parts as give every wavefront at most one pair, as long as all of them fit the chip at
-    // one workgroup per CU.  DPILQR_BIG_TEAM=0 switches it off (A/B), =N sets the parts.
+    // (riccati_big.hpp, BigTeam).  Parts: round 5's rule was as many as give every wavefront at most one pair (nine at cfg5's size) --
+    // more only added hand-over cost.  With round 6's hand-overs (one acquire per workgroup, no L2 write-back inside an XCD) and
+    // more of the step on the team (S1's block pairs, the plugin stage, the substitution's tiles, S4) twice as many pay: one item
+    // 18.0 ms with 9 parts, 17.2 with 13, 16.2 - 16.5 from 16 to 30 (profiles/r06_big_parts.txt), so 2 x that + 2, at most 28 (a
+    // team stays inside one XCD's 32 CUs with a margin), as long as all teams fit the chip at one workgroup per CU.
+    // DPILQR_BIG_TEAM=0 switches it off (A/B), =N caps the parts.
     const int n = D.k * D.n_s, m = D.k * D.n_c;
     const BigScratch S(n, m);
     int nparts = 1;
@@ -29,7 +33,8 @@ static int32_t launch_riccati_big_t(const dpilqr_batch_desc& D, const R* X, cons
         const int cus = device_cus();      // of the CURRENT device (remembered per device id)
         const int tn = (n + 1 + 15) / 16, npair = tn * (tn + 1) / 2, waves = kBigThreads / 64;
         const int slots8 = ((grid_items + 7) / 8) * 8;
-        nparts = (npair + waves - 1) / waves;
+        nparts = 2 * ((npair + waves - 1) / waves) + 2;
+        if (nparts > 28) nparts = 28;
         if (nparts > cus / slots8) nparts = cus / slots8;
         // (a debug route: null in a process without DPILQR_DEBUG_ROUTES=1, where nothing is read from the environment here; with
         // the gate open the tests switch it from launch to launch)
