@@ -66,7 +66,10 @@ template <> struct Mfma<float> {
     __device__ static constexpr int group_of(int row) { return row / 4; }
 };
 
-// the value lane `src` holds (ds_bpermute: any lane to any lane)
+// the value lane `src` holds (ds_bpermute: any lane to any lane).  (Measured and dropped, round 6: for the substitution's broadcasts --
+// the same lane of another 16-lane row -- gfx950's row swaps, v_permlane32_swap + v_permlane16_swap on two copies of the value
+// (semantics: scripts/ubench/permlane_swap.hip), instead of the trip through the LDS crossbar: bit-identical and SLOWER, the
+// substitution 61 k -> 68 k clocks per step, 256 items 55.7 -> 57.5 ms.)
 __device__ __forceinline__ double lane_bcast(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)));
 }
