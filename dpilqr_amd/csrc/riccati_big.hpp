@@ -665,8 +665,18 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
         // ascending order).  The multipliers are stored as such (the column form stored a and scaled at the end).
         // (The column form with its look-ahead wavefront: -DDPILQR_BIG_LU_COLUMN, A/B builds.  Round 5's blocked attempt -- sixteen-
         // column panels, the trailing block on the vector pipe one thread per row -- was slower than the column form.)
-        for (int K0 = 0; K0 < m; K0 += 4) {
-            const int nbp = min(4, m - K0), base = K0 + nbp;
+        // Panel WIDTH (later in round 6): eight columns -- two chained products per trailing tile -- wherever the panel's rows fit
+        // one row per lane (m - K0 <= 64: every panel but the first sixteen columns' at n_u = 80; with two rows per lane the
+        // eight-column panel does not fit the 128 registers a 1024-thread workgroup has): twelve trailing updates and 24 barriers
+        // per factorisation instead of twenty and 40, and what a trailing update costs is its tiles' trips through LDS, not the
+        // product.  A column's eliminations reach every entry in the same order either way -- inside the panel's registers, or
+        // as reduction rows 0 .. 3 then 4 .. 7 of the chained products: bit-identical factors (-DDPILQR_BIG_LU_PANEL4: all
+        // panels four wide, A/B builds).
+        // (one loop per width, the width a compile-time constant in each: with the width a run-time value of ONE loop the kernel
+        // spilled 107 registers)
+        auto lu_step = [&](const int K0, auto pw_c) __attribute__((always_inline)) {
+            constexpr int pw = decltype(pw_c)::value;
+            const int nbp = min(pw, m - K0), base = K0 + nbp;
 #ifdef DPILQR_PHASE_STAMPS
             const unsigned long long lu_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -675,33 +685,40 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 // exchange (the row at position K0 + j takes the pivot's old position), a pivot row simply stops taking part.
                 // The arg-max works on the magnitudes' bit patterns (unsigned keys order like the magnitudes): the high words'
                 // wave maximum, then the low words' among the lanes that hold it -- integer DPP reductions --, then a ballot.
-                // Two instantiations: rows K0 .. K0 + 63 only (every panel but the first four at n_u = 80), or a second row per lane.
-                auto panel = [&](auto two_tag) __attribute__((always_inline)) {
+                // Instantiations: rows K0 .. K0 + 63 only (PW 4 or 8), or a second row per lane (PW 4).
+                auto panel = [&](auto two_tag, auto pw_tag) __attribute__((always_inline)) {
                     constexpr bool TWO = decltype(two_tag)::value;
+                    constexpr int PW = decltype(pw_tag)::value;
                     const int p0 = K0 + lane, p1 = p0 + 64;
                     const bool in0 = p0 < m, in1 = TWO && p1 < m;
                     const int r0 = sPerm[min(p0, mk - 1)], r1 = TWO ? sPerm[min(p1, mk - 1)] : 0;
                     int pos0 = p0, pos1 = p1;
                     bool act0 = in0, act1 = in1;
-                    R a0[4], a1[4];
+                    R a0[PW], a1[TWO ? PW : 1];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < PW; ++j) {
                         a0[j] = (in0 && j < nbp) ? sLU[r0 * ldlu + K0 + j] : (R)0.0;
-                        a1[j] = (in1 && j < nbp) ? sLU[r1 * ldlu + K0 + j] : (R)0.0;
+                        if (TWO) a1[j] = (in1 && j < nbp) ? sLU[r1 * ldlu + K0 + j] : (R)0.0;
                     }
-                    int pvl[4] = {0, 0, 0, 0};                            // the pivots: lane | chunk << 6 (the same in every lane)
+                    int pvl[PW];                            // the pivots: lane | chunk << 6 (the same in every lane)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < PW; ++j) pvl[j] = 0;
+#pragma unroll
+                    for (int j = 0; j < PW; ++j) {
                         if (j >= nbp) break;
-                        const R x0 = a0[j], x1 = a1[j];
+                        const R x0 = a0[j], x1 = TWO ? a1[j] : (R)0.0;
                         // every lane divides for ITS candidate while the maximum is being found: the pivot's reciprocal is then
                         // one lane read away (the division, a dozen dependent instructions, used to follow the search)
-                        R i0 = (x0 == (R)0.0) ? (R)0.0 : (R)1.0 / x0;
-                        R i1 = TWO ? ((x1 == (R)0.0) ? (R)0.0 : (R)1.0 / x1) : (R)0.0;
-                        // (pinned HERE: the compiler otherwise sinks the divisions behind the search, into the branch that picks the
-                        // pivot's chunk -- back onto the column's critical path)
-                        asm volatile("" : "+v"(i0));
-                        if (TWO) asm volatile("" : "+v"(i1));
+                        constexpr bool EARLY = true;
+                        R i0 = (R)0.0, i1 = (R)0.0;
+                        if constexpr (EARLY) {
+                            i0 = (x0 == (R)0.0) ? (R)0.0 : (R)1.0 / x0;
+                            i1 = TWO ? ((x1 == (R)0.0) ? (R)0.0 : (R)1.0 / x1) : (R)0.0;
+                            // (pinned HERE: the compiler otherwise sinks the divisions behind the search, into the branch that picks the
+                            // pivot's chunk -- back onto the column's critical path)
+                            asm volatile("" : "+v"(i0));
+                            if (TWO) asm volatile("" : "+v"(i1));
+                        }
                         unsigned h0, l0k, h1 = 0u, l1k = 0u;
                         mag_keys(x0, h0, l0k);
                         if (TWO) mag_keys(x1, h1, l1k);
@@ -752,7 +769,13 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         const bool me = lane == pl;
                         if (TWO && pc) { pos1 = me ? K0 + j : pos1; act1 = act1 && !me; }
                         else { pos0 = me ? K0 + j : pos0; act0 = act0 && !me; }
-                        const R inv = (TWO && pc) ? lane_get(i1, pl) : lane_get(i0, pl);      // (pv == 0) ? 0 : 1 / pv, the pivot lane's own
+                        R inv;      // (pv == 0) ? 0 : 1 / pv
+                        if constexpr (EARLY) {
+                            inv = (TWO && pc) ? lane_get(i1, pl) : lane_get(i0, pl);      // the pivot lane's own
+                        } else {
+                            const R pv = lane_get(x0, pl);      // (a value every lane holds: the same division, the same bits)
+                            inv = (pv == (R)0.0) ? (R)0.0 : (R)1.0 / pv;
+                        }
                         if (lane == 0) {
                             if (!ok) sFlag[0] = 1;            // zero (or NaN) pivot: np.linalg.solve would raise
                             sInv[K0 + j] = inv;
@@ -764,7 +787,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         R m1 = (R)0.0;
                         if (TWO) { a1[j] = act1 ? x1 * inv : x1; m1 = act1 ? a1[j] : (R)0.0; }
 #pragma unroll
-                        for (int jj = j + 1; jj < 4; ++jj) {
+                        for (int jj = j + 1; jj < PW; ++jj) {
                             const R prj = (TWO && pc) ? lane_get(a1[jj], pl) : lane_get(a0[jj], pl);
                             a0[jj] = fma(-m0, prj, a0[jj]);
                             if (TWO) a1[jj] = fma(-m1, prj, a1[jj]);
@@ -773,51 +796,82 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                     if (in0) sPerm[pos0] = r0;
                     if (in1) sPerm[pos1] = r1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < PW; ++j) {
                         if (in0 && j < nbp) sLU[r0 * ldlu + K0 + j] = a0[j];
-                        if (in1 && j < nbp) sLU[r1 * ldlu + K0 + j] = a1[j];
+                        if (TWO && in1 && j < nbp) sLU[r1 * ldlu + K0 + j] = a1[j];
                     }
-                    // (B) the panel's rows of U right of it: column c of the pivot rows R_1 .. R_3 takes the eliminations of the
-                    // panel's earlier columns
-                    int Rr[4];
-                    auto of_pivot = [&](int j_, R v0, R v1) -> R {
-                        return (TWO && (pvl[j_] >> 6)) ? lane_get(v1, pvl[j_] & 63) : lane_get(v0, pvl[j_] & 63);
-                    };
+                    // (B) the panel's rows of U right of it: column c of the pivot rows R_1 .. R_PW-1 takes the eliminations of the
+                    // panel's earlier columns, in their order.  The multipliers -- pivot row j's entries of the panel's columns
+                    // before j -- are read where the loop above has just put them (one address for the wavefront: a broadcast)
+                    int Rr[PW];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < PW; ++j)
                         Rr[j] = ((TWO && (pvl[j] >> 6)) ? __builtin_amdgcn_readlane(r1, pvl[j] & 63) : __builtin_amdgcn_readlane(r0, pvl[j] & 63)) * ldlu;
-                    R lmq[6];      // l10, l20, l21, l30, l31, l32: pivot row j's multipliers of the columns before it
-                    lmq[0] = of_pivot(1, a0[0], a1[0]); lmq[1] = of_pivot(2, a0[0], a1[0]); lmq[2] = of_pivot(2, a0[1], a1[1]);
-                    lmq[3] = of_pivot(3, a0[0], a1[0]); lmq[4] = of_pivot(3, a0[1], a1[1]); lmq[5] = of_pivot(3, a0[2], a1[2]);
-                    for (int c = base + lane; c < m; c += 64) {
-                        const R u0 = sLU[Rr[0] + c];
-                        if (nbp > 1) {
-                            const R u1 = fma(-lmq[0], u0, sLU[Rr[1] + c]);
-                            sLU[Rr[1] + c] = u1;
-                            if (nbp > 2) {
-                                const R u2 = fma(-lmq[2], u1, fma(-lmq[1], u0, sLU[Rr[2] + c]));
-                                sLU[Rr[2] + c] = u2;
-                                if (nbp > 3) sLU[Rr[3] + c] = fma(-lmq[5], u2, fma(-lmq[4], u1, fma(-lmq[3], u0, sLU[Rr[3] + c])));
+                    if constexpr (PW == 4) {
+                        auto of_pivot = [&](int j_, R v0, R v1) -> R {
+                            return (TWO && (pvl[j_] >> 6)) ? lane_get(v1, pvl[j_] & 63) : lane_get(v0, pvl[j_] & 63);
+                        };
+                        R lmq[6];      // l10, l20, l21, l30, l31, l32: pivot row j's multipliers of the columns before it
+                        lmq[0] = of_pivot(1, a0[0], TWO ? a1[0] : (R)0.0); lmq[1] = of_pivot(2, a0[0], TWO ? a1[0] : (R)0.0); lmq[2] = of_pivot(2, a0[1], TWO ? a1[1] : (R)0.0);
+                        lmq[3] = of_pivot(3, a0[0], TWO ? a1[0] : (R)0.0); lmq[4] = of_pivot(3, a0[1], TWO ? a1[1] : (R)0.0); lmq[5] = of_pivot(3, a0[2], TWO ? a1[2] : (R)0.0);
+                        for (int c = base + lane; c < m; c += 64) {
+                            const R u0 = sLU[Rr[0] + c];
+                            if (nbp > 1) {
+                                const R u1 = fma(-lmq[0], u0, sLU[Rr[1] + c]);
+                                sLU[Rr[1] + c] = u1;
+                                if (nbp > 2) {
+                                    const R u2 = fma(-lmq[2], u1, fma(-lmq[1], u0, sLU[Rr[2] + c]));
+                                    sLU[Rr[2] + c] = u2;
+                                    if (nbp > 3) sLU[Rr[3] + c] = fma(-lmq[5], u2, fma(-lmq[4], u1, fma(-lmq[3], u0, sLU[Rr[3] + c])));
+                                }
+                            }
+                        }
+                    } else {
+                        for (int c = base + lane; c < m; c += 64) {
+                            R u[PW];
+#pragma unroll
+                            for (int j = 0; j < PW; ++j) u[j] = sLU[Rr[j < nbp ? j : 0] + c];
+#pragma unroll
+                            for (int j = 1; j < PW; ++j) {
+                                if (j >= nbp) break;
+                                R t_ = u[j];
+#pragma unroll
+                                for (int i = 0; i < j; ++i) t_ = fma(-sLU[Rr[j] + K0 + i], u[i], t_);
+                                u[j] = t_;
+                                sLU[Rr[j] + c] = t_;
+                                asm volatile("" ::: "memory");      // (row j + 1's multipliers are not requested before row j is done)
                             }
                         }
                     }
                 };
-                if ((m - K0) > 64) panel(std::true_type{});
-                else panel(std::false_type{});
+                if constexpr (pw == 4) {
+                    if ((m - K0) > 64) panel(std::true_type{}, std::integral_constant<int, 4>{});
+                    else panel(std::false_type{}, std::integral_constant<int, 4>{});
+                } else {
+                    panel(std::false_type{}, std::integral_constant<int, 8>{});
+                }
             }
 #ifdef DPILQR_PHASE_STAMPS
             bph[5] += __builtin_amdgcn_s_memtime() - lu_t0;      // (slot 5, "S5": the panels, wave 0's clock)
 #endif
             __syncthreads();
-            // (C) the trailing block: positions and columns from `base` on, 16 x 16 tiles dealt to the wavefronts
+            // (C) the trailing block: positions and columns from `base` on, 16 x 16 tiles dealt to the wavefronts; an eight-column
+            // panel is two chained products, reduction rows K0 .. K0 + 3 first
             if (base < m) {
                 const int tb = base >> 4, nt = ((m + 15) >> 4) - tb;
                 for (int tl = wave; tl < nt * nt; tl += kBigThreads / 64) {
                     const int it = tb + tl / nt, jt = tb + tl - (tl / nt) * nt;
                     const int pos_a = 16 * it + c16, col = 16 * jt + c16;
-                    const bool red = g16 < nbp;
-                    const R a = (red && pos_a >= base && pos_a < m) ? -sLU[sPerm[pos_a] * ldlu + K0 + g16] : (R)0.0;
-                    const R b = (red && col >= base && col < m) ? sLU[sPerm[K0 + (red ? g16 : 0)] * ldlu + col] : (R)0.0;
+                    const bool red = g16 < nbp, red2 = g16 + 4 < nbp;
+                    const bool va = pos_a >= base && pos_a < m, vb = col >= base && col < m;
+                    const int ra = sPerm[min(pos_a, mk - 1)] * ldlu + K0;
+                    const R a = (red && va) ? -sLU[ra + g16] : (R)0.0;
+                    const R b = (red && vb) ? sLU[sPerm[K0 + (red ? g16 : 0)] * ldlu + min(col, mk - 1)] : (R)0.0;
+                    R a2 = (R)0.0, b2 = (R)0.0;
+                    if constexpr (pw == 8) {
+                        a2 = (red2 && va) ? -sLU[ra + (red2 ? g16 + 4 : 0)] : (R)0.0;
+                        b2 = (red2 && vb) ? sLU[sPerm[K0 + (red2 ? g16 + 4 : 0)] * ldlu + min(col, mk - 1)] : (R)0.0;
+                    }
                     acc_t cc;
                     int rw[4];
 #pragma unroll
@@ -827,6 +881,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                         cc[v] = sLU[rw[v]];
                     }
                     cc = Mfma<R>::mac(a, b, cc);
+                    if constexpr (pw == 8) cc = Mfma<R>::mac(a2, b2, cc);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int pos = 16 * it + Mfma<R>::row(v, g16);
@@ -835,6 +890,15 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
                 }
             }
             __syncthreads();
+        };
+        {
+            int K0 = 0;
+#ifdef DPILQR_BIG_LU_PANEL4
+            for (; K0 < m; K0 += 4) lu_step(K0, std::integral_constant<int, 4>{});
+#else
+            for (; K0 < m && (m - K0) > 64; K0 += 4) lu_step(K0, std::integral_constant<int, 4>{});
+            for (; K0 < m; K0 += 8) lu_step(K0, std::integral_constant<int, 8>{});
+#endif
         }
 #elif !defined(DPILQR_BIG_LU_PLAIN)
         // With LOOK-AHEAD (round 3): while fifteen wavefronts apply column kk's eliminations to the columns from kk + 2 on, the
