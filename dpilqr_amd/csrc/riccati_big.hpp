@@ -896,6 +896,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #ifdef DPILQR_BIG_LU_PANEL4
             for (; K0 < m; K0 += 4) lu_step(K0, std::integral_constant<int, 4>{});
 #else
+            // (eight wide with two rows per lane too: 107 spilled registers)
             for (; K0 < m && (m - K0) > 64; K0 += 4) lu_step(K0, std::integral_constant<int, 4>{});
             for (; K0 < m; K0 += 8) lu_step(K0, std::integral_constant<int, 8>{});
 #endif
