@@ -66,6 +66,21 @@ template <> struct Mfma<float> {
     __device__ static constexpr int group_of(int row) { return row / 4; }
 };
 
+// An fp32 16x16x4 accumulator (lane (g, c): rows 4 g + v of column c in register v) into the fp64 instruction's arrangement (rows
+// g + 4 v), which is also the matrix pipe's OPERAND arrangement (lane group g supplies reduction row 4 q + g at step q): a 4 x 4
+// transposition between the registers and the 16-lane rows, four of gfx950's row swaps (v_permlane32_swap exchanges rows 2, 3 of
+// its first operand with rows 0, 1 of its second, v_permlane16_swap rows 1, 3 with rows 0, 2: scripts/ubench/permlane_swap.hip).
+// With it a product's result is the next product's operand without leaving the registers in fp32 too (riccati_big_s1.inc).
+__device__ __forceinline__ void mfma_rows_to_operand_order(float __attribute__((ext_vector_type(4)))& t) {
+    unsigned r0 = __float_as_uint(t[0]), r1 = __float_as_uint(t[1]), r2 = __float_as_uint(t[2]), r3 = __float_as_uint(t[3]);
+    const auto a = __builtin_amdgcn_permlane32_swap(r0, r2, false, false); r0 = a[0]; r2 = a[1];
+    const auto b = __builtin_amdgcn_permlane32_swap(r1, r3, false, false); r1 = b[0]; r3 = b[1];
+    const auto c = __builtin_amdgcn_permlane16_swap(r0, r1, false, false); r0 = c[0]; r1 = c[1];
+    const auto d = __builtin_amdgcn_permlane16_swap(r2, r3, false, false); r2 = d[0]; r3 = d[1];
+    t[0] = __uint_as_float(r0); t[1] = __uint_as_float(r1); t[2] = __uint_as_float(r2); t[3] = __uint_as_float(r3);
+}
+__device__ __forceinline__ void mfma_rows_to_operand_order(double __attribute__((ext_vector_type(4)))&) {}      // (fp64: it is that order)
+
 // the value lane `src` holds (ds_bpermute: any lane to any lane).  (Measured and dropped, round 6: for the substitution's broadcasts --
 // the same lane of another 16-lane row -- gfx950's row swaps, v_permlane32_swap + v_permlane16_swap on two copies of the value
 // (semantics: scripts/ubench/permlane_swap.hip), instead of the trip through the LDS crossbar: bit-identical and SLOWER, the
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
 #ifdef DPILQR_BIG_TEAM_S1_ALL
     constexpr bool kTeamS1 = true;
 #else
-    constexpr bool kTeamS1 = (sizeof(R) == 8 && NS == 12 && NC == 4);
+    constexpr bool kTeamS1 = (NS == 12 && NC == 4);
 #endif
     constexpr bool kTeamSolve = kTeamS1 || (NS == 12 && NC == 4);      // ... and the substitution's column tiles (round 6; twelve-state clusters, either type)
     int coop = 0;      // 1: this pass is run by the team
