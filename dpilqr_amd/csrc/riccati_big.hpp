@@ -604,8 +604,10 @@ __global__ __launch_bounds__(kBigThreads) void k_riccati_big(dpilqr_batch_desc D
     for (int t = T - 1; t >= 0; --t) {
         if (kTeamS1 && coop && staged_ok) {
             // the team's part 1 has evaluated this step's plugin data while this workgroup factorised and substituted (the helper
-            // loop above): they are loaded, not made
-            if (!big_wait_ge(&team->staged, T - t, &sFlag[2], spin_log2)) { gave_up(); return; }
+            // loop above): they are loaded, not made.  No wait of its own (later in round 6): part 1 stores the data and raises
+            // `staged` BEFORE it arrives at the previous step's `done`, which this workgroup has just acquired -- whatever a part did
+            // before that arrival is visible here -- so a poll, an acquire and a barrier per step (~3 k clocks) told nothing new.
+            // (`staged` itself remains for part 1's own bookkeeping and the give-up path.)
             const R* gS = gStage + (int64_t)(t & 1) * S.stage_elems;
             int tid_c = threadIdx.x;
             asm volatile("" : "+v"(tid_c));
