@@ -580,8 +580,35 @@ __global__ __launch_bounds__(256, (KDIRECT || NS >= 12) ? 1 : 2) void k_forward(
     if (slot >= (n_items ? *n_items : D.B)) return;
     const int b = items ? items[slot] : slot;
     const int k = D.k, T = D.T, n = k * NS, m = k * NC;
-    const int g = tid / k, a = tid - g * k;
+    int g = tid / k, a = tid - g * k;
     const ItemParams P = item_params(D, b);
+    if constexpr (KDIRECT) {
+        // Heterogeneous clusters (config 5: fourteen twelve-state quadcopters + six padded humans), candidates / line-search mode: a
+        // wavefront that holds agents of BOTH models runs both models' integration one after the other, every step (the lanes of one
+        // take no part in the other's).  Lanes dealt by CLASS instead -- the agents that share agent 0's model first, candidate by
+        // candidate, padded to a wavefront boundary, then the others -- make every wavefront homogeneous where the padded layout
+        // fits the workgroup (cfg5: 140 lanes in three wavefronts, 60 in the fourth).  Only which lane computes which (candidate,
+        // agent) changes: same arithmetic, same results.  Round 6; the rollout's 64 threads and clusters of one model keep the plain deal.
+        const int k0 = P.model[0];
+        int nA = 0;
+        for (int i = 0; i < k; ++i) nA += P.model[i] == k0;
+        const int groups_ = mode == kModeRollout ? 1 : ngrp;
+        const int lanesA = groups_ * nA, lanesB = groups_ * (k - nA), baseB = ((lanesA + 63) / 64) * 64;
+        if (ipb == 1 && nA < k && baseB + lanesB <= nth) {
+            const bool inB = tid >= baseB;
+            const int idx = inB ? tid - baseB : tid, nC = inB ? k - nA : nA;
+            const bool on = idx < (inB ? lanesB : lanesA);
+            const int gi = idx / nC, ai = idx - gi * nC;
+            int cnt = 0, ag = 0;      // the ai-th agent of the lane's class
+            for (int i = 0; i < k; ++i) {
+                const bool mine = (P.model[i] == k0) != inB;
+                if (mine && cnt == ai) ag = i;
+                cnt += mine;
+            }
+            g = on ? gi : groups_;      // (a lane of the padding: no candidate)
+            a = on ? ag : 0;
+        }
+    }
     const bool homog = homogeneous_ndims(P.n_dims, k);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R* lds = reinterpret_cast<R*>(lds_raw) + (size_t)sub * lds_per_item;
